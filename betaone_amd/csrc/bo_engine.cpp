@@ -1,0 +1,467 @@
+// betaone_amd/csrc/bo_engine.cpp -- host side of the C ABI (include/betaone_engine.h).
+// Compiled by hipcc for gfx950 into libbetaone_hip.so together with the kernels in bo_tree.h.
+// No torch types, no chess logic on the host: FEN / UCI text is parsed into plain bitboards and
+// everything else (replaying the move stack, keys, legality, draw rules) happens on the device.
+#include "../../include/betaone_engine.h"
+
+#include "bo_tree.h"
+#include "bo_select_wide.h"
+#include "bo_rt.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define RT(call)                                                                                     \
+    do {                                                                                             \
+        int _rc = (call);                                                                            \
+        if (_rc != 0) return fail(BO_E_HIP, std::string(#call) + ": " + rt_errstr(_rc));             \
+    } while (0)
+
+struct bo_engine {
+    Eng d;
+    bo_config cfg;
+    int device;
+    std::vector<void *> allocs;
+    int *d_go = nullptr, *d_action = nullptr;
+    std::vector<int> h_i32;  // scratch [G]
+    template <class T> int alloc(T **p, size_t n) {
+        void *v = nullptr;
+        int rc = rt_malloc(&v, n * sizeof(T));
+        if (rc) return rc;
+        allocs.push_back(v);
+        *p = (T *)v;
+        return 0;
+    }
+};
+
+extern "C" int bo_abi_version(void) { return BO_ABI_VERSION; }
+extern "C" const char *bo_last_error(void) { return g_err.c_str(); }
+
+// ---- text -> plain data (host) ---------------------------------------------------------------------
+static const char *START_FEN = "rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR w KQkq - 0 1";
+
+static bool parse_fen(const char *fen, DPos *out) {
+    memset(out, 0, sizeof(*out));
+    const char *s = fen;
+    while (*s == ' ') s++;
+    int r = 7, f = 0;
+    for (; *s && *s != ' '; s++) {
+        char c = *s;
+        if (c == '/') { r--; f = 0; continue; }
+        if (c >= '1' && c <= '8') { f += c - '0'; continue; }
+        int white = (c >= 'A' && c <= 'Z');
+        char l = (char)(white ? c - 'A' + 'a' : c);
+        int t = l == 'p' ? 0 : l == 'n' ? 1 : l == 'b' ? 2 : l == 'r' ? 3 : l == 'q' ? 4 : l == 'k' ? 5 : -1;
+        if (t < 0 || r < 0 || f > 7) return false;
+        out->bb[t] |= BIT(r * 8 + f);
+        out->bb[white ? BB_WHITE : BB_BLACK] |= BIT(r * 8 + f);
+        f++;
+    }
+    int turn = 1, ep = -1, half = 0, full = 1;
+    uint32_t cr = 0;
+    while (*s == ' ') s++;
+    if (*s) { if (*s == 'w') turn = 1; else if (*s == 'b') turn = 0; else return false; s++; }
+    while (*s == ' ') s++;
+    for (; *s && *s != ' '; s++) {
+        if (*s == 'K') cr |= 0x02u; else if (*s == 'Q') cr |= 0x04u; else if (*s == 'k') cr |= 0x08u;
+        else if (*s == 'q') cr |= 0x10u; else if (*s != '-') return false;
+    }
+    // python-chess clean_castling_rights(): rook on its corner, king on e1/e8
+    const uint64_t wk = out->bb[BB_K] & out->bb[BB_WHITE] & BIT(4), bk = out->bb[BB_K] & out->bb[BB_BLACK] & BIT(60);
+    const uint64_t wr = out->bb[BB_R] & out->bb[BB_WHITE], br = out->bb[BB_R] & out->bb[BB_BLACK];
+    if (!wk || !(wr & BIT(7))) cr &= ~0x02u;
+    if (!wk || !(wr & BIT(0))) cr &= ~0x04u;
+    if (!bk || !(br & BIT(63))) cr &= ~0x08u;
+    if (!bk || !(br & BIT(56))) cr &= ~0x10u;
+    while (*s == ' ') s++;
+    if (*s) {
+        if (*s != '-') {
+            if (s[0] < 'a' || s[0] > 'h' || s[1] < '1' || s[1] > '8') return false;
+            ep = (s[1] - '1') * 8 + (s[0] - 'a');
+            s += 2;
+        } else s++;
+    }
+    while (*s == ' ') s++;
+    if (*s) half = (int)strtol(s, (char **)&s, 10);
+    while (*s == ' ') s++;
+    if (*s) full = (int)strtol(s, (char **)&s, 10);
+    if (full < 1) full = 1;
+    out->flags = (turn ? F_TURN : 0u) | cr | ((uint32_t)(ep + 1) << F_EP_SHIFT);
+    out->halfmove = half;
+    out->fullmove = full;
+    return true;
+}
+
+static bool parse_uci_moves(const char *s, std::vector<bo_mv> *out) {
+    out->clear();
+    if (!s) return true;
+    while (*s) {
+        while (*s == ' ') s++;
+        if (!*s) break;
+        const char *b = s;
+        while (*s && *s != ' ') s++;
+        size_t n = (size_t)(s - b);
+        if (n < 4 || n > 5) return false;
+        if (b[0] < 'a' || b[0] > 'h' || b[2] < 'a' || b[2] > 'h' || b[1] < '1' || b[1] > '8' || b[3] < '1' || b[3] > '8') return false;
+        int from = (b[1] - '1') * 8 + (b[0] - 'a'), to = (b[3] - '1') * 8 + (b[2] - 'a'), promo = 0;
+        if (n == 5) {
+            promo = b[4] == 'n' ? 2 : b[4] == 'b' ? 3 : b[4] == 'r' ? 4 : b[4] == 'q' ? 5 : -1;
+            if (promo < 0) return false;
+        }
+        out->push_back(MV(from, to, promo));
+    }
+    return true;
+}
+
+static DPos from_abi(const bo_position &p) {
+    DPos d;
+    memset(&d, 0, sizeof(d));
+    for (int i = 0; i < 8; i++) d.bb[i] = p.bb[i];
+    d.flags = (p.turn ? F_TURN : 0u) | ((p.castling & 0xFu) << F_CASTLE_SHIFT) | ((uint32_t)(p.ep_square + 1) << F_EP_SHIFT);
+    if (p.ep_key >= 0) d.flags |= (uint32_t)(p.ep_key + 1) << F_EPKEY_SHIFT;
+    // ep_key == -1 means "the key has no ep component": drop the raw square so finish_key() does not re-derive it
+    if (p.ep_key == -1) d.flags &= ~F_EP_MASK;
+    d.halfmove = p.halfmove_clock;
+    d.fullmove = p.fullmove_number;
+    return d;
+}
+static void to_abi(const DPos &d, bo_position *p) {
+    for (int i = 0; i < 8; i++) p->bb[i] = d.bb[i];
+    p->turn = (int)(d.flags & F_TURN);
+    p->castling = (d.flags & F_CASTLE_MASK) >> F_CASTLE_SHIFT;
+    p->ep_square = (int)((d.flags & F_EP_MASK) >> F_EP_SHIFT) - 1;
+    p->ep_key = (int)((d.flags & F_EPKEY_MASK) >> F_EPKEY_SHIFT) - 1;
+    p->halfmove_clock = d.halfmove;
+    p->fullmove_number = d.fullmove;
+}
+
+// ---- create / destroy -------------------------------------------------------------------------------
+extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **out) {
+    if (!cfg || !out) return fail(BO_E_ARG, "null argument");
+    if (cfg->n_games < 1 || cfg->num_simulations < 0 || cfg->mcts_batch_size < 1 || cfg->max_plies < 2)
+        return fail(BO_E_ARG, "n_games/num_simulations/mcts_batch_size/max_plies out of range");
+    const int root_m = (int)(cfg->widen_coeff * sqrt(1.0));
+    const int ch_max = (int)(cfg->widen_coeff * sqrt((double)cfg->mcts_batch_size));
+    if (cfg->widen_coeff < 1.0 || ch_max > BO_CH_CAP)
+        return fail(BO_E_CONFIG, "WIDEN_COEFF must be >= 1 and int(WIDEN_COEFF*sqrt(MCTS_BATCH_SIZE)) <= 32");
+    RT(rt_set_device(device));
+    bo_engine *e = new bo_engine();
+    e->cfg = *cfg;
+    e->device = device;
+    EngCfg &c = e->d.c;
+    c.G = cfg->n_games; c.S = cfg->num_simulations; c.B = cfg->mcts_batch_size;
+    c.NCAP = c.S + 2 * root_m + 4;
+    c.PLY_CAP = cfg->max_plies; c.TRK_CAP = cfg->max_plies;
+    c.UL_MAX = c.B; c.CH_MAX = ch_max < 1 ? 1 : ch_max;
+    c.cpuct = (float)cfg->cpuct;
+    c.keep = (float)(1.0 - cfg->dirichlet_epsilon);
+    c.eps = cfg->dirichlet_epsilon;
+    c.use_noise = cfg->dirichlet_alpha > 0 ? 1 : 0;
+    c.root_m = root_m;
+    const size_t G = (size_t)c.G, N = G * (size_t)c.NCAP;
+    Eng &d = e->d;
+    int rc = 0;
+    float *sq = nullptr; int *wl = nullptr;
+    rc |= e->alloc(&sq, (size_t)c.S + 2); rc |= e->alloc(&wl, (size_t)c.B + 1);
+    int **iscal[] = {&d.phase, &d.sims_done, &d.n_nodes, &d.rows, &d.n_runs, &d.n_ul, &d.req_node, &d.req_nlegal, &d.status,
+                     &d.ply, &d.trk_n, &d.n_hist, &d.ctx_mode, &d.root_nlegal, &d.root_term, &d.root_nch, &d.stat_evals,
+                     &d.stat_flushes, &d.stat_term_sims, &d.stat_levels, &d.stat_children_scanned, &d.res_n,
+                     &d.res_best_idx, &d.res_best_mv, &d.res_total, &e->d_go, &e->d_action};
+    for (int **p : iscal) rc |= e->alloc(p, G);
+    rc |= e->alloc(&d.gpos, G * c.PLY_CAP); rc |= e->alloc(&d.trk, G * c.TRK_CAP); rc |= e->alloc(&d.trk_cnt, G * c.TRK_CAP);
+    rc |= e->alloc(&d.hist, G * 7);
+    rc |= e->alloc(&d.n_visits, N); rc |= e->alloc(&d.parent, N); rc |= e->alloc(&d.first_child, N); rc |= e->alloc(&d.n_children, N);
+    rc |= e->alloc(&d.q, N); rc |= e->alloc(&d.prior, N); rc |= e->alloc(&d.move, N); rc |= e->alloc(&d.term, N);
+    rc |= e->alloc(&d.eval_slot, N); rc |= e->alloc(&d.npos, N);
+    rc |= e->alloc(&d.run_leaf, G * c.B); rc |= e->alloc(&d.run_cnt, G * c.B);
+    rc |= e->alloc(&d.ul_node, G * c.UL_MAX); rc |= e->alloc(&d.ul_nlegal, G * c.UL_MAX); rc |= e->alloc(&d.ul_value, G * c.UL_MAX);
+    rc |= e->alloc(&d.ul_move, G * c.UL_MAX * BO_CH_CAP); rc |= e->alloc(&d.ul_prior, G * c.UL_MAX * BO_CH_CAP);
+    rc |= e->alloc(&d.req_moves, G * BO_MAX_MOVES); rc |= e->alloc(&d.root_moves, G * BO_MAX_MOVES);
+    rc |= e->alloc(&d.root_child_rank, G * 2 * BO_CH_CAP); rc |= e->alloc(&d.noise, G * BO_MAX_MOVES);
+    rc |= e->alloc(&d.played, G * c.PLY_CAP);
+    rc |= e->alloc(&d.res_idx, G * BO_RES_CAP); rc |= e->alloc(&d.res_val, G * BO_RES_CAP);
+    if (rc) { bo_engine_destroy(e); return fail(BO_E_HIP, "device allocation failed"); }
+    // host-built lookup tables: Python's math.sqrt / int() in double, rounded to binary32 once
+    std::vector<float> hs((size_t)c.S + 2);
+    for (int n = 0; n < c.S + 2; n++) hs[n] = (float)sqrt((double)n + 1e-8);  // mcts.py:93
+    std::vector<int> hw((size_t)c.B + 1);
+    for (int k = 0; k <= c.B; k++) hw[k] = (int)(cfg->widen_coeff * sqrt((double)k));  // mcts.py:55-57 with n_visits+1 == k
+    rt_h2d(sq, hs.data(), hs.size() * sizeof(float), nullptr);
+    rt_h2d(wl, hw.data(), hw.size() * sizeof(int), nullptr);
+    d.sqrt_lut = sq; d.widen_lut = wl;
+    for (int **p : iscal) rt_memset(*p, 0, G * sizeof(int), nullptr);
+    rt_memset(d.noise, 0, G * BO_MAX_MOVES * sizeof(double), nullptr);
+    rt_sync(nullptr);
+    e->h_i32.resize(G);
+    *out = e;
+    return BO_OK;
+}
+
+extern "C" void bo_engine_destroy(bo_engine *e) {
+    if (!e) return;
+    rt_set_device(e->device);
+    for (void *p : e->allocs) rt_free(p);
+    delete e;
+}
+
+// ---- set-up ---------------------------------------------------------------------------------------------
+extern "C" int bo_games_reset_ex(bo_engine *e, int n, const int32_t *slots, const char *const *fens, const char *const *moves,
+                                 const bo_position *hist, const int32_t *n_hist, const bo_position *trk,
+                                 const int32_t *trk_counts, const int32_t *trk_off, void *stream) {
+    if (!e || n < 1 || !slots) return fail(BO_E_ARG, "bad arguments");
+    const EngCfg &c = e->d.c;
+    std::vector<DPos> start((size_t)n);
+    std::vector<std::vector<bo_mv>> mv((size_t)n);
+    size_t max_moves = 1, max_trk = 1;
+    for (int i = 0; i < n; i++) {
+        if (slots[i] < 0 || slots[i] >= c.G) return fail(BO_E_ARG, "slot out of range");
+        if (!parse_fen(fens && fens[i] ? fens[i] : START_FEN, &start[i])) return fail(BO_E_FEN, "bad FEN");
+        if (!parse_uci_moves(moves ? moves[i] : nullptr, &mv[i])) return fail(BO_E_FEN, "bad UCI move list");
+        if ((int)mv[i].size() + 2 > c.PLY_CAP) return fail(BO_E_ARG, "move list longer than max_plies");
+        if (mv[i].size() > max_moves) max_moves = mv[i].size();
+        if (trk_off && (size_t)(trk_off[i + 1] - trk_off[i]) > max_trk) max_trk = (size_t)(trk_off[i + 1] - trk_off[i]);
+    }
+    if (max_trk > (size_t)c.TRK_CAP) return fail(BO_E_ARG, "tracker larger than max_plies");
+    std::vector<bo_mv> flat((size_t)n * max_moves, 0);
+    std::vector<int> nm((size_t)n), nh((size_t)n, -1), nt((size_t)n, 0);
+    for (int i = 0; i < n; i++) {
+        nm[i] = (int)mv[i].size();
+        for (size_t k = 0; k < mv[i].size(); k++) flat[(size_t)i * max_moves + k] = mv[i][k];
+    }
+    std::vector<DPos> hh, tt;
+    std::vector<int> tc;
+    if (n_hist) {
+        hh.resize((size_t)n * 7);
+        tt.resize((size_t)n * max_trk);
+        tc.resize((size_t)n * max_trk, 0);
+        for (int i = 0; i < n; i++) {
+            nh[i] = n_hist[i];
+            if (nh[i] > 7) return fail(BO_E_ARG, "more than 7 history boards");
+            for (int k = 0; k < nh[i]; k++) hh[(size_t)i * 7 + k] = from_abi(hist[(size_t)i * 7 + k]);
+            nt[i] = trk_off ? trk_off[i + 1] - trk_off[i] : 0;
+            for (int k = 0; k < nt[i]; k++) {
+                tt[(size_t)i * max_trk + k] = from_abi(trk[trk_off[i] + k]);
+                tc[(size_t)i * max_trk + k] = trk_counts[trk_off[i] + k];
+            }
+        }
+    }
+    SetupArgs a;
+    memset(&a, 0, sizeof(a));
+    int *d_slots, *d_nm, *d_nh = nullptr, *d_nt = nullptr, *d_tc = nullptr;
+    DPos *d_start, *d_hh = nullptr, *d_tt = nullptr;
+    bo_mv *d_mv;
+    std::vector<void *> tmp;
+    auto up = [&](auto **dp, const auto &vec) -> int {
+        void *p = nullptr;
+        int rc = rt_malloc(&p, vec.size() * sizeof(vec[0]));
+        if (rc) return rc;
+        tmp.push_back(p);
+        *dp = (typename std::remove_reference<decltype(**dp)>::type *)p;
+        return rt_h2d(p, vec.data(), vec.size() * sizeof(vec[0]), stream);
+    };
+    std::vector<int> sl(slots, slots + n);
+    int rc = up(&d_slots, sl) | up(&d_start, start) | up(&d_mv, flat) | up(&d_nm, nm);
+    if (n_hist) rc |= up(&d_nh, nh) | up(&d_hh, hh) | up(&d_tt, tt) | up(&d_tc, tc) | up(&d_nt, nt);
+    if (!rc) {
+        a.slots = d_slots; a.start = d_start; a.moves = d_mv; a.n_moves = d_nm; a.max_moves = (int)max_moves;
+        a.hist = d_hh; a.n_hist = d_nh; a.trk = d_tt; a.trk_cnt = d_tc; a.n_trk = d_nt; a.max_trk = (int)max_trk;
+        rc = RT_LAUNCH(bo_k_setup, n, stream, e->d, a);
+    }
+    int rc2 = rt_sync(stream);
+    for (void *p : tmp) rt_free(p);
+    if (rc || rc2) return fail(BO_E_HIP, std::string("bo_games_reset: ") + rt_errstr(rc ? rc : rc2));
+    return BO_OK;
+}
+
+extern "C" int bo_games_reset(bo_engine *e, int n, const int32_t *slots, const char *const *fens, const char *const *moves,
+                              void *stream) {
+    return bo_games_reset_ex(e, n, slots, fens, moves, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int bo_root_info(bo_engine *e, int32_t *n_legal, int32_t *terminal, int32_t *ply, void *stream) {
+    if (!e) return fail(BO_E_ARG, "null engine");
+    const size_t G = (size_t)e->d.c.G;
+    if (n_legal) RT(rt_d2h(n_legal, e->d.root_nlegal, G * 4, stream));
+    if (terminal) RT(rt_d2h(terminal, e->d.root_term, G * 4, stream));
+    if (ply) RT(rt_d2h(ply, e->d.ply, G * 4, stream));
+    RT(rt_sync(stream));
+    return BO_OK;
+}
+
+// ---- search --------------------------------------------------------------------------------------------
+extern "C" int bo_search_begin(bo_engine *e, const int32_t *go, const double *noise, float *nn_in_dev, void *stream) {
+    if (!e || !go || !nn_in_dev) return fail(BO_E_ARG, "null argument");
+    const size_t G = (size_t)e->d.c.G;
+    if (e->d.c.use_noise && !noise) return fail(BO_E_ARG, "noise required when dirichlet_alpha > 0");
+    RT(rt_h2d(e->d_go, go, G * 4, stream));
+    if (noise) RT(rt_h2d(e->d.noise, noise, G * BO_MAX_MOVES * sizeof(double), stream));
+    RT(RT_LAUNCH(bo_k_search_begin, e->d.c.G, stream, e->d, (const int *)e->d_go, nn_in_dev));
+    return BO_OK;
+}
+
+extern "C" int bo_step(bo_engine *e, const float *policy_dev, const float *value_dev, int policy_kind, float *nn_in_dev,
+                       void *stream) {
+    if (!e || !nn_in_dev) return fail(BO_E_ARG, "null argument");
+    if (policy_kind != BO_POLICY_NONE && (!policy_dev || !value_dev)) return fail(BO_E_ARG, "policy/value required");
+    RT(RT_LAUNCH(bo_k_step, e->d.c.G, stream, e->d, policy_dev, value_dev, policy_kind, nn_in_dev));
+    return BO_OK;
+}
+
+extern "C" int bo_search_poll(bo_engine *e, int32_t *n_running, int32_t *n_requested, int32_t *requested_mask, void *stream) {
+    if (!e) return fail(BO_E_ARG, "null engine");
+    const size_t G = (size_t)e->d.c.G;
+    std::vector<int> ph(G), rq(G);
+    RT(rt_d2h(ph.data(), e->d.phase, G * 4, stream));
+    RT(rt_d2h(rq.data(), e->d.req_node, G * 4, stream));
+    RT(rt_sync(stream));
+    int run = 0, req = 0;
+    for (size_t g = 0; g < G; g++) {
+        bool r = ph[g] == PH_RUN;
+        bool q = r && rq[g] >= 0;
+        run += r; req += q;
+        if (requested_mask) requested_mask[g] = q ? 1 : 0;
+    }
+    if (n_running) *n_running = run;
+    if (n_requested) *n_requested = req;
+    return BO_OK;
+}
+
+extern "C" int bo_search_result(bo_engine *e, int32_t *res_n, int32_t *res_idx, float *res_val, int32_t *best_idx,
+                                int32_t *best_move, int32_t *total_visits, void *stream) {
+    if (!e) return fail(BO_E_ARG, "null engine");
+    const size_t G = (size_t)e->d.c.G;
+    RT(RT_LAUNCH(bo_k_result, e->d.c.G, stream, e->d));
+    if (res_n) RT(rt_d2h(res_n, e->d.res_n, G * 4, stream));
+    if (res_idx) RT(rt_d2h(res_idx, e->d.res_idx, G * BO_RES_CAP * 4, stream));
+    if (res_val) RT(rt_d2h(res_val, e->d.res_val, G * BO_RES_CAP * 4, stream));
+    if (best_idx) RT(rt_d2h(best_idx, e->d.res_best_idx, G * 4, stream));
+    if (best_move) RT(rt_d2h(best_move, e->d.res_best_mv, G * 4, stream));
+    if (total_visits) RT(rt_d2h(total_visits, e->d.res_total, G * 4, stream));
+    RT(rt_sync(stream));
+    return BO_OK;
+}
+
+extern "C" int bo_play(bo_engine *e, const int32_t *action, void *stream) {
+    if (!e || !action) return fail(BO_E_ARG, "null argument");
+    RT(rt_h2d(e->d_action, action, (size_t)e->d.c.G * 4, stream));
+    RT(RT_LAUNCH(bo_k_play, e->d.c.G, stream, e->d, (const int *)e->d_action));
+    return BO_OK;
+}
+
+// ---- records ------------------------------------------------------------------------------------------------
+extern "C" int bo_game_export(bo_engine *e, int slot, bo_position *positions, int32_t *moves, int32_t cap, int32_t *n_plies,
+                              void *stream) {
+    if (!e || slot < 0 || slot >= e->d.c.G || !n_plies) return fail(BO_E_ARG, "bad arguments");
+    const EngCfg &c = e->d.c;
+    int ply = 0;
+    RT(rt_d2h(&ply, e->d.ply + slot, 4, stream));
+    RT(rt_sync(stream));
+    *n_plies = ply;
+    if (ply + 1 > cap) return fail(BO_E_ARG, "export buffer too small");
+    std::vector<DPos> gp((size_t)ply + 1);
+    std::vector<bo_mv> mv((size_t)ply + 1);
+    RT(rt_d2h(gp.data(), e->d.gpos + (size_t)slot * c.PLY_CAP, gp.size() * sizeof(DPos), stream));
+    RT(rt_d2h(mv.data(), e->d.played + (size_t)slot * c.PLY_CAP, mv.size() * sizeof(bo_mv), stream));
+    RT(rt_sync(stream));
+    for (int i = 0; i <= ply; i++) {
+        if (positions) to_abi(gp[i], &positions[i]);
+        if (moves && i < ply) moves[i] = mv[i];
+    }
+    return BO_OK;
+}
+
+extern "C" int bo_game_encode(bo_engine *e, int slot, int first, int n, float *out_dev, void *stream) {
+    if (!e || slot < 0 || slot >= e->d.c.G || n < 1 || first < 0 || !out_dev) return fail(BO_E_ARG, "bad arguments");
+    RT(RT_LAUNCH(bo_k_encode_game, n, stream, e->d, slot, first, out_dev));
+    return BO_OK;
+}
+
+// ---- introspection -----------------------------------------------------------------------------------------
+extern "C" int bo_debug_tree(bo_engine *e, int slot, bo_node *out, int32_t cap, int32_t *n_nodes, void *stream) {
+    if (!e || slot < 0 || slot >= e->d.c.G || !n_nodes) return fail(BO_E_ARG, "bad arguments");
+    const EngCfg &c = e->d.c;
+    int nn = 0;
+    RT(rt_d2h(&nn, e->d.n_nodes + slot, 4, stream));
+    RT(rt_sync(stream));
+    *n_nodes = nn;
+    if (!out) return BO_OK;
+    if (nn > cap) return fail(BO_E_ARG, "tree buffer too small");
+    const size_t off = (size_t)slot * c.NCAP, N = (size_t)nn;
+    std::vector<int> nv(N), pa(N), fc(N), nc(N);
+    std::vector<float> q(N), pr(N);
+    std::vector<bo_mv> mv(N);
+    std::vector<signed char> tm(N);
+    RT(rt_d2h(nv.data(), e->d.n_visits + off, N * 4, stream)); RT(rt_d2h(pa.data(), e->d.parent + off, N * 4, stream));
+    RT(rt_d2h(fc.data(), e->d.first_child + off, N * 4, stream)); RT(rt_d2h(nc.data(), e->d.n_children + off, N * 4, stream));
+    RT(rt_d2h(q.data(), e->d.q + off, N * 4, stream)); RT(rt_d2h(pr.data(), e->d.prior + off, N * 4, stream));
+    RT(rt_d2h(mv.data(), e->d.move + off, N * sizeof(bo_mv), stream)); RT(rt_d2h(tm.data(), e->d.term + off, N, stream));
+    RT(rt_sync(stream));
+    for (size_t i = 0; i < N; i++) {
+        out[i].parent = pa[i]; out[i].n_visits = nv[i]; out[i].first_child = fc[i]; out[i].n_children = nc[i];
+        out[i].q_value = q[i]; out[i].prior = pr[i]; out[i].move = mv[i]; out[i].terminal = tm[i];
+    }
+    return BO_OK;
+}
+
+extern "C" int bo_engine_status(bo_engine *e, int32_t *status, int32_t *evals, int32_t *flushes, int32_t *term_sims,
+                                int32_t *levels, int32_t *children_scanned, void *stream) {
+    if (!e) return fail(BO_E_ARG, "null engine");
+    const size_t G = (size_t)e->d.c.G;
+    if (status) RT(rt_d2h(status, e->d.status, G * 4, stream));
+    if (evals) RT(rt_d2h(evals, e->d.stat_evals, G * 4, stream));
+    if (flushes) RT(rt_d2h(flushes, e->d.stat_flushes, G * 4, stream));
+    if (term_sims) RT(rt_d2h(term_sims, e->d.stat_term_sims, G * 4, stream));
+    if (levels) RT(rt_d2h(levels, e->d.stat_levels, G * 4, stream));
+    if (children_scanned) RT(rt_d2h(children_scanned, e->d.stat_children_scanned, G * 4, stream));
+    RT(rt_sync(stream));
+    return BO_OK;
+}
+
+extern "C" int bo_movegen_batch(bo_engine *e, int n, const bo_position *pos, int32_t *moves_out, int32_t *n_out,
+                                int32_t *check_out, void *stream) {
+    if (!e || n < 1 || !pos || !moves_out || !n_out) return fail(BO_E_ARG, "bad arguments");
+    std::vector<DPos> hp((size_t)n);
+    for (int i = 0; i < n; i++) hp[i] = from_abi(pos[i]);
+    void *dp = nullptr, *dm = nullptr, *dn = nullptr, *dc = nullptr;
+    int rc = rt_malloc(&dp, hp.size() * sizeof(DPos)) | rt_malloc(&dm, (size_t)n * BO_MAX_MOVES * sizeof(bo_mv)) |
+             rt_malloc(&dn, (size_t)n * 4) | rt_malloc(&dc, (size_t)n * 4);
+    std::vector<bo_mv> hm((size_t)n * BO_MAX_MOVES);
+    std::vector<int> hc((size_t)n);
+    if (!rc) rc = rt_h2d(dp, hp.data(), hp.size() * sizeof(DPos), stream);
+    if (!rc) rc = RT_LAUNCH(bo_k_movegen, n, stream, (const DPos *)dp, (bo_mv *)dm, (int *)dn, (int *)dc);
+    if (!rc) rc = rt_d2h(hm.data(), dm, hm.size() * sizeof(bo_mv), stream) | rt_d2h(n_out, dn, (size_t)n * 4, stream) |
+                  rt_d2h(hc.data(), dc, (size_t)n * 4, stream);
+    int rc2 = rt_sync(stream);
+    rt_free(dp); rt_free(dm); rt_free(dn); rt_free(dc);
+    if (rc || rc2) return fail(BO_E_HIP, std::string("bo_movegen_batch: ") + rt_errstr(rc ? rc : rc2));
+    for (size_t i = 0; i < hm.size(); i++) moves_out[i] = hm[i];
+    if (check_out) for (int i = 0; i < n; i++) check_out[i] = hc[i];
+    return BO_OK;
+}
+
+// ---- wide PUCT select (roofline workload; independent of an engine instance) ----------------------------------
+extern "C" int bo_select_wide(const void *blocks_dev, const int32_t *root_block_dev, const int32_t *root_n_dev,
+                              const float *sqrt_lut_dev, int n_trees, int max_depth, float cpuct, int grid_blocks,
+                              int32_t *out_leaf_dev, int32_t *out_levels_dev, void *stream) {
+#if defined(BO_WAVE_EMU)
+    (void)blocks_dev; (void)root_block_dev; (void)root_n_dev; (void)sqrt_lut_dev; (void)n_trees; (void)max_depth;
+    (void)cpuct; (void)grid_blocks; (void)out_leaf_dev; (void)out_levels_dev; (void)stream;
+    return fail(BO_E_CONFIG, "bo_select_wide is a gfx950-only kernel");
+#else
+    if (!blocks_dev || !root_block_dev || !root_n_dev || !sqrt_lut_dev || !out_leaf_dev || !out_levels_dev || n_trees < 1)
+        return fail(BO_E_ARG, "bad arguments");
+    if (grid_blocks < 1) grid_blocks = (n_trees + 7) / 8;
+    hipLaunchKernelGGL(bo_k_select_wide, dim3((unsigned)grid_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const WideBlock *)blocks_dev, (const int *)root_block_dev, (const int *)root_n_dev, sqrt_lut_dev,
+                       n_trees, max_depth, cpuct, (int *)out_leaf_dev, (int *)out_levels_dev);
+    RT((int)hipGetLastError());
+    return BO_OK;
+#endif
+}

@@ -1,0 +1,750 @@
+// betaone_amd/csrc/bo_tree.h -- the MCTS tree kernels (device code), one 64-lane wavefront per game.
+//
+// Replaces, for thousands of concurrent games at once, the reference's per-game Python objects:
+//   MCTSNode.select_child / expand / update_recursive      /root/reference/mcts.py:45-144
+//   run_mcts (root init, simulation loop, pi/best move)     /root/reference/mcts.py:155-280
+//   _evaluate_batch (expand + backup of the pending rows)   /root/reference/mcts.py:283-295
+//   utils.encode_board (leaf planes)                        /root/reference/utils.py:111-217
+// with results bit-identical to the reference in dtype regime R3: every tree
+// operation is a single binary32 operation, compiled with -ffp-contract=off and correctly rounded
+// division; double->float roundings of math.sqrt()/int() come from host-built lookup tables.
+//
+// Data layout (HBM, structure of arrays, one contiguous block of NCAP nodes per game):
+//   n_visits i32 | q f32 | prior f32           <- the 12 B/child the PUCT scan reads (coalesced,
+//                                                  children of a node are contiguous)
+//   parent i32 | first_child i32 | n_children i32 | move u16 | term i8 | eval_slot i16 | pos DPos(80 B)
+// plus per game: the real game's position stack (draw rules, history planes), the repetition
+// tracker, the pending-row run list and the cache of evaluated-but-not-yet-expanded leaves.
+//
+// Schedule (differs from the reference on purpose, results identical):
+//   * the reference replays ONE leaf up to 96 times per NN batch (mcts.py:210-254); here a leaf is
+//     evaluated once, the identical re-selections are recorded as a run (leaf, count), and the
+//     flush replays the runs in order: children are created once with the final widened count and
+//     every ancestor applies `count` incremental-mean updates in the reference's rounding order;
+//   * one NN row per game per step (row index == game slot), so the net always sees a static
+//     [G,120,8,8] batch and the step is capturable in a hipGraph.
+#pragma once
+#include "bo_chess.h"
+#include <math.h>
+
+#define BO_CH_CAP 32     // max children created per expansion (int(WIDEN*sqrt(BATCH)) must fit)
+#define BO_PATH_CAP 1024 // max tree depth
+#define BO_RES_CAP 256
+#define BO_PLANES 120
+#define BO_ROW (BO_PLANES * 64)
+
+enum { PH_IDLE = 0, PH_RUN = 1, PH_DONE = 2 };
+enum { ST_OK = 0, ST_NODE_OVERFLOW = 1, ST_DEPTH_OVERFLOW = 2, ST_NAN_SCORE = 4, ST_PLY_OVERFLOW = 8,
+       ST_ILLEGAL_ACTION = 16, ST_UL_OVERFLOW = 32, ST_TRK_OVERFLOW = 64 };
+enum { POLICY_NONE = 0, POLICY_LOGITS = 1, POLICY_PROBS = 2 };
+
+struct EngCfg {
+    int G, S, B;                 // games, simulations per move, MCTS batch size
+    int NCAP, PLY_CAP, TRK_CAP;  // nodes per game, positions per game, tracker entries per game
+    int UL_MAX, CH_MAX;          // cached evaluated leaves per game; children per expansion
+    float cpuct, keep;           // f32(CPUCT), f32(1 - DIRICHLET_EPSILON)
+    double eps;                  // DIRICHLET_EPSILON
+    int use_noise;               // DIRICHLET_ALPHA > 0
+    int root_m;                  // children admitted by one root expand call: int(WIDEN*sqrt(1))
+};
+
+struct Eng {
+    EngCfg c;
+    const float *sqrt_lut;  // [S+2]  f32(math.sqrt(n + 1e-8))
+    const int *widen_lut;   // [B+1]  int(WIDEN*sqrt(k)) for k rows (0 -> "all legal moves")
+    // per game scalars
+    int *phase, *sims_done, *n_nodes, *rows, *n_runs, *n_ul, *req_node, *req_nlegal, *status;
+    int *ply, *trk_n, *n_hist, *ctx_mode, *root_nlegal, *root_term, *root_nch;
+    int *stat_evals, *stat_flushes, *stat_term_sims, *stat_levels, *stat_children_scanned;
+    // game stack, tracker, explicit history
+    DPos *gpos, *trk, *hist;
+    int *trk_cnt;
+    // nodes [G][NCAP]
+    int *n_visits, *parent, *first_child, *n_children;
+    float *q, *prior;
+    bo_mv *move;
+    signed char *term;
+    short *eval_slot;
+    DPos *npos;
+    // pending rows / evaluated leaves
+    int *run_leaf, *run_cnt;          // [G][B]
+    int *ul_node, *ul_nlegal;         // [G][UL_MAX]
+    float *ul_value;
+    bo_mv *ul_move;                   // [G][UL_MAX][CH_CAP]
+    float *ul_prior;
+    bo_mv *req_moves, *root_moves;    // [G][256]
+    int *root_child_rank;             // [G][2*CH_CAP] legal-order index of each root child
+    double *noise;                    // [G][256]
+    bo_mv *played;                    // [G][PLY_CAP]
+    // search results
+    int *res_n, *res_idx, *res_best_idx, *res_best_mv, *res_total;
+    float *res_val;
+};
+
+#define NOFF(e, g) ((size_t)(g) * (size_t)(e).c.NCAP)
+
+BO_DEV int bo_uniform(int v) {
+#if defined(BO_WAVE_EMU)
+    return v;
+#else
+    return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+
+// ---- chain walk: the positions python-chess revisits when it pops back to the last irreversible
+// move (Board.is_repetition / can_claim_threefold_repetition).  Calls f(const DPos&) per entry.
+template <class F> BO_DEV int chain_walk(const Eng &e, int g, int leaf, F f) {
+    const size_t no = NOFF(e, g);
+    int cnt = 0, x = leaf;
+    while (x > 0) {
+        if (e.npos[no + x].flags & F_IRREV) return cnt;
+        x = e.parent[no + x];
+        f(e.npos[no + x]);
+        cnt++;
+    }
+    const DPos *gp = e.gpos + (size_t)g * e.c.PLY_CAP;
+    int j = e.ply[g];
+    while (j > 0 && !(gp[j].flags & F_IRREV)) {
+        j--;
+        f(gp[j]);
+        cnt++;
+    }
+    return cnt;
+}
+
+// Board.outcome(claim_draw=True) of node `leaf` whose legal moves are mv[0..n): 0 ongoing, 1 mate, 2 draw
+BO_DEV int terminal_eval(const Eng &e, int g, int leaf, const DPos &P, const bo_mv *mv, int n, bool in_check, bo_mv *scratch) {
+    if (n == 0 && in_check) return 1;
+    if (insufficient_material(P)) return 2;
+    if (n == 0) return 2;
+    if (P.halfmove >= 150) return 2;
+    int self = 1;
+    int npred = chain_walk(e, g, leaf, [&](const DPos &E) { if (E.khash == P.khash && key_equal(E, P)) self++; });
+    if (self >= 5) return 2;
+    if (P.halfmove >= 100) return 2;
+    if (P.halfmove >= 99) {  // can_claim_fifty_moves: some non-zeroing move reaches 100 without ending the game
+        for (int j = 0; j < n; j++) {
+            bo_mv m = mv[j];
+            if (is_zeroing(P, m)) continue;
+            DPos c = make_move(P, m);
+            bool chk;
+            int n2 = bo_movegen(c, scratch, &chk);
+            if (n2 > 0) return 2;
+        }
+    }
+    if (self >= 3) return 2;
+    if (npred >= 3) {  // lookahead: a legal move into a position already seen twice
+        bool hit = false;
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            int j = j0 + bo_lane();
+            bool act = j < n;
+            bo_mv m = act ? mv[j] : (bo_mv)0;
+            act = act && !is_irreversible(P, m);
+            DPos c = P;
+            if (act) c = make_move(P, m);
+            int cc = 0;
+            chain_walk(e, g, leaf, [&](const DPos &E) { if (act && E.khash == c.khash && key_equal(E, c)) cc++; });
+            if (bo_ballot(act && cc >= 2)) hit = true;
+        }
+        if (hit) return 2;
+    }
+    return 0;
+}
+
+// tracker.repetitions(board) = max(0, count - 1)   (utils.py:91-99)
+BO_DEV int tracker_reps(const Eng &e, int g, const DPos &P) {
+    const DPos *t = e.trk + (size_t)g * e.c.TRK_CAP;
+    const int *tc = e.trk_cnt + (size_t)g * e.c.TRK_CAP;
+    int n = e.trk_n[g], c = 0;
+    for (int j = bo_lane(); j < n; j += 64)
+        if (t[j].khash == P.khash && key_equal(t[j], P)) c += tc[j];
+    c = bo_wave_sum(c);
+    return c > 1 ? c - 1 : 0;
+}
+
+// one 14-plane history block (utils.py:172-188); lane == square
+BO_DEV void encode_block(float *row, int block, const DPos &H, int rep) {
+    const int s = bo_lane();
+    float *p = row + (size_t)block * 14 * 64 + s;
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+        p[(2 * t) * 64] = (float)((H.bb[t] & H.bb[BB_WHITE]) >> s & 1);
+        p[(2 * t + 1) * 64] = (float)((H.bb[t] & H.bb[BB_BLACK]) >> s & 1);
+    }
+    p[12 * 64] = rep >= 1 ? 1.0f : 0.0f;
+    p[13 * 64] = rep >= 2 ? 1.0f : 0.0f;
+}
+// planes 112..119 (utils.py:190-215)
+BO_DEV void encode_scalars(float *row, const DPos &P) {
+    const int s = bo_lane();
+    float *p = row + 112 * 64 + s;
+    p[0] = (P.flags & F_TURN) ? 1.0f : 0.0f;
+    p[64] = (P.flags & 0x02u) ? 1.0f : 0.0f;
+    p[128] = (P.flags & 0x04u) ? 1.0f : 0.0f;
+    p[192] = (P.flags & 0x08u) ? 1.0f : 0.0f;
+    p[256] = (P.flags & 0x10u) ? 1.0f : 0.0f;
+    p[320] = (float)P.halfmove;
+    p[384] = (float)P.fullmove;
+    p[448] = pos_ep(P) == s ? 1.0f : 0.0f;
+}
+// planes 0..97 of a search: the <=7 boards before the root; constant for the whole search (mcts.py:242)
+BO_DEV void encode_static(const Eng &e, int g, float *row) {
+    const int s = bo_lane();
+    const int nh = e.n_hist[g];
+    const DPos *h = e.hist + (size_t)g * 7;
+    for (int pl = 0; pl < (7 - nh) * 14; pl++) row[pl * 64 + s] = 0.0f;
+    for (int i = 0; i < nh; i++) {
+        DPos H = h[i];
+        encode_block(row, 7 - nh + i, H, tracker_reps(e, g, H));
+    }
+}
+BO_DEV void encode_leaf(const Eng &e, int g, float *row, const DPos &P) {
+    encode_block(row, 7, P, tracker_reps(e, g, P));
+    encode_scalars(row, P);
+}
+
+// MCTSNode.select_child repeated down to a leaf (mcts.py:218-230, 72-118)
+BO_DEV int select_leaf(const Eng &e, int g, int *flags) {
+    const size_t no = NOFF(e, g);
+    const int lane = bo_lane();
+    int cur = 0, levels = 0, scanned = 0;
+    for (;;) {
+        const int nc = e.n_children[no + cur];
+        if (nc == 0) break;
+        const int fc = e.first_child[no + cur];
+        const int pv = cur == 0 ? e.n_visits[no] : e.n_visits[no + e.parent[no + cur]];  // mcts.py:89
+        const float sp = e.sqrt_lut[pv];
+        float score = -__builtin_inff();
+        if (lane < nc) {
+            const int n = e.n_visits[no + fc + lane];
+            const float p = e.prior[no + fc + lane];
+            const float t1 = e.c.cpuct * p;
+            const float t2 = t1 * sp;
+            float qv = 0.0f, u = t2;
+            if (n > 0) {
+                qv = e.q[no + fc + lane];
+                u = t2 / (float)(1 + n);
+            }
+            score = qv + u;
+            if (!(score == score)) score = -__builtin_inff();  // NaN never wins `score > best`
+        }
+        int bi = lane;
+        for (int m = 1; m < 64; m <<= 1) {
+            float os = bo_shfl_xor_f(score, m);
+            int oi = bo_shfl_xor(bi, m);
+            if (os > score || (os == score && oi < bi)) { score = os; bi = oi; }
+        }
+        if (!(score > -__builtin_inff())) { *flags |= ST_NAN_SCORE; bi = 0; }  // reference: random.choice
+        cur = bo_uniform(fc + bi);
+        levels++;
+        scanned += nc;
+        if (levels >= BO_PATH_CAP - 1) { *flags |= ST_DEPTH_OVERFLOW; break; }
+    }
+    if (lane == 0) { e.stat_levels[g] += levels; e.stat_children_scanned[g] += scanned; }
+    return cur;
+}
+
+// MCTSNode.update_recursive applied `cnt` times with the same leaf value (mcts.py:120-144)
+BO_DEV void backup_run(const Eng &e, int g, int leaf, float v, int cnt, int *path, int *flags) {
+    const size_t no = NOFF(e, g);
+    int d = 0;
+    for (int x = leaf; x >= 0 && d < BO_PATH_CAP; x = e.parent[no + x]) {
+        if (bo_lane() == 0) path[d] = x;
+        d++;
+    }
+    bo_sync();
+    for (int i = bo_lane(); i < d; i += 64) {
+        const int nd = path[i];
+        const float val = (i & 1) ? -v : v;
+        int n = e.n_visits[no + nd];
+        float qv = e.q[no + nd];
+        for (int c = 0; c < cnt; c++) {
+            n += 1;
+            const float dd = val - qv;
+            const float ee = dd / (float)n;
+            qv = qv + ee;
+        }
+        e.n_visits[no + nd] = n;
+        e.q[no + nd] = qv;
+    }
+    bo_sync();
+}
+
+BO_DEV void init_node(const Eng &e, size_t no, int idx, int par, float prior, bo_mv m, const DPos &P) {
+    e.n_visits[no + idx] = 0;
+    e.q[no + idx] = 0.0f;
+    e.prior[no + idx] = prior;
+    e.parent[no + idx] = par;
+    e.first_child[no + idx] = 0;
+    e.n_children[no + idx] = 0;
+    e.move[no + idx] = m;
+    e.term[no + idx] = -1;
+    e.eval_slot[no + idx] = -1;
+    e.npos[no + idx] = P;
+}
+
+// _evaluate_batch's per-row expand + backup for all pending rows (mcts.py:291-295)
+BO_DEV void flush_pending(const Eng &e, int g, int n_runs, int n_ul, int *n_nodes_io, int *path, int *flags) {
+    const size_t no = NOFF(e, g);
+    const int lane = bo_lane();
+    const int *rl = e.run_leaf + (size_t)g * e.c.B, *rc = e.run_cnt + (size_t)g * e.c.B;
+    int n_nodes = *n_nodes_io;
+    for (int u = 0; u < n_ul; u++) {
+        const size_t uo = (size_t)g * e.c.UL_MAX + u;
+        const int leaf = e.ul_node[uo];
+        int k = 0;
+        for (int r = 0; r < n_runs; r++) k += rl[r] == leaf ? rc[r] : 0;
+        int c = e.widen_lut[k];             // int(WIDEN_COEFF*sqrt(k)) of the leaf's last row (mcts.py:55-57)
+        const int nl = e.ul_nlegal[uo];
+        if (c <= 0 || c > nl) c = nl;
+        if (c > e.c.CH_MAX) c = e.c.CH_MAX;
+        if (n_nodes + c > e.c.NCAP) { *flags |= ST_NODE_OVERFLOW; c = e.c.NCAP - n_nodes; }
+        if (lane < c) {
+            const DPos P = e.npos[no + leaf];
+            const bo_mv m = e.ul_move[uo * BO_CH_CAP + lane];
+            init_node(e, no, n_nodes + lane, leaf, e.ul_prior[uo * BO_CH_CAP + lane], m, make_move(P, m));
+        }
+        if (lane == 0) { e.first_child[no + leaf] = n_nodes; e.n_children[no + leaf] = c; }
+        n_nodes += c;
+    }
+    bo_sync();
+    for (int r = 0; r < n_runs; r++) {
+        const int leaf = rl[r];
+        const int slot = e.eval_slot[no + leaf];
+        backup_run(e, g, leaf, e.ul_value[(size_t)g * e.c.UL_MAX + slot], rc[r], path, flags);
+    }
+    *n_nodes_io = n_nodes;
+    if (lane == 0) e.stat_flushes[g] += 1;
+}
+
+// numpy's pairwise float32 sum of exactly 4672 contiguous values (np.ndarray.sum, mcts.py:201).
+// numpy halves n (rounded down to a multiple of 8) until a block has <= 128 elements:
+// 4672 -> 2336 -> 1168 -> 584 -> (288, 296) -> (144,144 | 144,152) -> (72,72 | 72,72 | 72,72 | 72,80),
+// i.e. 64 leaf blocks at offsets 584*c + 72*k (the 8th of every group has 80 elements), each summed
+// with 8 strided accumulators, combined by a balanced binary tree -- one leaf per lane + a butterfly.
+BO_DEV float np_sum_4672(const float *a) {
+    const int L = bo_lane();
+    const float *b = a + (L >> 3) * 584 + (L & 7) * 72;
+    const int n = (L & 7) == 7 ? 80 : 72;
+    float r0 = b[0], r1 = b[1], r2 = b[2], r3 = b[3], r4 = b[4], r5 = b[5], r6 = b[6], r7 = b[7];
+    for (int i = 8; i < n; i += 8) {
+        r0 += b[i]; r1 += b[i + 1]; r2 += b[i + 2]; r3 += b[i + 3];
+        r4 += b[i + 4]; r5 += b[i + 5]; r6 += b[i + 6]; r7 += b[i + 7];
+    }
+    float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (int m = 1; m < 64; m <<= 1) res = res + bo_shfl_xor_f(res, m);
+    return res;
+}
+
+// stable descending rank of p[j] among p[0..n): #greater + #equal-before (sorted(..., reverse=True), mcts.py:58-62)
+BO_DEV int stable_rank(const float *p, int n, int j) {
+    const float pj = p[j];
+    int r = 0;
+    for (int i = 0; i < n; i++) r += (p[i] > pj) || (p[i] == pj && i < j);
+    return r;
+}
+
+struct StepShared {
+    bo_mv moves[BO_MAX_MOVES];
+    bo_mv moves2[BO_MAX_MOVES];
+    float pv[BO_MAX_MOVES];
+    int path[BO_PATH_CAP];
+    float probs[BO_NUM_ACTIONS];
+    int rank_of[2 * BO_CH_CAP];
+};
+
+// softmax row -> LDS (policy_kind LOGITS) or copy (PROBS)
+BO_DEV void load_probs(const float *row, int kind, float *out) {
+    const int lane = bo_lane();
+    if (kind == POLICY_PROBS) {
+        for (int i = lane; i < BO_NUM_ACTIONS; i += 64) out[i] = row[i];
+    } else {
+        float mx = -__builtin_inff();
+        for (int i = lane; i < BO_NUM_ACTIONS; i += 64) { float x = row[i]; mx = x > mx ? x : mx; }
+        mx = bo_wave_max_f(mx);
+        float sum = 0.0f;
+        for (int i = lane; i < BO_NUM_ACTIONS; i += 64) { float ex = expf(row[i] - mx); out[i] = ex; sum += ex; }
+        sum = bo_wave_sum_f(sum);
+        for (int i = lane; i < BO_NUM_ACTIONS; i += 64) out[i] = out[i] / sum;
+    }
+    bo_sync();
+}
+
+// root initialisation after the root's evaluation (mcts.py:185-203)
+BO_DEV void apply_root(const Eng &e, int g, const float *row, int kind, StepShared &sh, int *n_nodes_io, int *flags) {
+    const size_t no = NOFF(e, g);
+    const int lane = bo_lane();
+    const int n = e.root_nlegal[g];
+    const bo_mv *mv = e.root_moves + (size_t)g * BO_MAX_MOVES;
+    load_probs(row, kind, sh.probs);
+    int m = e.c.root_m < n ? e.c.root_m : n;
+    if (m > BO_CH_CAP) m = BO_CH_CAP;
+    for (int j = lane; j < n; j += 64) sh.pv[j] = sh.probs[move_to_index(mv[j])];
+    if (lane < 2 * BO_CH_CAP) sh.rank_of[lane] = -1;
+    bo_sync();
+    for (int j = lane; j < n; j += 64) {  // first expand: top-m raw priors
+        int r = stable_rank(sh.pv, n, j);
+        if (r < m) sh.rank_of[r] = j;
+    }
+    bo_sync();
+    const DPos P = e.npos[no];
+    int nch = m;
+    if (lane < m) {
+        int j = sh.rank_of[lane];
+        init_node(e, no, 1 + lane, 0, sh.pv[j], mv[j], make_move(P, mv[j]));
+        e.root_child_rank[(size_t)g * 2 * BO_CH_CAP + lane] = j;
+    }
+    bo_sync();
+    if (e.c.use_noise) {  // mcts.py:190-201
+        const double *nz = e.noise + (size_t)g * BO_MAX_MOVES;
+        for (int j = lane; j < n; j += 64) {
+            const int idx = move_to_index(mv[j]);
+            const float a = e.c.keep * sh.probs[idx];
+            const double s2 = (double)a + e.c.eps * nz[j];
+            sh.probs[idx] = (float)s2;
+        }
+        bo_sync();
+        const float sum = np_sum_4672(sh.probs);
+        const float denom = sum + 1e-12f;
+        for (int j = lane; j < n; j += 64) sh.pv[j] = sh.probs[move_to_index(mv[j])] / denom;
+        bo_sync();
+    }
+    // second expand (mcts.py:203): top-m of the (noised) priors, children not yet present are appended
+    for (int j = lane; j < n; j += 64) {
+        int r = stable_rank(sh.pv, n, j);
+        if (r < m) sh.rank_of[BO_CH_CAP + r] = j;
+    }
+    bo_sync();
+    for (int r = 0; r < m; r++) {  // wave-uniform, m is tiny (1 with the default WIDEN_COEFF)
+        const int j = sh.rank_of[BO_CH_CAP + r];
+        bool present = false;
+        for (int k = 0; k < m; k++) present = present || sh.rank_of[k] == j;
+        if (!present) {
+            if (lane == 0) {
+                init_node(e, no, 1 + nch, 0, sh.pv[j], mv[j], make_move(P, mv[j]));
+                e.root_child_rank[(size_t)g * 2 * BO_CH_CAP + nch] = j;
+            }
+            nch++;
+        }
+    }
+    if (lane == 0) { e.first_child[no] = 1; e.n_children[no] = nch; e.root_nch[g] = nch; }
+    *n_nodes_io = 1 + nch;
+    bo_sync();
+}
+
+// a leaf's evaluation arrives: keep its value and its CH_MAX best (move, prior) pairs until the flush
+BO_DEV void apply_leaf(const Eng &e, int g, int leaf, const float *row, int kind, float value, StepShared &sh, int *n_ul_io, int *flags) {
+    const size_t no = NOFF(e, g);
+    const int lane = bo_lane();
+    const int n = e.req_nlegal[g];
+    const bo_mv *mv = e.req_moves + (size_t)g * BO_MAX_MOVES;
+    int slot = *n_ul_io;
+    if (slot >= e.c.UL_MAX) { *flags |= ST_UL_OVERFLOW; slot = e.c.UL_MAX - 1; }
+    const size_t uo = (size_t)g * e.c.UL_MAX + slot;
+    if (kind == POLICY_PROBS) {
+        for (int j = lane; j < n; j += 64) sh.pv[j] = row[move_to_index(mv[j])];
+    } else {  // softmax restricted to what is needed: max and sum over the row, exp at the legal indices
+        float mx = -__builtin_inff();
+        for (int i = lane; i < BO_NUM_ACTIONS; i += 64) { float x = row[i]; mx = x > mx ? x : mx; }
+        mx = bo_wave_max_f(mx);
+        float sum = 0.0f;
+        for (int i = lane; i < BO_NUM_ACTIONS; i += 64) sum += expf(row[i] - mx);
+        sum = bo_wave_sum_f(sum);
+        for (int j = lane; j < n; j += 64) sh.pv[j] = expf(row[move_to_index(mv[j])] - mx) / sum;
+    }
+    bo_sync();
+    const int M = n < e.c.CH_MAX ? n : e.c.CH_MAX;
+    for (int j = lane; j < n; j += 64) {
+        int r = stable_rank(sh.pv, n, j);
+        if (r < M) { e.ul_move[uo * BO_CH_CAP + r] = mv[j]; e.ul_prior[uo * BO_CH_CAP + r] = sh.pv[j]; }
+    }
+    if (lane == 0) {
+        e.ul_node[uo] = leaf;
+        e.ul_nlegal[uo] = n;
+        e.ul_value[uo] = value;
+        e.eval_slot[no + leaf] = (short)slot;
+    }
+    *n_ul_io = slot + 1;
+    bo_sync();
+}
+
+// ---- kernels -------------------------------------------------------------------------------------
+
+// One step of every running search: consume the previous NN outputs (row g <-> game g), advance the
+// simulation loop until the game needs a new evaluation or its search is complete, and write the
+// requested leaf's planes into NN input row g.
+BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kind, float *nn_in) {
+    BO_SHARED StepShared sh;
+    const int g = bo_block();
+    const int lane = bo_lane();
+    if (e.phase[g] != PH_RUN) return;
+    const size_t no = NOFF(e, g);
+    int flags = 0;
+    int sims = e.sims_done[g], rows = e.rows[g], n_runs = e.n_runs[g], n_ul = e.n_ul[g], n_nodes = e.n_nodes[g];
+    int req = e.req_node[g];
+    int *rl = e.run_leaf + (size_t)g * e.c.B, *rc = e.run_cnt + (size_t)g * e.c.B;
+    float *row = nn_in + (size_t)g * BO_ROW;
+
+    if (req >= 0) {
+        if (kind == POLICY_NONE) return;  // evaluation still outstanding
+        if (req == 0) apply_root(e, g, policy + (size_t)g * BO_NUM_ACTIONS, kind, sh, &n_nodes, &flags);
+        else apply_leaf(e, g, req, policy + (size_t)g * BO_NUM_ACTIONS, kind, value[g], sh, &n_ul, &flags);
+        req = -1;
+    }
+    int phase = PH_RUN;
+    for (;;) {
+        if (sims >= e.c.S) {  // mcts.py:256-257
+            if (rows > 0) { flush_pending(e, g, n_runs, n_ul, &n_nodes, sh.path, &flags); rows = n_runs = n_ul = 0; }
+            phase = PH_DONE;
+            break;
+        }
+        const int leaf = select_leaf(e, g, &flags);
+        int t = e.term[no + leaf];
+        if (t < 0) {  // first visit: legal moves + is_terminal()  (mcts.py:235, cached per node)
+            const DPos P = e.npos[no + leaf];
+            bool chk;
+            const int n = bo_movegen(P, sh.moves, &chk);
+            t = terminal_eval(e, g, leaf, P, sh.moves, n, chk, sh.moves2);
+            if (lane == 0) e.term[no + leaf] = (signed char)t;
+            if (t == 0) {  // it will be evaluated now: keep its ordered legal moves for apply_leaf
+                for (int j = lane; j < n; j += 64) e.req_moves[(size_t)g * BO_MAX_MOVES + j] = sh.moves[j];
+                if (lane == 0) e.req_nlegal[g] = n;
+            }
+            bo_sync();
+        }
+        if (t > 0) {  // mcts.py:235-238: terminal leaves absorb the simulation, no NN row
+            backup_run(e, g, leaf, t == 1 ? 1.0f : 0.0f, 1, sh.path, &flags);
+            sims++;
+            if (lane == 0) e.stat_term_sims[g] += 1;
+            continue;
+        }
+        if (e.eval_slot[no + leaf] < 0) {  // needs the net: emit planes 98..119 into row g and pause
+            encode_leaf(e, g, row, e.npos[no + leaf]);
+            req = leaf;
+            if (lane == 0) e.stat_evals[g] += 1;
+            break;
+        }
+        // mcts.py:247-254: until the next flush nothing changes, so every remaining row of this batch
+        // (or of the simulation budget) re-selects this same leaf
+        int cnt = e.c.B - rows;
+        if (cnt > e.c.S - sims) cnt = e.c.S - sims;
+        if (lane == 0) { rl[n_runs] = leaf; rc[n_runs] = cnt; }
+        n_runs++;
+        rows += cnt;
+        sims += cnt;
+        bo_sync();
+        if (rows >= e.c.B) { flush_pending(e, g, n_runs, n_ul, &n_nodes, sh.path, &flags); rows = n_runs = n_ul = 0; }
+    }
+    if (lane == 0) {
+        e.sims_done[g] = sims; e.rows[g] = rows; e.n_runs[g] = n_runs; e.n_ul[g] = n_ul; e.n_nodes[g] = n_nodes;
+        e.req_node[g] = req; e.phase[g] = phase;
+        if (flags) e.status[g] |= flags;
+    }
+}
+
+// Prepare the root of game g's next search from the top of its position stack: reset the tree,
+// generate the root's ordered legal moves, evaluate is_game_over(claim_draw=True).
+BO_DEV void root_prepare(const Eng &e, int g, StepShared &sh) {
+    const size_t no = NOFF(e, g);
+    const int lane = bo_lane();
+    const int ply = e.ply[g];
+    const DPos P = e.gpos[(size_t)g * e.c.PLY_CAP + ply];
+    if (lane == 0) {
+        init_node(e, no, 0, -1, 1.0f, 0, P);
+        e.n_nodes[g] = 1; e.sims_done[g] = 0; e.rows[g] = 0; e.n_runs[g] = 0; e.n_ul[g] = 0;
+        e.req_node[g] = -1; e.phase[g] = PH_IDLE; e.root_nch[g] = 0;
+        if (e.ctx_mode[g] == 0) {  // self-play context: history = the <=7 real positions before the root
+            int nh = ply < 7 ? ply : 7;
+            e.n_hist[g] = nh;
+            for (int i = 0; i < nh; i++) e.hist[(size_t)g * 7 + i] = e.gpos[(size_t)g * e.c.PLY_CAP + ply - nh + i];
+        }
+    }
+    bo_sync();
+    bool chk;
+    const int n = bo_movegen(P, sh.moves, &chk);
+    const int t = terminal_eval(e, g, 0, P, sh.moves, n, chk, sh.moves2);
+    for (int j = lane; j < n; j += 64) {
+        e.root_moves[(size_t)g * BO_MAX_MOVES + j] = sh.moves[j];
+        e.req_moves[(size_t)g * BO_MAX_MOVES + j] = sh.moves[j];
+    }
+    if (lane == 0) { e.root_nlegal[g] = n; e.req_nlegal[g] = n; e.root_term[g] = t; e.term[no] = (signed char)t; }
+    bo_sync();
+}
+
+// (re)build game stacks: start position + moves; computes key fields; prepares the first root.
+struct SetupArgs {
+    const int *slots;        // [n] game slots to set up
+    const DPos *start;       // [n] raw start positions (key fields filled here)
+    const bo_mv *moves;      // [n][max_moves]
+    const int *n_moves;      // [n]
+    int max_moves;
+    const DPos *hist;        // [n][7] explicit history boards or NULL
+    const int *n_hist;       // [n] (-1 = self-play context)
+    const DPos *trk;         // [n][max_trk] explicit tracker keys or NULL
+    const int *trk_cnt;      // [n][max_trk]
+    const int *n_trk;        // [n]
+    int max_trk;
+};
+BO_DEV void finish_key(DPos &p) {
+    if (!(p.flags & F_EPKEY_MASK) && pos_ep(p) >= 0 && has_legal_ep(p)) p.flags |= (uint32_t)(pos_ep(p) + 1) << F_EPKEY_SHIFT;
+    p.khash = key_hash(p);
+}
+BO_KERNEL void bo_k_setup(Eng e, SetupArgs a) {
+    BO_SHARED StepShared sh;
+    const int i = bo_block(), lane = bo_lane();
+    const int g = a.slots[i];
+    DPos *gp = e.gpos + (size_t)g * e.c.PLY_CAP;
+    DPos *tk = e.trk + (size_t)g * e.c.TRK_CAP;
+    int *tc = e.trk_cnt + (size_t)g * e.c.TRK_CAP;
+    const bool explicit_ctx = a.n_hist && a.n_hist[i] >= 0;
+    if (lane == 0) {
+        DPos p = a.start[i];
+        p.flags |= F_IRREV;
+        finish_key(p);
+        gp[0] = p;
+        int ply = 0, st = 0;
+        for (int k = 0; k < a.n_moves[i]; k++) {
+            if (ply + 1 >= e.c.PLY_CAP) { st |= ST_PLY_OVERFLOW; break; }
+            bo_mv m = a.moves[(size_t)i * a.max_moves + k];
+            e.played[(size_t)g * e.c.PLY_CAP + ply] = m;
+            gp[ply + 1] = make_move(gp[ply], m);
+            ply++;
+        }
+        e.ply[g] = ply;
+        e.status[g] = st;
+        e.ctx_mode[g] = explicit_ctx ? 1 : 0;
+        if (explicit_ctx) {
+            int nh = a.n_hist[i];
+            e.n_hist[g] = nh;
+            for (int k = 0; k < nh; k++) { DPos h = a.hist[(size_t)i * 7 + k]; finish_key(h); e.hist[(size_t)g * 7 + k] = h; }
+            int nt = a.n_trk[i] < e.c.TRK_CAP ? a.n_trk[i] : e.c.TRK_CAP;
+            for (int k = 0; k < nt; k++) { DPos t = a.trk[(size_t)i * a.max_trk + k]; finish_key(t); tk[k] = t; tc[k] = a.trk_cnt[(size_t)i * a.max_trk + k]; }
+            e.trk_n[g] = nt;
+        } else {  // utils.RepetitionTracker.add_board after every real move (self_play.py:93,182)
+            for (int k = 0; k <= ply; k++) { tk[k] = gp[k]; tc[k] = 1; }
+            e.trk_n[g] = ply + 1;
+        }
+        e.stat_evals[g] = e.stat_flushes[g] = e.stat_term_sims[g] = e.stat_levels[g] = e.stat_children_scanned[g] = 0;
+    }
+    bo_sync();
+    root_prepare(e, g, sh);
+}
+
+// Start the searches of all games flagged in `go`: static history planes into NN row g, phase = RUN.
+BO_KERNEL void bo_k_search_begin(Eng e, const int *go, float *nn_in) {
+    const int g = bo_block();
+    if (!go[g]) return;
+    encode_static(e, g, nn_in + (size_t)g * BO_ROW);
+    if (bo_lane() == 0) e.phase[g] = PH_RUN;
+}
+
+// pi and best move of a finished search (mcts.py:259-280)
+BO_KERNEL void bo_k_result(Eng e) {
+    const int g = bo_block(), lane = bo_lane();
+    if (e.phase[g] != PH_DONE) return;
+    const size_t no = NOFF(e, g);
+    const int nch = e.n_children[no], fc = e.first_child[no], n = e.root_nlegal[g];
+    const bo_mv *mv = e.root_moves + (size_t)g * BO_MAX_MOVES;
+    int *ridx = e.res_idx + (size_t)g * BO_RES_CAP;
+    float *rval = e.res_val + (size_t)g * BO_RES_CAP;
+    const int v = lane < nch ? e.n_visits[no + fc + lane] : 0;
+    const int total = bo_wave_sum(v);
+    if (total > 0) {
+        // best = first maximum in LEGAL-move order (mcts.py:279), children carry their legal-order index
+        int key = lane < nch ? e.root_child_rank[(size_t)g * 2 * BO_CH_CAP + lane] : 0x7fffffff;
+        int bv = v, bk = key;
+        for (int m = 1; m < 64; m <<= 1) {
+            int ov = bo_shfl_xor(bv, m), ok = bo_shfl_xor(bk, m);
+            if (ov > bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
+        }
+        // a never-created child has 0 visits: if the maximum is 0 < total that cannot happen; bk is valid
+        const uint64_t nzmask = bo_ballot(lane < nch && v > 0);
+        if (lane < nch && v > 0) {
+            int o = bo_popc64(nzmask & (BIT(lane) - 1));
+            ridx[o] = move_to_index(e.move[no + fc + lane]);
+            rval[o] = (float)((double)v / (double)total);
+        }
+        if (lane == 0) {
+            e.res_n[g] = bo_popc64(nzmask);
+            e.res_best_mv[g] = mv[bk];
+            e.res_best_idx[g] = move_to_index(mv[bk]);
+            e.res_total[g] = total;
+        }
+    } else {
+        for (int j = lane; j < n; j += 64) { ridx[j] = move_to_index(mv[j]); rval[j] = (float)(1.0 / (double)n); }
+        if (lane == 0) {
+            e.res_n[g] = n;
+            e.res_best_mv[g] = n ? mv[0] : 0;
+            e.res_best_idx[g] = n ? move_to_index(mv[0]) : -1;  // -1: the reference raises ValueError
+            e.res_total[g] = 0;
+        }
+    }
+}
+
+// Play the sampled action in every game with action[g] >= 0 (self_play.py:125-184), then prepare
+// the next root.  action -2 = "play res_best_mv".
+BO_KERNEL void bo_k_play(Eng e, const int *action) {
+    BO_SHARED StepShared sh;
+    const int g = bo_block(), lane = bo_lane();
+    const int a = action[g];
+    if (a == -1) return;
+    const int ply = e.ply[g];
+    DPos *gp = e.gpos + (size_t)g * e.c.PLY_CAP;
+    const DPos P = gp[ply];
+    const int n = e.root_nlegal[g];
+    const bo_mv *mv = e.root_moves + (size_t)g * BO_MAX_MOVES;
+    const bo_mv best = (bo_mv)e.res_best_mv[g];
+    bo_mv m = best;
+    if (a >= 0 && !index_to_move(a, P, &m)) m = best;  // self_play.py:127-137
+    bool ok = false, best_ok = false;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        int j = j0 + lane;
+        ok = ok || bo_ballot(j < n && mv[j] == m) != 0;
+        best_ok = best_ok || bo_ballot(j < n && mv[j] == best) != 0;
+    }
+    if (!ok) {  // self_play.py:142-167
+        if (best != m && best_ok) m = best;
+        else { if (lane == 0) { e.status[g] |= ST_ILLEGAL_ACTION; e.phase[g] = PH_IDLE; } return; }
+    }
+    if (ply + 1 >= e.c.PLY_CAP || e.trk_n[g] >= e.c.TRK_CAP) { if (lane == 0) e.status[g] |= ST_PLY_OVERFLOW; return; }
+    if (lane == 0) {
+        const DPos c = make_move(P, m);
+        gp[ply + 1] = c;
+        e.played[(size_t)g * e.c.PLY_CAP + ply] = m;
+        e.ply[g] = ply + 1;
+        const int tn = e.trk_n[g];
+        e.trk[(size_t)g * e.c.TRK_CAP + tn] = c;  // tracker.add_board (self_play.py:182)
+        e.trk_cnt[(size_t)g * e.c.TRK_CAP + tn] = 1;
+        e.trk_n[g] = tn + 1;
+    }
+    bo_sync();
+    root_prepare(e, g, sh);
+}
+
+// Final training encodings of a finished game (self_play.py:200-208): record i uses
+// board_history[max(0,i-7) : i+1] and the END-OF-GAME tracker.  One wave per (game, ply).
+BO_KERNEL void bo_k_encode_game(Eng e, int g, int first, float *out) {
+    const int i = first + bo_block(), s = bo_lane();
+    const DPos *gp = e.gpos + (size_t)g * e.c.PLY_CAP;
+    float *row = out + (size_t)bo_block() * BO_ROW;
+    const int h0 = i - 7 > 0 ? i - 7 : 0, nb = i + 1 - h0;
+    for (int pl = 0; pl < (8 - nb) * 14; pl++) row[pl * 64 + s] = 0.0f;
+    for (int k = 0; k < nb; k++) {
+        DPos H = gp[h0 + k];
+        encode_block(row, 8 - nb + k, H, tracker_reps(e, g, H));
+    }
+    encode_scalars(row, gp[i]);
+}
+
+// Stand-alone batch utilities (tests, drop-in utils.encode_board): legal moves + outcome of positions
+// given with their move stacks already loaded into game slots is covered by bo_k_setup; this one
+// runs the move generator alone on raw positions.
+BO_KERNEL void bo_k_movegen(const DPos *pos, bo_mv *out, int *n_out, int *check_out) {
+    BO_SHARED bo_mv mv[BO_MAX_MOVES];
+    const int i = bo_block(), lane = bo_lane();
+    DPos P = pos[i];
+    bool chk;
+    const int n = bo_movegen(P, mv, &chk);
+    for (int j = lane; j < n; j += 64) out[(size_t)i * BO_MAX_MOVES + j] = mv[j];
+    if (lane == 0) { n_out[i] = n; check_out[i] = chk ? 1 : 0; }
+}

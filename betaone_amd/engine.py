@@ -1,0 +1,257 @@
+"""
+betaone_amd/engine.py -- thin ctypes binding of the C ABI in include/betaone_engine.h.
+
+The product only ever loads csrc/libbetaone_hip.so (hipcc, gfx950) and raises if it is missing or
+cannot be loaded -- there is no CPU fallback.  (Tests may bind the same class to the wave-emulator
+build of the same sources by passing their own CDLL; see tests/wave_emulator.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+NUM_ACTIONS = 4672
+INPUT_CHANNELS = 120
+ROW_FLOATS = 120 * 64
+MAX_LEGAL = 256
+RES_CAP = 256
+POLICY_NONE, POLICY_LOGITS, POLICY_PROBS = 0, 1, 2
+
+STATUS_BITS = {1: "node overflow", 2: "depth overflow", 4: "NaN PUCT score", 8: "ply overflow",
+               16: "illegal action", 32: "leaf cache overflow", 64: "tracker overflow"}
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class BoConfig(C.Structure):
+    _fields_ = [("n_games", C.c_int32), ("num_simulations", C.c_int32), ("mcts_batch_size", C.c_int32),
+                ("max_plies", C.c_int32), ("cpuct", C.c_double), ("widen_coeff", C.c_double),
+                ("dirichlet_alpha", C.c_double), ("dirichlet_epsilon", C.c_double)]
+
+
+class BoPosition(C.Structure):
+    _fields_ = [("bb", C.c_uint64 * 8), ("turn", C.c_int32), ("castling", C.c_uint32), ("ep_square", C.c_int32),
+                ("ep_key", C.c_int32), ("halfmove_clock", C.c_int32), ("fullmove_number", C.c_int32)]
+
+
+class BoNode(C.Structure):
+    _fields_ = [("parent", C.c_int32), ("n_visits", C.c_int32), ("first_child", C.c_int32), ("n_children", C.c_int32),
+                ("q_value", C.c_float), ("prior", C.c_float), ("move", C.c_int32), ("terminal", C.c_int32)]
+
+
+_I32P = C.POINTER(C.c_int32)
+_F32P = C.POINTER(C.c_float)
+_F64P = C.POINTER(C.c_double)
+
+_SYMBOLS = {
+    "bo_abi_version": (C.c_int, []),
+    "bo_last_error": (C.c_char_p, []),
+    "bo_engine_create": (C.c_int, [C.POINTER(BoConfig), C.c_int, C.POINTER(C.c_void_p)]),
+    "bo_engine_destroy": (None, [C.c_void_p]),
+    "bo_games_reset": (C.c_int, [C.c_void_p, C.c_int, _I32P, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p]),
+    "bo_games_reset_ex": (C.c_int, [C.c_void_p, C.c_int, _I32P, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
+                                    C.POINTER(BoPosition), _I32P, C.POINTER(BoPosition), _I32P, _I32P, C.c_void_p]),
+    "bo_root_info": (C.c_int, [C.c_void_p, _I32P, _I32P, _I32P, C.c_void_p]),
+    "bo_search_begin": (C.c_int, [C.c_void_p, _I32P, _F64P, C.c_void_p, C.c_void_p]),
+    "bo_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "bo_search_poll": (C.c_int, [C.c_void_p, _I32P, _I32P, _I32P, C.c_void_p]),
+    "bo_search_result": (C.c_int, [C.c_void_p, _I32P, _I32P, _F32P, _I32P, _I32P, _I32P, C.c_void_p]),
+    "bo_play": (C.c_int, [C.c_void_p, _I32P, C.c_void_p]),
+    "bo_game_export": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BoPosition), _I32P, C.c_int32, _I32P, C.c_void_p]),
+    "bo_game_encode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "bo_debug_tree": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BoNode), C.c_int32, _I32P, C.c_void_p]),
+    "bo_engine_status": (C.c_int, [C.c_void_p, _I32P, _I32P, _I32P, _I32P, _I32P, _I32P, C.c_void_p]),
+    "bo_movegen_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BoPosition), _I32P, _I32P, _I32P, C.c_void_p]),
+    "bo_select_wide": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+HIP_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libbetaone_hip.so")
+
+
+def bind(cdll: C.CDLL) -> C.CDLL:
+    """Attach argument/return types for every symbol include/betaone_engine.h declares."""
+    for name, (res, args) in _SYMBOLS.items():
+        fn = getattr(cdll, name)  # AttributeError here == library does not export the ABI
+        fn.restype = res
+        fn.argtypes = args
+    return cdll
+
+
+_hip_lib: Optional[C.CDLL] = None
+
+
+def load_hip_library() -> C.CDLL:
+    """The product's only loader: csrc/libbetaone_hip.so or an exception."""
+    global _hip_lib
+    if _hip_lib is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise EngineError(f"{HIP_LIB_PATH} is missing: build it with `python -m betaone_amd.build` "
+                              "(hipcc --offload-arch=gfx950); betaone_amd has no CPU fallback")
+        _hip_lib = bind(C.CDLL(HIP_LIB_PATH))
+        if _hip_lib.bo_abi_version() != 1:
+            raise EngineError("libbetaone_hip.so ABI version mismatch")
+    return _hip_lib
+
+
+def move_to_uci(m: int) -> str:
+    f, t, p = m & 63, (m >> 6) & 63, (m >> 12) & 7
+    s = "abcdefgh"[f & 7] + str((f >> 3) + 1) + "abcdefgh"[t & 7] + str((t >> 3) + 1)
+    return s + (" pnbrqk"[p] if p else "")
+
+
+def _i32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a: np.ndarray, typ=_I32P):
+    return a.ctypes.data_as(typ)
+
+
+class Engine:
+    """G game slots on one GPU.  All pointer arguments are raw addresses (tensor.data_ptr())."""
+
+    def __init__(self, n_games: int, num_simulations: int = 250, mcts_batch_size: int = 96, cpuct: float = 1.0,
+                 widen_coeff: float = 1.5, dirichlet_alpha: float = 0.1, dirichlet_epsilon: float = 0.25,
+                 max_plies: int = 1024, device: int = 0, lib: Optional[C.CDLL] = None):
+        self.lib = lib if lib is not None else load_hip_library()
+        self.G = int(n_games)
+        self.cfg = BoConfig(n_games, num_simulations, mcts_batch_size, max_plies, cpuct, widen_coeff, dirichlet_alpha,
+                            dirichlet_epsilon)
+        self.num_simulations, self.dirichlet_alpha = num_simulations, dirichlet_alpha
+        h = C.c_void_p()
+        self._check(self.lib.bo_engine_create(C.byref(self.cfg), device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bo_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise EngineError(f"betaone engine error {rc}: {self.lib.bo_last_error().decode()}")
+
+    # -- set-up ----------------------------------------------------------------------------------
+    @staticmethod
+    def _strs(items: Optional[Sequence[Optional[str]]], n: int):
+        arr = (C.c_char_p * n)()
+        for i in range(n):
+            v = items[i] if items is not None else None
+            arr[i] = v.encode() if v is not None else None
+        return arr
+
+    def reset(self, slots: Sequence[int], fens: Optional[Sequence[Optional[str]]] = None,
+              moves: Optional[Sequence[Optional[str]]] = None, stream: int = 0):
+        s = _i32(slots)
+        n = len(s)
+        self._check(self.lib.bo_games_reset(self.h, n, _p(s), self._strs(fens, n), self._strs(moves, n), stream))
+
+    def reset_ex(self, slots, fens, moves, hist: Sequence[Sequence[BoPosition]],
+                 trk: Sequence[Sequence[Tuple[BoPosition, int]]], stream: int = 0):
+        s = _i32(slots)
+        n = len(s)
+        harr = (BoPosition * (7 * n))()
+        nh = np.zeros(n, dtype=np.int32)
+        off = np.zeros(n + 1, dtype=np.int32)
+        flat, cnts = [], []
+        for i in range(n):
+            nh[i] = len(hist[i])
+            for k, p in enumerate(hist[i]):
+                harr[i * 7 + k] = p
+            for p, c in trk[i]:
+                flat.append(p)
+                cnts.append(c)
+            off[i + 1] = len(flat)
+        tarr = (BoPosition * max(1, len(flat)))(*flat)
+        tc = _i32(cnts if cnts else [0])
+        self._check(self.lib.bo_games_reset_ex(self.h, n, _p(s), self._strs(fens, n), self._strs(moves, n), harr, _p(nh),
+                                               tarr, _p(tc), _p(off), stream))
+
+    def root_info(self, stream: int = 0):
+        nl, tm, ply = (np.zeros(self.G, dtype=np.int32) for _ in range(3))
+        self._check(self.lib.bo_root_info(self.h, _p(nl), _p(tm), _p(ply), stream))
+        return nl, tm, ply
+
+    # -- search ----------------------------------------------------------------------------------
+    def search_begin(self, go, noise: Optional[np.ndarray], nn_in_ptr: int, stream: int = 0):
+        g = _i32(go)
+        nz = None
+        if noise is not None:
+            nz = np.ascontiguousarray(noise, dtype=np.float64).reshape(self.G, MAX_LEGAL)
+        self._check(self.lib.bo_search_begin(self.h, _p(g), _p(nz, _F64P) if nz is not None else None, nn_in_ptr, stream))
+
+    def step(self, policy_ptr: int, value_ptr: int, kind: int, nn_in_ptr: int, stream: int = 0):
+        self._check(self.lib.bo_step(self.h, policy_ptr, value_ptr, kind, nn_in_ptr, stream))
+
+    def poll(self, stream: int = 0, want_mask: bool = True):
+        run, req = C.c_int32(), C.c_int32()
+        mask = np.zeros(self.G, dtype=np.int32) if want_mask else None
+        self._check(self.lib.bo_search_poll(self.h, C.byref(run), C.byref(req), _p(mask) if want_mask else None, stream))
+        return run.value, req.value, mask
+
+    def result(self, stream: int = 0) -> Dict[str, np.ndarray]:
+        G = self.G
+        out = dict(n=np.zeros(G, np.int32), idx=np.zeros((G, RES_CAP), np.int32), val=np.zeros((G, RES_CAP), np.float32),
+                   best_idx=np.zeros(G, np.int32), best_move=np.zeros(G, np.int32), total=np.zeros(G, np.int32))
+        self._check(self.lib.bo_search_result(self.h, _p(out["n"]), _p(out["idx"]), _p(out["val"], _F32P),
+                                              _p(out["best_idx"]), _p(out["best_move"]), _p(out["total"]), stream))
+        return out
+
+    def play(self, actions, stream: int = 0):
+        a = _i32(actions)
+        assert a.shape == (self.G,)
+        self._check(self.lib.bo_play(self.h, _p(a), stream))
+
+    # -- records / introspection --------------------------------------------------------------------
+    def export_game(self, slot: int, stream: int = 0):
+        cap = self.cfg.max_plies + 1
+        pos = (BoPosition * cap)()
+        mv = np.zeros(cap, dtype=np.int32)
+        n = C.c_int32()
+        self._check(self.lib.bo_game_export(self.h, slot, pos, _p(mv), cap, C.byref(n), stream))
+        return [pos[i] for i in range(n.value + 1)], [int(m) for m in mv[:n.value]]
+
+    def encode_game(self, slot: int, first: int, n: int, out_ptr: int, stream: int = 0):
+        self._check(self.lib.bo_game_encode(self.h, slot, first, n, out_ptr, stream))
+
+    def debug_tree(self, slot: int, stream: int = 0) -> List[dict]:
+        n = C.c_int32()
+        self._check(self.lib.bo_debug_tree(self.h, slot, None, 0, C.byref(n), stream))
+        arr = (BoNode * max(1, n.value))()
+        self._check(self.lib.bo_debug_tree(self.h, slot, arr, n.value, C.byref(n), stream))
+        return [dict(parent=a.parent, n=a.n_visits, q=np.float32(a.q_value), prior=np.float32(a.prior), move=a.move,
+                     n_children=a.n_children, first_child=a.first_child, terminal=a.terminal) for a in arr[:n.value]]
+
+    def status(self, stream: int = 0) -> Dict[str, np.ndarray]:
+        names = ["status", "evals", "flushes", "term_sims", "levels", "children_scanned"]
+        out = {k: np.zeros(self.G, np.int32) for k in names}
+        self._check(self.lib.bo_engine_status(self.h, *[_p(out[k]) for k in names], stream))
+        return out
+
+    def check_status(self):
+        st = self.status()["status"]
+        bad = np.nonzero(st)[0]
+        if len(bad):
+            g = int(bad[0])
+            msg = ", ".join(v for b, v in STATUS_BITS.items() if st[g] & b)
+            raise EngineError(f"game slot {g}: {msg}")
+
+    def movegen(self, positions: Sequence[BoPosition], stream: int = 0):
+        n = len(positions)
+        arr = (BoPosition * n)(*positions)
+        mv = np.zeros((n, MAX_LEGAL), np.int32)
+        cnt, chk = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        self._check(self.lib.bo_movegen_batch(self.h, n, arr, _p(mv), _p(cnt), _p(chk), stream))
+        return [[int(m) for m in mv[i, :cnt[i]]] for i in range(n)], chk

@@ -1,0 +1,174 @@
+/*
+ * include/betaone_engine.h -- C ABI of the MI355X self-play rollout engine (libbetaone_hip.so).
+ *
+ * The reference (kevinh-e/BetaOne) has no FFI layer: its hot path is plain Python
+ *   run_mcts(root_board, model, history, tracker)      /root/reference/mcts.py:155-280
+ *   _evaluate_batch(nodes, paths, model)               /root/reference/mcts.py:283-295
+ *   run_self_play_game(model, game_id)                 /root/reference/self_play.py:84-216
+ *   utils.encode_board / move_to_index / index_to_move /root/reference/utils.py:111-365
+ * called by main.py:56 and uci.py:63,84.  This header is what a ctypes binding of that path
+ * binds instead; INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a negative
+ * BO_E_* code and never throws; bo_last_error() gives the text.  "dev" pointers are raw device
+ * addresses (tensor.data_ptr()); `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * All kernels are enqueued on `stream`; functions documented as "synchronises" wait for it.
+ * One engine = one GPU = G game slots; NN input row g / policy row g / value g belong to slot g.
+ */
+#ifndef BETAONE_ENGINE_H
+#define BETAONE_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BO_ABI_VERSION 1
+#define BO_NUM_ACTIONS 4672          /* config.NUM_ACTIONS, config.py:29 */
+#define BO_INPUT_CHANNELS 120        /* config.INPUT_CHANNELS, config.py:28 */
+#define BO_ROW_FLOATS (120 * 64)
+#define BO_MAX_LEGAL 256
+#define BO_RES_CAP 256
+
+enum {
+    BO_OK = 0,
+    BO_E_ARG = -1,        /* bad argument */
+    BO_E_HIP = -2,        /* HIP runtime error */
+    BO_E_CONFIG = -3,     /* unsupported configuration (see bo_engine_create) */
+    BO_E_FEN = -4,        /* unparsable FEN / UCI move */
+    BO_E_STATE = -5       /* call out of order */
+};
+
+/* per-game status bits reported by bo_engine_status() */
+enum {
+    BO_ST_NODE_OVERFLOW = 1, BO_ST_DEPTH_OVERFLOW = 2, BO_ST_NAN_SCORE = 4, BO_ST_PLY_OVERFLOW = 8,
+    BO_ST_ILLEGAL_ACTION = 16, BO_ST_UL_OVERFLOW = 32, BO_ST_TRK_OVERFLOW = 64
+};
+
+enum { BO_POLICY_NONE = 0, BO_POLICY_LOGITS = 1, BO_POLICY_PROBS = 2 };
+
+/* The constants of config.py that the path reads at call time (config.py:32-41,59). */
+typedef struct {
+    int32_t n_games;            /* G: game slots resident on this GPU */
+    int32_t num_simulations;    /* config.NUM_SIMULATIONS */
+    int32_t mcts_batch_size;    /* config.MCTS_BATCH_SIZE */
+    int32_t max_plies;          /* capacity of one game's position stack (>= plies + 2) */
+    double cpuct;               /* config.CPUCT */
+    double widen_coeff;         /* config.WIDEN_COEFF (>= 1.0, int(w*sqrt(batch)) <= 32) */
+    double dirichlet_alpha;     /* config.DIRICHLET_ALPHA (only its sign is used on the device) */
+    double dirichlet_epsilon;   /* config.DIRICHLET_EPSILON */
+} bo_config;
+
+/* A position as plain data.  bb: pawns, knights, bishops, rooks, queens, kings, white, black. */
+typedef struct {
+    uint64_t bb[8];
+    int32_t turn;             /* 1 white, 0 black */
+    uint32_t castling;        /* bit0 K, bit1 Q, bit2 k, bit3 q */
+    int32_t ep_square;        /* python-chess Board.ep_square, -1 = None */
+    int32_t ep_key;           /* -2: derive (ep square iff an ep capture is legal); else the key's ep (-1 none) */
+    int32_t halfmove_clock;
+    int32_t fullmove_number;
+} bo_position;
+
+typedef struct bo_engine bo_engine;
+
+int bo_abi_version(void);
+const char *bo_last_error(void);
+
+int bo_engine_create(const bo_config *cfg, int device, bo_engine **out);
+void bo_engine_destroy(bo_engine *e);
+
+/* ---- game set-up ---------------------------------------------------------------------------
+ * (Re)start the games in `slots[0..n)`: position `fens[i]` (NULL = standard start, self_play.py:91)
+ * followed by the space-separated UCI moves `moves[i]` (NULL = none) -- i.e. a python-chess Board
+ * with its move stack, which the draw rules need (mcts.py:36,152).  The repetition tracker holds
+ * every position of that stack and the history planes use the <=7 positions before the current
+ * one (self_play.py:93-109,182-184).  Also prepares the first search root.  Synchronises. */
+int bo_games_reset(bo_engine *e, int n, const int32_t *slots, const char *const *fens, const char *const *moves,
+                   void *stream);
+
+/* Same, but with the caller's own history boards and tracker contents (uci.py:62-63 passes
+ * whatever it accumulated): hist[i*7 .. i*7+n_hist[i]) boards BEFORE the root (oldest first),
+ * tracker keys trk[trk_off[i] .. trk_off[i+1]) with their counts.  Synchronises. */
+int bo_games_reset_ex(bo_engine *e, int n, const int32_t *slots, const char *const *fens, const char *const *moves,
+                      const bo_position *hist, const int32_t *n_hist, const bo_position *trk,
+                      const int32_t *trk_counts, const int32_t *trk_off, void *stream);
+
+/* Root facts the host needs before a search: number of legal moves (np.random.dirichlet needs it,
+ * mcts.py:191-192) and is_game_over(claim_draw=True) of the current position (0 no, 1 side to move
+ * is checkmated, 2 draw; self_play.py:101-102).  Synchronises.  Arrays are [G]. */
+int bo_root_info(bo_engine *e, int32_t *n_legal, int32_t *terminal, int32_t *ply, void *stream);
+
+/* ---- one search per game, all games in lock step ------------------------------------------------
+ * bo_search_begin: start run_mcts for every slot with go[g] != 0.  noise[g*256 + i] is the
+ * Dirichlet sample of the i-th legal move of game g in python-chess order (mcts.py:192-198);
+ * may be NULL when dirichlet_alpha <= 0.  Writes planes 0..97 of NN input row g (nn_in_dev,
+ * float32 [G,120,8,8], NCHW contiguous). */
+int bo_search_begin(bo_engine *e, const int32_t *go, const double *noise, float *nn_in_dev, void *stream);
+
+/* bo_step: consume the net's output for the rows requested by the previous step (policy_dev
+ * float32 [G,4672] logits or softmax probabilities per `policy_kind`, value_dev float32 [G]),
+ * run select / terminal backups / expand+backup flushes until each game needs its next
+ * evaluation, and write that leaf's planes into nn_in_dev row g.  First call of a search:
+ * policy_kind = BO_POLICY_NONE.  Asynchronous on `stream`. */
+int bo_step(bo_engine *e, const float *policy_dev, const float *value_dev, int policy_kind, float *nn_in_dev,
+            void *stream);
+
+/* How many searches are still running / how many rows were requested by the last step.
+ * requested_mask (optional, [G] int32) marks the rows the net must evaluate.  Synchronises. */
+int bo_search_poll(bo_engine *e, int32_t *n_running, int32_t *n_requested, int32_t *requested_mask, void *stream);
+
+/* Result of the finished searches (mcts.py:259-280): sparse pi (res_n[g] entries of
+ * (action index, probability) at [g*BO_RES_CAP ..]), best move as action index (-1: no legal
+ * move, the reference raises ValueError) and as from|to<<6|promo<<12, total root-child visits.
+ * Synchronises. */
+int bo_search_result(bo_engine *e, int32_t *res_n, int32_t *res_idx, float *res_val, int32_t *best_idx,
+                     int32_t *best_move, int32_t *total_visits, void *stream);
+
+/* self_play.py:125-184: play action[g] (an index into the 4672 actions; -2 = play the search's
+ * best move; -1 = leave the game alone) with the reference's decode-error / illegal-move
+ * fallbacks, push it on the game's stack and tracker, prepare the next root.  Asynchronous. */
+int bo_play(bo_engine *e, const int32_t *action, void *stream);
+
+/* ---- records ------------------------------------------------------------------------------------
+ * The game in `slot` as plain data: its positions[0..n_plies] and moves[0..n_plies). */
+int bo_game_export(bo_engine *e, int slot, bo_position *positions, int32_t *moves, int32_t cap, int32_t *n_plies,
+                   void *stream);
+/* Training encodings of plies [first, first+n) of the game in `slot` with the CURRENT (end of
+ * game) tracker, float32 [n,120,8,8] into out_dev (self_play.py:200-208).  Asynchronous. */
+int bo_game_encode(bo_engine *e, int slot, int first, int n, float *out_dev, void *stream);
+
+/* ---- introspection (parity tests, profiling) ------------------------------------------------- */
+typedef struct {
+    int32_t parent, n_visits, first_child, n_children;
+    float q_value, prior;
+    int32_t move;      /* from|to<<6|promo<<12 */
+    int32_t terminal;  /* -1 never visited as leaf, 0 no, 1 mate, 2 draw */
+} bo_node;
+int bo_debug_tree(bo_engine *e, int slot, bo_node *out, int32_t cap, int32_t *n_nodes, void *stream);
+/* per game [G]: status bits, NN evaluations, flushes, terminal simulations, tree levels descended,
+ * children scanned by the PUCT select (the last two give the select kernel's algorithmic bytes). */
+int bo_engine_status(bo_engine *e, int32_t *status, int32_t *evals, int32_t *flushes, int32_t *term_sims,
+                     int32_t *levels, int32_t *children_scanned, void *stream);
+
+/* ---- stand-alone kernels -------------------------------------------------------------------------
+ * Legal moves (python-chess order) of n raw positions: moves_out [n,256] int32, n_out [n], check_out [n]. */
+int bo_movegen_batch(bo_engine *e, int n, const bo_position *pos, int32_t *moves_out, int32_t *n_out,
+                     int32_t *check_out, void *stream);
+
+/* PUCT select (mcts.py:72-118 arithmetic) over caller-provided WIDE trees, the HBM-roofline workload of
+ * SURVEY.md section 8d.  blocks_dev: array of 512-byte child blocks
+ *   { int32 n[32]; float q[32]; float prior[32]; int32 child_block[32] (-1 = leaf) }
+ * root_block_dev[t] / root_n_dev[t]: root child block and root visit count of tree t; sqrt_lut_dev[n] =
+ * f32(sqrt(n + 1e-8)).  out_leaf_dev[t] = block*32 + child of the selected leaf, out_levels_dev[t] = levels
+ * descended (x 392 B = algorithmic bytes).  grid_blocks <= 0 picks one 256-thread workgroup per 8 trees.
+ * Asynchronous on `stream`. */
+int bo_select_wide(const void *blocks_dev, const int32_t *root_block_dev, const int32_t *root_n_dev,
+                   const float *sqrt_lut_dev, int n_trees, int max_depth, float cpuct, int grid_blocks,
+                   int32_t *out_leaf_dev, int32_t *out_levels_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

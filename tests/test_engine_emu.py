@@ -1,0 +1,35 @@
+"""CPU tests of the ENGINE'S DEVICE CODE (betaone_amd/csrc) under the 64-lane wave emulator: the
+same sources hipcc compiles for gfx950, executed lane by lane on the CPU.  They check kernel logic
+(and memory safety) before any GPU minute is spent; the `-m gpu` tests repeat them on the product
+library.  Nothing here is a product path."""
+import numpy as np
+import pytest
+
+import engine_cases as EC
+
+
+@pytest.fixture(scope="module")
+def backend():
+    return "emu"
+
+
+def test_movegen_matches_oracle_order(backend):
+    EC.check_movegen_random_positions(backend, n_games=12, max_plies=60, seed=0)
+
+
+def test_movegen_special_positions(backend):
+    EC.check_movegen_special(backend)
+
+
+@pytest.mark.parametrize("name", EC.SEARCH_NAMES)
+def test_search_matches_reference_trace(backend, name):
+    EC.check_golden_search(backend, name)
+
+
+@pytest.mark.parametrize("name", EC.GAME_NAMES)
+def test_self_play_game_matches_reference(backend, name):
+    EC.check_golden_game(backend, name)
+
+
+def test_many_games_in_lockstep_match_oracle(backend):
+    EC.check_multi_game_vs_oracle(backend, n_games=5, plies=6, sims=60, batch=16)
