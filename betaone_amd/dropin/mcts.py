@@ -1,0 +1,159 @@
+"""
+mcts -- `run_mcts(root_board, model, history, tracker)` of /root/reference/mcts.py:155-280 over the
+MI355X engine.  Same signature, same return value `(best_move, pi float32[4672])`, same error
+behaviour (ValueError on a root without legal moves, mcts.py:279), callable from uci.py's search
+thread (ctypes releases the GIL).  The tree arithmetic of MCTSNode (mcts.py:19-152) runs in
+betaone_amd/csrc/bo_tree.h; this file only marshals the caller's duck-typed python-chess objects
+into plain data and runs the evaluate stage under PyTorch-ROCm.
+"""
+import sys
+import threading
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+import config
+from betaone_amd import engine as E
+
+_lock = threading.Lock()
+_ctx = {}            # config tuple -> (Engine, nn_in tensor)
+_test_backend = None  # tests only: (ctypes library, torch device string)
+
+
+def _set_test_backend(lib, device: str = "cpu"):
+    """tests/ only: bind the drop-in to the wave-emulator build of the engine."""
+    global _test_backend
+    _test_backend = (lib, device) if lib is not None else None
+    _ctx.clear()
+
+
+def _context():
+    key = (config.NUM_SIMULATIONS, config.MCTS_BATCH_SIZE, config.CPUCT, config.WIDEN_COEFF, config.DIRICHLET_ALPHA,
+           config.DIRICHLET_EPSILON, _test_backend is not None)
+    if key not in _ctx:
+        if _test_backend is not None:
+            lib, dev = _test_backend
+        else:
+            lib, dev = None, config.DEVICE
+            if not str(dev).startswith("cuda"):
+                raise E.EngineError("mcts.run_mcts needs config.DEVICE == 'cuda' (MI355X); there is no CPU path")
+        device = torch.device(dev)
+        eng = E.Engine(1, num_simulations=config.NUM_SIMULATIONS, mcts_batch_size=config.MCTS_BATCH_SIZE,
+                       cpuct=config.CPUCT, widen_coeff=config.WIDEN_COEFF, dirichlet_alpha=config.DIRICHLET_ALPHA,
+                       dirichlet_epsilon=config.DIRICHLET_EPSILON, max_plies=config.ENGINE_MAX_PLIES,
+                       device=device.index or 0, lib=lib)
+        nn_in = torch.zeros((1, config.INPUT_CHANNELS, 8, 8), dtype=torch.float32, device=device)
+        _ctx.clear()  # one live engine is enough for the single-search path
+        _ctx[key] = (eng, nn_in)
+    return _ctx[key]
+
+
+def _castling_bits(rights: int) -> int:
+    return (1 if rights & (1 << 7) else 0) | (2 if rights & 1 else 0) | (4 if rights & (1 << 63) else 0) | \
+           (8 if rights & (1 << 56) else 0)
+
+
+def board_to_position(board) -> E.BoPosition:
+    p = E.BoPosition()
+    occ = board.occupied_co
+    for i, v in enumerate((board.pawns, board.knights, board.bishops, board.rooks, board.queens, board.kings,
+                           occ[True], occ[False])):
+        p.bb[i] = int(v)
+    p.turn = 1 if board.turn else 0
+    rights = board.clean_castling_rights() if hasattr(board, "clean_castling_rights") else board.castling_rights
+    p.castling = _castling_bits(int(rights))
+    p.ep_square = -1 if board.ep_square is None else int(board.ep_square)
+    p.ep_key = -2
+    p.halfmove_clock, p.fullmove_number = int(board.halfmove_clock), int(board.fullmove_number)
+    return p
+
+
+def key_to_position(key) -> E.BoPosition:
+    """python-chess Board._transposition_key() tuple -> plain data."""
+    p = E.BoPosition()
+    for i in range(8):
+        p.bb[i] = int(key[i])
+    p.turn = 1 if key[8] else 0
+    p.castling = _castling_bits(int(key[9]))
+    p.ep_square = p.ep_key = -1 if key[10] is None else int(key[10])
+    p.halfmove_clock, p.fullmove_number = 0, 1
+    return p
+
+
+def board_to_stack(board) -> Tuple[str, Optional[str]]:
+    """(FEN of the bottom of the move stack, UCI moves) -- the draw rules need the whole stack (mcts.py:36,152)."""
+    b = board.copy()
+    ucis = []
+    while b.move_stack:
+        ucis.append(b.pop().uci())
+    try:
+        fen = b.fen(en_passant="fen")
+    except TypeError:
+        fen = b.fen()
+    return fen, (" ".join(reversed(ucis)) or None)
+
+
+def _make_move(board, m: int):
+    f, t, promo = m & 63, (m >> 6) & 63, (m >> 12) & 7
+    mod = sys.modules.get(type(board).__module__)
+    cls = getattr(mod, "Move", None)
+    if cls is None:
+        import chess
+
+        cls = chess.Move
+    return cls(f, t, promotion=promo or None)
+
+
+def _evaluate(model, nn_in):
+    with torch.no_grad():
+        if config.AUTOCAST:
+            with torch.autocast(nn_in.device.type):
+                logits, value = model(nn_in)
+        else:
+            logits, value = model(nn_in)
+    return logits.float().contiguous(), value.float().contiguous()
+
+
+def run_mcts(root_board, model, history: List, tracker) -> Tuple[object, np.ndarray]:
+    with _lock:
+        eng, nn_in = _context()
+        fen, moves = board_to_stack(root_board)
+        hist = [board_to_position(b) for b in list(history)[-7:]]          # (history + [root])[-8:], mcts.py:180
+        trk = [(key_to_position(k), int(c)) for k, c in tracker.counts.items() if c > 0]
+        eng.reset_ex([0], [fen], [moves], [hist], [trk])
+        n_legal, terminal, _ = eng.root_info()
+        noise = None
+        if config.DIRICHLET_ALPHA > 0:
+            noise = np.zeros((1, E.MAX_LEGAL))
+            if terminal[0] == 0:
+                noise[0, :n_legal[0]] = np.random.dirichlet([config.DIRICHLET_ALPHA] * int(n_legal[0]))  # mcts.py:192
+        cuda = nn_in.device.type == "cuda"
+        stream = torch.cuda.current_stream(nn_in.device).cuda_stream if cuda else 0
+        eng.search_begin([1], noise, nn_in.data_ptr(), stream)
+        eng.step(0, 0, E.POLICY_NONE, nn_in.data_ptr(), stream)
+        keep = None
+        while True:
+            running, _, _ = eng.poll(stream, want_mask=False)
+            if running == 0:
+                break
+            keep = _evaluate(model, nn_in)
+            eng.step(keep[0].data_ptr(), keep[1].data_ptr(), E.POLICY_LOGITS, nn_in.data_ptr(), stream)
+        eng.check_status()
+        res = eng.result(stream)
+        if res["best_idx"][0] < 0:
+            raise ValueError("max() arg is an empty sequence")  # mcts.py:279 on a root without legal moves
+        pi = np.zeros(config.NUM_ACTIONS, dtype=np.float32)
+        n = int(res["n"][0])
+        pi[res["idx"][0, :n]] = res["val"][0, :n]
+        return _make_move(root_board, int(res["best_move"][0])), pi
+
+
+class MCTS:
+    """North-star alias (BASELINE.json): MCTS(model).search(board, history, tracker) == run_mcts(...)."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def search(self, root_board, history, tracker):
+        return run_mcts(root_board, self.model, history, tracker)

@@ -1,0 +1,140 @@
+"""
+self_play -- `run_self_play_game(model, game_id)` / `save_game_data` of
+/root/reference/self_play.py:84-231 over the MI355X engine, plus the batched entry point the engine is
+built for (`run_self_play_games`: thousands of games in one process, one RandomState per game).
+
+Return type is the reference's: a list of `(torch.FloatTensor[120,8,8], np.ndarray float32[4672], float)`
+per ply, or None when the game was aborted (self_play.py:119,167,180); main.py and train.py consume it
+unchanged (pickle format of save_game_data, train.py:187-219).
+"""
+import os
+import pickle
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+import config
+from betaone_amd import engine as E
+from betaone_amd import sampling
+from betaone_amd.rollout import FinishedGame, Rollout
+
+SelfPlayData = Tuple[torch.Tensor, np.ndarray, float]
+
+_test_backend = None  # tests only: (ctypes library, device string)
+
+
+def _set_test_backend(lib, device: str = "cpu"):
+    global _test_backend
+    _test_backend = (lib, device) if lib is not None else None
+
+
+def apply_temperature(probs: np.ndarray, temperature: float) -> np.ndarray:
+    return sampling.apply_temperature(probs, temperature, np.random)
+
+
+def select_move_with_temperature(probs: np.ndarray, move_number: int) -> int:
+    return sampling.select_move_with_temperature(probs, move_number, np.random, config.TEMPERATURE_THRESHOLD,
+                                                 config.TEMPERATURE_INITIAL, config.TEMPERATURE_FINAL)
+
+
+def _rollout(model, n_slots: int) -> Rollout:
+    lib, dev = (None, config.DEVICE) if _test_backend is None else _test_backend
+    if _test_backend is None and not str(dev).startswith("cuda"):
+        raise E.EngineError("self_play needs config.DEVICE == 'cuda' (MI355X); there is no CPU path")
+    return Rollout(model, n_slots, num_simulations=config.NUM_SIMULATIONS, mcts_batch_size=config.MCTS_BATCH_SIZE,
+                   cpuct=config.CPUCT, widen_coeff=config.WIDEN_COEFF, dirichlet_alpha=config.DIRICHLET_ALPHA,
+                   dirichlet_epsilon=config.DIRICHLET_EPSILON, max_plies=config.ENGINE_MAX_PLIES,
+                   max_game_moves=config.MAX_GAME_MOVES,
+                   temperature=(config.TEMPERATURE_THRESHOLD, config.TEMPERATURE_INITIAL, config.TEMPERATURE_FINAL),
+                   device=dev, autocast=config.AUTOCAST, use_graph=_test_backend is None, lib=lib)
+
+
+def _records(ro: Rollout, fin: FinishedGame) -> List[SelfPlayData]:
+    n = len(fin.pis)
+    states = ro.encode_finished_in_slot(fin.slot, n).cpu()
+    out = []
+    for i in range(n):
+        idx, val = fin.pis[i]
+        out.append((states[i].clone(), sampling.dense_pi(idx, val), fin.z(i)))
+    return out
+
+
+def run_self_play_games(model, game_ids: Sequence[int], seeds: Optional[Sequence[int]] = None,
+                        n_slots: Optional[int] = None, start_fens: Optional[Sequence[Optional[str]]] = None
+                        ) -> Dict[int, Optional[List[SelfPlayData]]]:
+    """Play len(game_ids) games, n_slots at a time, on one GPU.  Game i draws its Dirichlet noise and its
+    moves from numpy.random.RandomState(seeds[i]) -- the stream the reference consumes after
+    np.random.seed(seeds[i]) -- so results do not depend on n_slots or on which GPU a game lands on."""
+    ids = list(game_ids)
+    seeds = list(seeds) if seeds is not None else ids
+    n_slots = min(n_slots or len(ids), len(ids))
+    ro = _rollout(model, n_slots)
+    results: Dict[int, Optional[List[SelfPlayData]]] = {}
+    queue = list(range(len(ids)))
+
+    def next_game(_slot):
+        if not queue:
+            return None
+        i = queue.pop(0)
+        return ids[i], np.random.RandomState(seeds[i]), (start_fens[i] if start_fens else None)
+
+    def finished(fin: FinishedGame):
+        if fin.terminal == 0:
+            print(f"Game {fin.game_id} aborted after {len(fin.moves)} moves (max).")  # self_play.py:186-187
+        results[fin.game_id] = _records(ro, fin)
+
+    first = [next_game(s) for s in range(n_slots)]
+    ro.start_games(list(range(n_slots)), [f[0] for f in first], [f[1] for f in first], [f[2] for f in first])
+    try:
+        while any(g is not None for g in ro.games):
+            ro.play_ply(on_finished=finished, refill=next_game)
+            bad = np.nonzero(ro.eng.status()["status"])[0]
+            for g in bad:  # aborted games return None (self_play.py:119,167,180)
+                if ro.games[g] is not None:
+                    results[ro.games[g].game_id] = None
+                    ro.games[g] = None
+            if len(bad):
+                break
+    finally:
+        ro.close()
+    return results
+
+
+def run_self_play_game(model, game_id: int) -> Optional[List[SelfPlayData]]:
+    """self_play.py:84-216: one game from the standard start position, RNG = numpy's process-global
+    legacy generator exactly as in the reference (mcts.py:192, self_play.py:73)."""
+    ro = _rollout(model, 1)
+    out: List[Optional[List[SelfPlayData]]] = [None]
+
+    def finished(fin: FinishedGame):
+        if fin.terminal == 0:
+            print(f"Game {game_id} aborted after {len(fin.moves)} moves (max).")
+        out[0] = _records(ro, fin)
+
+    ro.start_games([0], [game_id], [np.random])
+    try:
+        while ro.games[0] is not None:
+            ro.play_ply(on_finished=finished)
+            if ro.eng.status()["status"][0]:
+                return None
+    finally:
+        ro.close()
+    return out[0]
+
+
+play_game = run_self_play_game  # north-star alias (BASELINE.json)
+
+
+def save_game_data(game_data: List[SelfPlayData], iteration: int, game_id: int):
+    """self_play.py:220-231: pickle to DATA_DIR/iter_{iteration}/game_{game_id}.pkl."""
+    if not game_data:
+        return
+    data_dir = os.path.join(config.DATA_DIR, f"iter_{iteration}")
+    os.makedirs(data_dir, exist_ok=True)
+    filepath = os.path.join(data_dir, f"game_{game_id}.pkl")
+    try:
+        with open(filepath, "wb") as f:
+            pickle.dump(game_data, f)
+    except Exception as e:
+        print(f"Error saving game data to {filepath}: {e}")

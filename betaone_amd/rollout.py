@@ -1,0 +1,241 @@
+"""
+betaone_amd/rollout.py -- the self-play rollout driver: G concurrent games on one MI355X.
+
+Host side of what the reference does one game at a time in Python
+  run_mcts              /root/reference/mcts.py:155-280
+  _evaluate_batch       /root/reference/mcts.py:283-295
+  run_self_play_game    /root/reference/self_play.py:84-216
+re-organised for the GPU: the trees of all G games live in HBM and advance in lock step through
+the engine's kernels (include/betaone_engine.h); each step evaluates ONE leaf per game, so the net
+always sees a static [G,120,8,8] batch (NN row g <-> game slot g) and `net forward + tree step` is
+captured once as a hipGraph and replayed.  The host only does the per-move NumPy work whose RNG
+stream has to stay bit-identical to the reference (Dirichlet noise, temperature sampling) and
+recycles the slots of finished games.
+
+There is no CPU path here: the engine is csrc/libbetaone_hip.so or an exception.
+"""
+from __future__ import annotations
+
+import math
+import time
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import engine as E
+from . import sampling
+
+
+@dataclass
+class GameState:
+    """Host-side bookkeeping of one game slot (what run_self_play_game keeps in locals)."""
+    game_id: int
+    rng: object                      # numpy RandomState (or the numpy.random module)
+    start_fen: Optional[str] = None
+    start_fullmove: int = 1
+    start_white: bool = True
+    plies: int = 0
+    pis: List = field(default_factory=list)   # per ply: (action indices, float32 probabilities)
+
+    def fullmove_number(self) -> int:          # board.fullmove_number of the current root (self_play.py:104)
+        return self.start_fullmove + (self.plies + (0 if self.start_white else 1)) // 2
+
+
+@dataclass
+class FinishedGame:
+    game_id: int
+    slot: int
+    moves: List[int]                 # from|to<<6|promo<<12
+    positions: List[E.BoPosition]    # positions[i] = position before moves[i]; last = final position
+    pis: List                        # sparse pi per ply
+    outcome: float                   # utils.get_game_outcome of the final board, 0.0 if not over (self_play.py:190-197)
+    terminal: int                    # 0 stopped by move limit, 1 checkmate, 2 draw
+
+    def z(self, i: int) -> float:    # self_play.py:202
+        return self.outcome if self.positions[i].turn == 1 else -self.outcome
+
+
+def _fen_meta(fen: Optional[str]):
+    if not fen:
+        return 1, True
+    parts = fen.split()
+    white = len(parts) < 2 or parts[1] == "w"
+    full = max(1, int(parts[5])) if len(parts) > 5 else 1
+    return full, white
+
+
+class Rollout:
+    def __init__(self, model: torch.nn.Module, n_games: int, *, num_simulations: int = 250, mcts_batch_size: int = 96,
+                 cpuct: float = 1.0, widen_coeff: float = 1.5, dirichlet_alpha: float = 0.1,
+                 dirichlet_epsilon: float = 0.25, max_plies: int = 2048, max_game_moves: int = 16384,
+                 temperature=(30, 1.0, 0.1), device: str = "cuda:0", use_graph: bool = True, autocast: bool = False,
+                 lib=None):
+        if not str(device).startswith("cuda") and lib is None:
+            raise E.EngineError("betaone_amd.Rollout runs on an MI355X (device='cuda:N'); there is no CPU path")
+        self.device = torch.device(device)
+        self.G = int(n_games)
+        self.S, self.B = int(num_simulations), int(mcts_batch_size)
+        self.alpha = float(dirichlet_alpha)
+        self.max_game_moves = int(max_game_moves)
+        self.temperature = temperature
+        self.model = model
+        self.autocast = autocast
+        dev_index = self.device.index or 0
+        self.eng = E.Engine(self.G, num_simulations=self.S, mcts_batch_size=self.B, cpuct=cpuct, widen_coeff=widen_coeff,
+                            dirichlet_alpha=dirichlet_alpha, dirichlet_epsilon=dirichlet_epsilon, max_plies=max_plies,
+                            device=dev_index, lib=lib)
+        self.nn_in = torch.zeros((self.G, E.INPUT_CHANNELS, 8, 8), dtype=torch.float32, device=self.device)
+        self.expected_evals = 1 + math.ceil(self.S / self.B)
+        self.games: List[Optional[GameState]] = [None] * self.G
+        self.use_graph = bool(use_graph) and self.device.type == "cuda"
+        self._graph = None
+        self._logits = self._value = None
+        self.n_forward = 0          # NN forwards issued
+        self.n_sims = 0             # simulations completed (NUM_SIMULATIONS per finished search)
+        self.n_plies = 0
+        self.host_seconds = 0.0     # time spent in per-move host work (noise + sampling + bookkeeping)
+
+    # ---- evaluate + step -------------------------------------------------------------------------
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+
+    def _forward(self):
+        with torch.no_grad():
+            if self.autocast:
+                with torch.autocast(self.device.type):
+                    logits, value = self.model(self.nn_in)
+            else:
+                logits, value = self.model(self.nn_in)
+        return logits.float().contiguous(), value.float().contiguous()
+
+    def _eval_and_step_eager(self):
+        logits, value = self._forward()
+        self._logits, self._value = logits, value  # keep alive until the step kernel has run
+        self.eng.step(logits.data_ptr(), value.data_ptr(), E.POLICY_LOGITS, self.nn_in.data_ptr(), self._stream())
+
+    def _capture(self):
+        """Capture `net forward -> tree step` once; afterwards a step is one hipGraphLaunch."""
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(2):  # warm-up outside capture (MIOpen find, allocator)
+                self._forward()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            logits, value = self._forward()
+            self.eng.step(logits.data_ptr(), value.data_ptr(), E.POLICY_LOGITS, self.nn_in.data_ptr(), self._stream())
+        self._graph, self._logits, self._value = g, logits, value
+
+    def _eval_and_step(self):
+        self.n_forward += 1
+        if self.use_graph:
+            if self._graph is None:
+                # the engine's state must not advance during capture: capture is recorded, not executed
+                self._capture()
+            self._graph.replay()
+        else:
+            self._eval_and_step_eager()
+
+    # ---- game slots ---------------------------------------------------------------------------------
+    def start_games(self, slots: Sequence[int], game_ids: Sequence[int], rngs: Sequence, fens: Optional[Sequence] = None,
+                    moves: Optional[Sequence] = None):
+        self.eng.reset(list(slots), fens, moves, stream=self._stream())
+        for i, s in enumerate(slots):
+            fen = fens[i] if fens is not None else None
+            full, white = _fen_meta(fen)
+            self.games[s] = GameState(game_id=int(game_ids[i]), rng=rngs[i], start_fen=fen, start_fullmove=full,
+                                      start_white=white)
+            if moves is not None and moves[i]:
+                self.games[s].plies = len(moves[i].split())
+
+    # ---- one search for every active slot (run_mcts) ----------------------------------------------------
+    def search(self, go: np.ndarray, n_legal: np.ndarray, terminal: np.ndarray) -> Dict[str, np.ndarray]:
+        t0 = time.perf_counter()
+        noise = None
+        if self.alpha > 0:
+            noise = np.zeros((self.G, E.MAX_LEGAL), dtype=np.float64)
+            for g in np.nonzero(go)[0]:
+                if terminal[g] == 0:  # mcts.py:179: noise only for a non-terminal root
+                    noise[g, :n_legal[g]] = sampling.root_noise(n_legal[g], self.alpha, self.games[g].rng)
+        self.host_seconds += time.perf_counter() - t0
+        stream = self._stream()
+        self.eng.search_begin(go, noise, self.nn_in.data_ptr(), stream)
+        self.eng.step(0, 0, E.POLICY_NONE, self.nn_in.data_ptr(), stream)
+        burst = self.expected_evals
+        while True:
+            for _ in range(burst):
+                self._eval_and_step()
+            running, _, _ = self.eng.poll(self._stream(), want_mask=False)
+            if running == 0:
+                break
+            burst = 1
+        self.n_sims += int(np.count_nonzero(go)) * self.S
+        return self.eng.result(self._stream())
+
+    # ---- one ply for every active game (the body of self_play.py:101-184) --------------------------------
+    def play_ply(self, on_finished: Optional[Callable[[FinishedGame], None]] = None,
+                 refill: Optional[Callable[[int], Optional[tuple]]] = None) -> int:
+        """Advance every active game by one move.  Finished games are reported through `on_finished`
+        and their slots refilled by `refill(slot) -> (game_id, rng, fen)`.  Returns the number of
+        moves played."""
+        n_legal, terminal, ply = self.eng.root_info(self._stream())
+        t0 = time.perf_counter()
+        done_slots = [g for g in range(self.G) if self.games[g] is not None and
+                      (terminal[g] != 0 or self.games[g].plies >= self.max_game_moves)]
+        self.host_seconds += time.perf_counter() - t0
+        if done_slots:
+            new_slots, ids, rngs, fens = [], [], [], []
+            for g in done_slots:
+                fin = self._finish(g, int(terminal[g]))
+                if on_finished is not None:
+                    on_finished(fin)
+                self.games[g] = None
+                nxt = refill(g) if refill is not None else None
+                if nxt is not None:
+                    new_slots.append(g); ids.append(nxt[0]); rngs.append(nxt[1]); fens.append(nxt[2])
+            if new_slots:
+                self.start_games(new_slots, ids, rngs, fens)
+                n_legal, terminal, ply = self.eng.root_info(self._stream())
+        go = np.array([1 if (self.games[g] is not None and terminal[g] == 0) else 0 for g in range(self.G)], dtype=np.int32)
+        if not go.any():
+            return 0
+        res = self.search(go, n_legal, terminal)
+        t0 = time.perf_counter()
+        actions = np.full(self.G, -1, dtype=np.int32)
+        th, ti, tf = self.temperature
+        for g in np.nonzero(go)[0]:
+            gs = self.games[g]
+            n = int(res["n"][g])
+            idx, val = res["idx"][g, :n].copy(), res["val"][g, :n].copy()
+            gs.pis.append((idx, val))
+            actions[g] = sampling.select_action_sparse(idx, val, gs.fullmove_number(), gs.rng, th, ti, tf)
+            gs.plies += 1
+        self.host_seconds += time.perf_counter() - t0
+        self.eng.play(actions, self._stream())
+        n_moves = int(np.count_nonzero(go))
+        self.n_plies += n_moves
+        return n_moves
+
+    def _finish(self, g: int, terminal: int) -> FinishedGame:
+        gs = self.games[g]
+        positions, moves = self.eng.export_game(g, self._stream())
+        outcome = 1.0 if terminal == 1 else 0.0
+        return FinishedGame(game_id=gs.game_id, slot=g, moves=moves, positions=positions, pis=gs.pis, outcome=outcome,
+                            terminal=terminal)
+
+    # ---- training records ---------------------------------------------------------------------------------
+    def encode_finished_in_slot(self, g: int, n_records: int) -> torch.Tensor:
+        """Dense (state) tensors [n,120,8,8] of the game still resident in slot g (self_play.py:200-208:
+        END-of-game tracker).  Call from `on_finished`, i.e. before the slot is refilled."""
+        out = torch.empty((max(1, n_records), E.INPUT_CHANNELS, 8, 8), dtype=torch.float32, device=self.device)
+        if n_records:
+            self.eng.encode_game(g, 0, n_records, out.data_ptr(), self._stream())
+        return out[:n_records]
+
+    def close(self):
+        self._graph = None
+        self.eng.close()

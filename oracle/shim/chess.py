@@ -188,10 +188,18 @@ class Board:
 
     __copy__ = copy
 
-    def fen(self, **_kw) -> str:
+    def fen(self, *, en_passant: str = "legal", **_kw) -> str:
         buf = C.create_string_buffer(128)
         self._L.bo_pos_to_fen(C.byref(self._p), buf, 128)
-        return buf.value.decode()
+        f = buf.value.decode()
+        if en_passant == "fen" and self.ep_square is not None:  # raw ep square, capturable or not
+            parts = f.split()
+            parts[3] = SQUARE_NAMES[self.ep_square]
+            f = " ".join(parts)
+        return f
+
+    def clean_castling_rights(self) -> int:
+        return self.castling_rights
 
     def _transposition_key(self):
         return self._s.key[self._s.n - 1].tup()

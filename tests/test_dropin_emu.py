@@ -1,0 +1,203 @@
+"""CPU tests of the drop-in surface (betaone_amd/dropin: config, network, utils, mcts, self_play) --
+the host logic that marshals the caller's python-chess objects into the engine.  The engine behind it
+is the wave-emulator build (test infrastructure); boards are oracle/shim `chess` boards standing in
+for python-chess.  Bit-exact comparisons use a net with constant logits: softmax of equal logits is
+exactly 1/4672 in any implementation, so the (priors, value) seam is identical on both sides."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle", "shim"))
+
+import chess  # noqa: E402  (oracle/shim)
+from betaone_amd import dropin  # noqa: E402
+
+dropin.install()
+import config  # noqa: E402
+import mcts  # noqa: E402
+import network  # noqa: E402
+import self_play  # noqa: E402
+import utils  # noqa: E402
+
+import golden_util as G  # noqa: E402
+from engine_harness import emu_lib  # noqa: E402
+from fake_model import FakeNet, fake_logits_values, hash_init_  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+@pytest.fixture(autouse=True)
+def _emu_backend():
+    saved = {k: getattr(config, k) for k in ("NUM_SIMULATIONS", "MCTS_BATCH_SIZE", "MAX_GAME_MOVES", "DIRICHLET_ALPHA")}
+    mcts._set_test_backend(emu_lib(), "cpu")
+    self_play._set_test_backend(emu_lib(), "cpu")
+    yield
+    mcts._set_test_backend(None)
+    self_play._set_test_backend(None)
+    for k, v in saved.items():
+        setattr(config, k, v)
+
+
+def uniform_eval(salt):
+    def fn(planes):
+        _, v = fake_logits_values(planes, 0.0, salt)
+        return np.full((planes.shape[0], 4672), np.float32(1.0) / np.float32(4672.0), dtype=np.float32), v
+    return fn
+
+
+def context(fen, moves, uci_style=False):
+    board = chess.Board(fen)
+    tracker = utils.RepetitionTracker()
+    tracker.add_board(board)
+    hist = [board.copy()]
+    for u in moves:
+        board.push(chess.Move.from_uci(u))
+        tracker.add_board(board)
+        hist.append(board.copy())
+    history = hist[-8:][-7:] if uci_style else hist[max(0, len(hist) - 8):-1]
+    return board, history, tracker
+
+
+def oracle_context(fen, moves, uci_style=False):
+    b = O.Board(fen)
+    trk = O.PyTracker()
+    trk.add_board(b)
+    for u in moves:
+        b.push(u)
+        trk.add_board(b)
+    pos = b.positions()
+    return b, (pos[-8:][-7:] if uci_style else pos[max(0, len(pos) - 8):-1]), trk
+
+
+CASES = [
+    (chess.STARTING_FEN, [], False, 120),
+    (chess.STARTING_FEN, "e2e4 e7e5 g1f3 b8c6 f1b5 a7a6 b5a4 g8f6 e1g1".split(), False, 200),
+    (chess.STARTING_FEN, "e2e4 c7c5 g1f3".split(), True, 100),
+    ("rnbqkbnr/ppp1pppp/8/8/3pP3/8/PPPP1PPP/RNBQKBNR b KQkq e3 0 3", [], False, 100),
+    (chess.STARTING_FEN, "g1f3 g8f6 f3g1 f6g8 g1f3 g8f6".split(), False, 150),
+]
+
+
+@pytest.mark.parametrize("fen,moves,uci_style,sims", CASES)
+def test_run_mcts_dropin_matches_oracle(fen, moves, uci_style, sims):
+    config.NUM_SIMULATIONS = sims
+    board, history, tracker = context(fen, moves, uci_style)
+    np.random.seed(7)
+    best, pi = mcts.run_mcts(board, FakeNet(scale=0.0, salt=3), history, tracker)
+    ob, oh, ot = oracle_context(fen, moves, uci_style)
+    r = O.run_mcts(ob, oh, ot, uniform_eval(3), np.random.RandomState(7), O.default_config(num_simulations=sims))
+    assert isinstance(best, chess.Move) and best.uci() == O.move_to_uci(r["best"])
+    assert pi.dtype == np.float32 and pi.shape == (4672,)
+    assert np.array_equal(pi.view(np.uint32), r["pi"].view(np.uint32))
+    assert board.move_stack == [chess.Move.from_uci(u) for u in moves]  # caller's board untouched (mcts.py:36)
+
+
+def test_run_mcts_raises_on_root_without_moves():
+    board, history, tracker = context("k6R/8/1K6/8/8/8/8/8 b - - 1 1", [])
+    with pytest.raises(ValueError):
+        mcts.run_mcts(board, FakeNet(scale=0.0), history, tracker)
+    assert mcts.MCTS(FakeNet(scale=0.0)).search  # north-star alias exists
+
+
+def test_run_self_play_game_dropin_matches_oracle(tmp_path):
+    config.NUM_SIMULATIONS, config.MCTS_BATCH_SIZE, config.MAX_GAME_MOVES = 40, 16, 7
+    np.random.seed(11)
+    data = self_play.run_self_play_game(FakeNet(scale=0.0, salt=5), 42)
+    ref = O.self_play(uniform_eval(5), np.random.RandomState(11),
+                      O.default_config(num_simulations=40, batch_size=16, max_game_moves=7))
+    assert isinstance(data, list) and len(data) == len(ref["records"]) == 7
+    for (st, pi, z), (rst, rpi, rz) in zip(data, ref["records"]):
+        assert isinstance(st, torch.Tensor) and st.dtype == torch.float32 and tuple(st.shape) == (120, 8, 8)
+        assert np.array_equal(st.numpy(), rst)
+        assert isinstance(pi, np.ndarray) and np.array_equal(pi.view(np.uint32), rpi.view(np.uint32))
+        assert isinstance(z, float) and z == rz and np.signbit(z) == np.signbit(rz)
+    # save_game_data keeps the reference's pickle layout (train.py:207-214 expects a non-empty list)
+    config.DATA_DIR = str(tmp_path)
+    self_play.save_game_data(data, 3, 42)
+    import pickle
+
+    back = pickle.load(open(tmp_path / "iter_3" / "game_42.pkl", "rb"))
+    assert isinstance(back, list) and len(back) == 7 and torch.equal(back[0][0], data[0][0])
+    assert self_play.play_game is self_play.run_self_play_game
+
+
+def test_batched_games_are_independent_of_slot_count():
+    config.NUM_SIMULATIONS, config.MCTS_BATCH_SIZE, config.MAX_GAME_MOVES = 30, 16, 5
+    model = FakeNet(scale=0.0, salt=9)
+    a = self_play.run_self_play_games(model, [0, 1, 2, 3, 4], seeds=[10, 11, 12, 13, 14], n_slots=5)
+    b = self_play.run_self_play_games(model, [0, 1, 2, 3, 4], seeds=[10, 11, 12, 13, 14], n_slots=2)
+    for gid in range(5):
+        assert len(a[gid]) == len(b[gid]) == 5
+        for (s1, p1, z1), (s2, p2, z2) in zip(a[gid], b[gid]):
+            assert torch.equal(s1, s2) and np.array_equal(p1, p2) and z1 == z2
+    ref = O.self_play(uniform_eval(9), np.random.RandomState(12),
+                      O.default_config(num_simulations=30, batch_size=16, max_game_moves=5))
+    for (s1, p1, z1), (rs, rp, rz) in zip(a[2], ref["records"]):
+        assert np.array_equal(s1.numpy(), rs) and np.array_equal(p1, rp) and z1 == rz
+
+
+def test_utils_codec_and_encoding_match_oracle():
+    for e in G.load_codec():
+        b = chess.Board(e["fen"])
+        assert utils.test_move_indexing(b) == 0
+        assert [[m.uci(), utils.move_to_index(m)] for m in b.legal_moves] == e["moves"]
+        for uci, idx in e["moves"]:
+            assert utils.index_to_move(idx, b).uci() == uci
+    with pytest.raises(ValueError):
+        utils.index_to_move(4672, chess.Board())
+    with pytest.raises(ValueError):
+        utils.index_to_move(0 * 73 + 64, chess.Board())  # under-promotion plane without a pawn on a1
+    for fen, moves, uci_style, _ in CASES:
+        board, history, tracker = context(fen, moves, uci_style)
+        enc = utils.encode_board(board, (history + [board])[-8:], tracker)
+        ob, oh, ot = oracle_context(fen, moves, uci_style)
+        assert np.array_equal(enc.numpy(), O.encode_board((list(oh) + [ob.pos])[-8:], ot))
+    t = utils.RepetitionTracker()
+    b = chess.Board()
+    assert t.repetitions(b) == 0
+    t.add_board(b); t.add_board(b); t.add_board(b)
+    assert t.repetitions(b) == 2 and t.get_count(b) == 3
+    assert utils.get_game_outcome(chess.Board()) is None
+    assert utils.get_game_outcome(chess.Board("k6R/8/1K6/8/8/8/8/8 b - - 1 1")) == 1.0
+    assert utils.get_game_outcome(chess.Board("8/8/8/8/8/2k5/8/K7 w - - 0 1")) == 0.0
+
+
+NET_SIZES = {"3+1x64": (3, 1, 64), "8+2x128": (8, 2, 128), "15+5x256": (15, 5, 256)}
+
+
+@pytest.mark.parametrize("name", list(NET_SIZES))
+def test_network_matches_reference_outputs(name):
+    z = np.load(os.path.join(ROOT, "tests", "golden", "g1_net.npz"))
+    saved = (config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS)
+    config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = NET_SIZES[name]
+    try:
+        net = hash_init_(network.PolicyValueNet().eval())
+        assert len(net.state_dict()) == int(z[f"nkeys_{name}"])
+        assert sum(p.numel() for p in net.parameters()) == int(z[f"nparams_{name}"])
+        x = torch.from_numpy(z["inputs"])
+        with torch.no_grad():
+            logits, value = net(x)
+            flogits, fvalue = net.for_inference(channels_last=False)(x)
+        assert tuple(logits.shape) == (3, 4672) and tuple(value.shape) == (3, 1)
+        assert np.abs(logits.numpy() - z[f"logits_{name}"]).max() < 1e-4   # north_star tolerance
+        assert np.abs(value.numpy() - z[f"value_{name}"]).max() < 1e-4
+        assert np.abs(flogits.numpy() - z[f"logits_{name}"]).max() < 1e-4  # BN-folded inference copy
+        assert np.abs(fvalue.numpy() - z[f"value_{name}"]).max() < 1e-4
+    finally:
+        config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = saved
+
+
+def test_product_paths_refuse_to_run_without_the_gpu():
+    from betaone_amd import engine as E
+
+    mcts._set_test_backend(None)
+    self_play._set_test_backend(None)
+    if not torch.cuda.is_available():
+        board, history, tracker = context(chess.STARTING_FEN, [])
+        with pytest.raises(E.EngineError):
+            mcts.run_mcts(board, FakeNet(scale=0.0), history, tracker)
+        with pytest.raises(E.EngineError):
+            self_play.run_self_play_game(FakeNet(scale=0.0), 0)
