@@ -126,8 +126,9 @@ static DPos from_abi(const bo_position &p) {
     for (int i = 0; i < 8; i++) d.bb[i] = p.bb[i];
     d.flags = (p.turn ? F_TURN : 0u) | ((p.castling & 0xFu) << F_CASTLE_SHIFT) | ((uint32_t)(p.ep_square + 1) << F_EP_SHIFT);
     if (p.ep_key >= 0) d.flags |= (uint32_t)(p.ep_key + 1) << F_EPKEY_SHIFT;
-    // ep_key == -1 means "the key has no ep component": drop the raw square so finish_key() does not re-derive it
-    if (p.ep_key == -1) d.flags &= ~F_EP_MASK;
+    // ep_key == -1 ("no ep component in the key") with a raw ep square present is re-derived on the device by
+    // finish_key(); that is deterministic and gives -1 again.  Tracker keys taken from python-chess key tuples
+    // carry ep_square == ep_key.
     d.halfmove = p.halfmove_clock;
     d.fullmove = p.fullmove_number;
     return d;
@@ -380,6 +381,21 @@ extern "C" int bo_game_export(bo_engine *e, int slot, bo_position *positions, in
 extern "C" int bo_game_encode(bo_engine *e, int slot, int first, int n, float *out_dev, void *stream) {
     if (!e || slot < 0 || slot >= e->d.c.G || n < 1 || first < 0 || !out_dev) return fail(BO_E_ARG, "bad arguments");
     RT(RT_LAUNCH(bo_k_encode_game, n, stream, e->d, slot, first, out_dev));
+    return BO_OK;
+}
+
+extern "C" int bo_records_encode(int n_positions, const bo_position *positions, int first, int n, float *out_dev, void *stream) {
+    if (n_positions < 1 || !positions || first < 0 || n < 1 || first + n > n_positions || !out_dev)
+        return fail(BO_E_ARG, "bad arguments");
+    std::vector<DPos> hp((size_t)n_positions);
+    for (int i = 0; i < n_positions; i++) hp[i] = from_abi(positions[i]);
+    void *dp = nullptr;
+    int rc = rt_malloc(&dp, hp.size() * sizeof(DPos));
+    if (!rc) rc = rt_h2d(dp, hp.data(), hp.size() * sizeof(DPos), stream);
+    if (!rc) rc = RT_LAUNCH(bo_k_encode_positions, n, stream, (const DPos *)dp, n_positions, first, out_dev);
+    int rc2 = rt_sync(stream);
+    rt_free(dp);
+    if (rc || rc2) return fail(BO_E_HIP, std::string("bo_records_encode: ") + rt_errstr(rc ? rc : rc2));
     return BO_OK;
 }
 

@@ -736,6 +736,24 @@ BO_KERNEL void bo_k_encode_game(Eng e, int g, int first, float *out) {
     encode_scalars(row, gp[i]);
 }
 
+// Expansion of a compact record (the wire format of betaone_amd/records.py) back into the dense training
+// encodings of self_play.py:200-208, on ANY rank: pos[0..n_pos) are the game's positions, the tracker is
+// the multiset of their keys (end-of-game tracker).  One wave per encoded ply.
+BO_KERNEL void bo_k_encode_positions(const DPos *pos, int n_pos, int first, float *out) {
+    const int i = first + bo_block(), s = bo_lane();
+    float *row = out + (size_t)bo_block() * BO_ROW;
+    const int h0 = i - 7 > 0 ? i - 7 : 0, nb = i + 1 - h0;
+    for (int pl = 0; pl < (8 - nb) * 14; pl++) row[pl * 64 + s] = 0.0f;
+    for (int k = 0; k < nb; k++) {
+        const DPos H = pos[h0 + k];
+        int c = 0;
+        for (int j = s; j < n_pos; j += 64) c += key_equal(pos[j], H) ? 1 : 0;
+        c = bo_wave_sum(c);
+        encode_block(row, 8 - nb + k, H, c > 1 ? c - 1 : 0);
+    }
+    encode_scalars(row, pos[i]);
+}
+
 // Stand-alone batch utilities (tests, drop-in utils.encode_board): legal moves + outcome of positions
 // given with their move stacks already loaded into game slots is covered by bo_k_setup; this one
 // runs the move generator alone on raw positions.

@@ -12,6 +12,11 @@ import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
+# PyTorch-ROCm bundles its own HIP/HSA runtime (torch/lib/libamdhip64.so).  It must be loaded BEFORE
+# libbetaone_hip.so so that the engine binds to that same runtime: two HIP runtimes in one process do not
+# share a device context (the second one reports "no ROCm-capable device"), and the engine exchanges raw
+# device pointers and stream handles with torch.
+import torch  # noqa: F401
 
 NUM_ACTIONS = 4672
 INPUT_CHANNELS = 120
@@ -64,6 +69,7 @@ _SYMBOLS = {
     "bo_play": (C.c_int, [C.c_void_p, _I32P, C.c_void_p]),
     "bo_game_export": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BoPosition), _I32P, C.c_int32, _I32P, C.c_void_p]),
     "bo_game_encode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "bo_records_encode": (C.c_int, [C.c_int, C.POINTER(BoPosition), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bo_debug_tree": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BoNode), C.c_int32, _I32P, C.c_void_p]),
     "bo_engine_status": (C.c_int, [C.c_void_p, _I32P, _I32P, _I32P, _I32P, _I32P, _I32P, C.c_void_p]),
     "bo_movegen_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BoPosition), _I32P, _I32P, _I32P, C.c_void_p]),

@@ -139,6 +139,10 @@ int bo_game_export(bo_engine *e, int slot, bo_position *positions, int32_t *move
  * game) tracker, float32 [n,120,8,8] into out_dev (self_play.py:200-208).  Asynchronous. */
 int bo_game_encode(bo_engine *e, int slot, int first, int n, float *out_dev, void *stream);
 
+/* The same encodings from a compact record on any rank (betaone_amd/records.py wire format): positions[0..n_positions)
+ * as returned by bo_game_export (ep_key filled), plies [first, first+n) into out_dev.  Needs no engine.  Synchronises. */
+int bo_records_encode(int n_positions, const bo_position *positions, int first, int n, float *out_dev, void *stream);
+
 /* ---- introspection (parity tests, profiling) ------------------------------------------------- */
 typedef struct {
     int32_t parent, n_visits, first_child, n_children;

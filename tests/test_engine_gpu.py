@@ -39,3 +39,122 @@ def test_self_play_game_matches_reference(backend, name):
 
 def test_many_games_in_lockstep_match_oracle(backend):
     EC.check_multi_game_vs_oracle(backend, n_games=24, plies=10, sims=120, batch=32)
+
+
+def test_select_wide_matches_numpy_reference(backend):
+    import torch
+    from betaone_amd import select_wide as SW
+
+    w = SW.build(96, nodes=60, seed=3, device="cuda:0", n_max=500)
+    leaf, levels = SW.run(w, max_depth=64)
+    torch.cuda.synchronize()
+    blocks = w["blocks"].cpu().numpy()
+    lut = w["sqrt_lut"].cpu().numpy()
+    rb, rn = w["root_block"].cpu().numpy(), w["root_n"].cpu().numpy()
+    leaf, levels = leaf.cpu().numpy(), levels.cpu().numpy()
+    assert levels.max() >= 2
+    for t in range(96):
+        el, ev = SW.reference_descent(blocks, rb[t], rn[t], lut)
+        assert (leaf[t], levels[t]) == (el, ev), t
+
+
+def test_in_kernel_softmax_close_to_torch(backend):
+    """policy_kind LOGITS: the engine's own softmax (the seam is NOT shared here) -- priors within 1e-6 relative
+    of torch.softmax, visit counts identical for well-separated logits."""
+    import torch
+    from betaone_amd import engine as E
+    from engine_harness import Buf, make_engine, canonical_tree
+    from fake_model import fake_logits_values
+    from oracle import oracle as O
+
+    cfg = dict(num_simulations=200, batch_size=32, dirichlet_alpha=0.0)
+    eng = make_engine("hip", 1, cfg)
+    eng.reset([0])
+    nn_in, pol, val = Buf("hip", (1, 120, 8, 8)), Buf("hip", (1, 4672)), Buf("hip", (1,))
+    eng.search_begin([1], None, nn_in.ptr)
+    kind = E.POLICY_NONE
+    while True:
+        eng.step(pol.ptr, val.ptr, kind, nn_in.ptr)
+        running, _, _ = eng.poll()
+        if not running:
+            break
+        logits, v = fake_logits_values(nn_in.numpy(), 6.0, 77)
+        pol.set(logits); val.set(v)
+        kind = E.POLICY_LOGITS
+    eng.check_status()
+    got = canonical_tree(eng.debug_tree(0))
+
+    def eval_fn(planes):
+        logits, v = fake_logits_values(planes, 6.0, 77)
+        return torch.softmax(torch.from_numpy(logits), dim=1).numpy(), v
+
+    b = O.Board(); trk = O.PyTracker(); trk.add_board(b)
+    r = O.run_mcts(b, [], trk, eval_fn, np.random.RandomState(0), O.default_config(**cfg))
+    exp = {"/".join(k): v for k, v in O.canonical_tree(r["nodes"]).items()}
+    assert set(got) == set(exp)
+    for k in exp:
+        assert got[k][0] == exp[k][0] and got[k][3] == exp[k][3]
+        pg = np.array([got[k][2]], dtype=np.uint32).view(np.float32)[0]
+        pe = np.array([exp[k][2]], dtype=np.uint32).view(np.float32)[0]
+        assert abs(pg - pe) <= 1e-6 * abs(pe) + 1e-12
+
+
+def test_rollout_with_torch_net_graph_equals_eager(backend):
+    import torch
+    from betaone_amd import dropin
+    dropin.install()
+    import config, network
+    from betaone_amd.rollout import Rollout
+
+    saved = (config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS)
+    config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 3, 1, 64
+    try:
+        torch.manual_seed(0)
+        net = network.PolicyValueNet().to("cuda:0").eval().for_inference()
+        runs = []
+        for use_graph in (True, False):
+            ro = Rollout(net, 16, num_simulations=120, mcts_batch_size=32, device="cuda:0", use_graph=use_graph)
+            ro.start_games(list(range(16)), list(range(16)), [np.random.RandomState(s) for s in range(16)])
+            for _ in range(4):
+                assert ro.play_ply() == 16
+            ro.eng.check_status()
+            runs.append([[(i.tolist(), v.tolist()) for i, v in g.pis] for g in ro.games])
+            moves = [ro.eng.export_game(g)[1] for g in range(16)]
+            runs.append(moves)
+            ro.close()
+        assert runs[0] == runs[2] and runs[1] == runs[3]
+    finally:
+        config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = saved
+
+
+def test_records_roundtrip_and_expand(backend):
+    import torch
+    from betaone_amd import records
+    from betaone_amd.rollout import Rollout
+    from fake_model import FakeNet
+
+    class Net(torch.nn.Module):
+        def forward(self, x):
+            l, v = FakeNet(scale=0.0, salt=4)(x)
+            return l.to(x.device), v.to(x.device)
+
+    ro = Rollout(Net(), 3, num_simulations=40, mcts_batch_size=16, max_game_moves=5, device="cuda:0", use_graph=False)
+    ro.start_games([0, 1, 2], [0, 1, 2], [np.random.RandomState(s) for s in range(3)])
+    fins, dense = [], {}
+
+    def fin(f):
+        fins.append(f)
+        dense[f.game_id] = ro.encode_finished_in_slot(f.slot, len(f.pis)).cpu()
+
+    while any(g is not None for g in ro.games):
+        ro.play_ply(on_finished=fin)
+    ro.close()
+    blob = b"".join(records.pack_game(f) for f in fins)
+    games = records.unpack_games(blob)
+    assert [g["game_id"] for g in games] == [f.game_id for f in fins]
+    for g, f in zip(games, fins):
+        recs = records.expand_game(g, "cuda:0")
+        assert len(recs) == 5
+        for i, (st, pi, z) in enumerate(recs):
+            assert torch.equal(st, dense[f.game_id][i])  # re-expanded on "another rank" == encoded in the slot
+            assert z == f.z(i)
