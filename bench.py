@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--wide-trees", type=int, default=32768)
+    ap.add_argument("--wide-trees", type=int, default=0, help="0 = 262144 if >= 150 GB of HBM is free, else 131072")
     ap.add_argument("--wide-nodes", type=int, default=800)
     return ap.parse_args()
 
@@ -87,13 +87,18 @@ def select_roofline(args, device):
     """HBM roofline of the PUCT-select kernel on the SURVEY section 8d wide workload."""
     from betaone_amd import select_wide as SW
 
-    w = SW.build(args.wide_trees, args.wide_nodes, seed=0, device=device)
+    n_trees = args.wide_trees
+    if n_trees <= 0:
+        free, _total = torch.cuda.mem_get_info(device)
+        n_trees = 262144 if free > 150 * (1 << 30) else (131072 if free > 75 * (1 << 30) else 32768)
+    args.wide_trees = n_trees
+    w = SW.build(n_trees, args.wide_nodes, seed=0, device=device)
     flush = torch.empty(512 << 20, dtype=torch.uint8, device=device)  # evict the 256 MiB Infinity Cache between launches
     out = SW.run(w)
     torch.cuda.synchronize(device)
     levels = int(out[1].sum().item())
     alg_bytes = levels * SW.LEVEL_BYTES
-    reps, ms = 10, []
+    reps, ms = 20, []
     for _ in range(reps):
         flush.fill_(1)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -107,7 +112,8 @@ def select_roofline(args, device):
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
             "traffic": None, "kernel": "bo_k_select_wide",
             "workload": f"{args.wide_trees} trees x {args.wide_nodes} nodes x 32 children (512 B child blocks, "
-                        f"{w['blocks'].numel() * 4 / 1e9:.1f} GB resident, L3 flushed between launches), one descent per tree per launch",
+                        f"{w['blocks'].numel() * 4 / 1e9:.1f} GB resident in HBM, 512 MiB written between launches to evict the Infinity Cache), "
+                        f"one PUCT descent per tree per launch; bytes = levels x (12 B x 32 children + 8 B), the kernel moves 512 B per level",
             "levels_per_launch": levels, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(t * 1e3, 4)}
 
 

@@ -473,8 +473,17 @@ extern "C" int bo_select_wide(const void *blocks_dev, const int32_t *root_block_
 #else
     if (!blocks_dev || !root_block_dev || !root_n_dev || !sqrt_lut_dev || !out_leaf_dev || !out_levels_dev || n_trees < 1)
         return fail(BO_E_ARG, "bad arguments");
-    if (grid_blocks < 1) grid_blocks = (n_trees + 7) / 8;
-    hipLaunchKernelGGL(bo_k_select_wide, dim3((unsigned)grid_blocks), dim3(256), 0, (hipStream_t)stream,
+    // grid_blocks: low 20 bits = workgroups (0 = auto), bits 20..23 = tuning variant (0 default; sweeps only)
+    const int variant = (grid_blocks >> 20) & 15;
+    grid_blocks &= 0xFFFFF;
+    const int U = variant == 1 ? 2 : variant == 2 ? 8 : 4;
+    if (grid_blocks < 1) {  // one workgroup per 8*U trees, capped at 16 workgroups per CU (grid-stride beyond)
+        grid_blocks = (n_trees + 8 * U - 1) / (8 * U);
+        if (grid_blocks > 4096) grid_blocks = 4096;
+    }
+    auto kern = variant == 1 ? bo_k_select_wide_u2 : variant == 2 ? bo_k_select_wide_u8 : variant == 3 ? bo_k_select_wide_u4_plain
+                                                                                                  : bo_k_select_wide;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid_blocks), dim3(256), 0, (hipStream_t)stream,
                        (const WideBlock *)blocks_dev, (const int *)root_block_dev, (const int *)root_n_dev, sqrt_lut_dev,
                        n_trees, max_depth, cpuct, (int *)out_leaf_dev, (int *)out_levels_dev);
     RT((int)hipGetLastError());

@@ -1,7 +1,7 @@
 """
 betaone_amd/select_wide.py -- the wide synthetic workload for the PUCT-select kernel's HBM roofline
 (SURVEY.md section 8d): T trees x `nodes` expanded nodes x 32 children, child blocks of 512 B
-(int32 n[32] | f32 q[32] | f32 prior[32] | int32 child_block[32]), fixed seed.  Visit counts are
+(32 records {int32 n, f32 q, f32 prior, int32 child_block}), fixed seed.  Visit counts are
 Zipf-like, Q ~ U(-1,1), priors = normalised Exp(1).  All trees share one random topology (random
 recursive tree) but have independent statistics, so every tree takes its own path.
 """
@@ -18,18 +18,14 @@ LEVEL_BYTES = 12 * C + 8  # N,Q,P of 32 children + child_b
 
 
 def topology(nodes: int, seed: int = 0) -> np.ndarray:
-    """child_block[nodes, 32] of ONE tree (local indices, -1 = leaf): random recursive tree."""
-    rng = np.random.RandomState(seed)
+    """child_block[nodes, 32] of ONE tree (local indices, -1 = leaf): expanded nodes fill the tree level by
+    level (node i's children are 32*i+1 .. 32*i+32), so with 800 nodes every descent scans 2 or 3 levels."""
     cb = np.full((nodes, C), -1, dtype=np.int32)
-    free = [(0, c) for c in range(C)]
-    for i in range(1, nodes):
-        k = rng.randint(len(free))
-        p, c = free[k]
-        free[k] = free[-1]
-        free.pop()
-        cb[p, c] = i
-        # depth-biased growth: new nodes offer their slots several times so that paths get deep
-        free.extend((i, cc) for cc in range(C))
+    for i in range(nodes):
+        for c in range(C):
+            j = C * i + 1 + c
+            if j < nodes:
+                cb[i, c] = j
     return cb
 
 
@@ -45,16 +41,16 @@ def build(n_trees: int, nodes: int = 800, seed: int = 0, device="cuda:0", n_max:
         b = min(n_trees, a + chunk)
         u = torch.rand((b - a, nodes, C), device=dev, generator=gen)
         n = (u.clamp_min(1e-6) ** (-1.0 / 1.2)).to(torch.int32).clamp_(0, n_max) - 1   # Zipf-ish, some zeros
-        v[a:b, :, 0:C] = n.clamp_min_(0)
+        v[a:b, :, 0::4] = n.clamp_min_(0)
         q = torch.rand((b - a, nodes, C), device=dev, generator=gen) * 2 - 1
-        v[a:b, :, C:2 * C] = q.view(torch.int32)
+        v[a:b, :, 1::4] = q.view(torch.int32)
         p = -torch.log(torch.rand((b - a, nodes, C), device=dev, generator=gen).clamp_min(1e-9))
         p = p / p.sum(dim=2, keepdim=True)
-        v[a:b, :, 2 * C:3 * C] = p.view(torch.int32)
+        v[a:b, :, 2::4] = p.view(torch.int32)
         base = (torch.arange(a, b, device=dev, dtype=torch.int32) * nodes).view(-1, 1, 1)
-        v[a:b, :, 3 * C:4 * C] = torch.where(topo.unsqueeze(0) >= 0, topo.unsqueeze(0) + base, torch.full_like(topo, -1).unsqueeze(0))
+        v[a:b, :, 3::4] = torch.where(topo.unsqueeze(0) >= 0, topo.unsqueeze(0) + base, torch.full_like(topo, -1).unsqueeze(0))
     root_block = (torch.arange(n_trees, device=dev, dtype=torch.int32) * nodes).contiguous()
-    root_n = v[:, 0, 0:C].sum(dim=1).to(torch.int32).clamp_(0, n_max * C).contiguous()
+    root_n = v[:, 0, 0::4].sum(dim=1).to(torch.int32).clamp_(0, n_max * C).contiguous()
     lut = torch.sqrt(torch.arange(n_max * C + 2, dtype=torch.float64) + 1e-8).to(torch.float32).to(dev)
     return dict(blocks=blocks, root_block=root_block, root_n=root_n, sqrt_lut=lut, n_trees=n_trees, nodes=nodes)
 
@@ -80,9 +76,9 @@ def reference_descent(blocks: np.ndarray, root_block: int, root_n: int, lut: np.
     c = np.float32(cpuct)
     while blk >= 0 and levels < max_depth:
         row = blocks[blk]
-        n = row[0:C]
-        q = row[C:2 * C].view(np.float32)
-        p = row[2 * C:3 * C].view(np.float32)
+        n = row[0::4]
+        q = row[1::4].view(np.float32)
+        p = row[2::4].view(np.float32)
         sp = lut[pv]
         best, bi = -np.inf, 0
         for i in range(C):
@@ -92,6 +88,6 @@ def reference_descent(blocks: np.ndarray, root_block: int, root_n: int, lut: np.
                 best, bi = score, i
         leaf = blk * C + bi
         pv, pv_next = pv_next, int(n[bi])
-        blk = int(row[3 * C + bi])
+        blk = int(row[3 + 4 * bi])
         levels += 1
     return leaf, levels

@@ -162,8 +162,8 @@ int bo_movegen_batch(bo_engine *e, int n, const bo_position *pos, int32_t *moves
                      int32_t *check_out, void *stream);
 
 /* PUCT select (mcts.py:72-118 arithmetic) over caller-provided WIDE trees, the HBM-roofline workload of
- * SURVEY.md section 8d.  blocks_dev: array of 512-byte child blocks
- *   { int32 n[32]; float q[32]; float prior[32]; int32 child_block[32] (-1 = leaf) }
+ * SURVEY.md section 8d.  blocks_dev: array of 512-byte, 512-byte-aligned child blocks = 32 records
+ *   { int32 n; float q; float prior; int32 child_block (-1 = not expanded) }
  * root_block_dev[t] / root_n_dev[t]: root child block and root visit count of tree t; sqrt_lut_dev[n] =
  * f32(sqrt(n + 1e-8)).  out_leaf_dev[t] = block*32 + child of the selected leaf, out_levels_dev[t] = levels
  * descended (x 392 B = algorithmic bytes).  grid_blocks <= 0 picks one 256-thread workgroup per 8 trees.

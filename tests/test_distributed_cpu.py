@@ -1,0 +1,119 @@
+"""CPU tests of the N>1 path: games shard by id over ranks (no data-path collective), finished games
+travel as compact records through ONE all-gather (gloo here, RCCL on the GPUs).  world_size = 2."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from betaone_amd import records
+    from betaone_amd.rollout import Rollout
+    from engine_harness import emu_lib
+    from fake_model import FakeNet
+
+    class Net(torch.nn.Module):
+        def forward(self, x):
+            return FakeNet(scale=0.0, salt=21)(x)
+
+    n_total = 6
+    ids = records.shard_game_ids(n_total, rank, world)           # game id -> rank = id mod world
+    assert ids == list(range(rank, n_total, world))
+    ro = Rollout(Net(), len(ids), num_simulations=30, mcts_batch_size=16, max_game_moves=3 + rank, device="cpu",
+                 use_graph=False, lib=emu_lib())
+    ro.start_games(list(range(len(ids))), ids, [np.random.RandomState(i) for i in ids])
+    fins = []
+    gathered = []
+    for _step in range(6):   # every rank makes the SAME number of exchange steps (as bench.py does: one per step)
+        batch = []
+        if any(g is not None for g in ro.games):
+            ro.play_ply(on_finished=batch.append)
+        fins.extend(batch)
+        gathered.extend(records.all_gather_games(batch))         # the path's only exchange step
+    assert not any(g is not None for g in ro.games)
+    ro.close()
+    mine = {g.game_id: [m for m in g.moves] for g in fins}
+    np.save(os.path.join(out_dir, f"rank{rank}.npy"),
+            np.array([[g["game_id"], g["n_plies"], g["terminal"]] + list(g["moves"][:3]) for g in
+                      sorted(gathered, key=lambda x: x["game_id"])], dtype=np.int64))
+    for g in gathered:
+        if g["game_id"] in mine:
+            assert list(g["moves"]) == mine[g["game_id"]]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_games_and_all_gather_records(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a = np.load(tmp_path / "rank0.npy")
+    b = np.load(tmp_path / "rank1.npy")
+    assert np.array_equal(a, b)                       # every rank ends with every game's record
+    assert sorted(a[:, 0].tolist()) == [0, 1, 2, 3, 4, 5]
+    assert all(a[a[:, 0] % 2 == 0][:, 1] == 3) and all(a[a[:, 0] % 2 == 1][:, 1] == 4)
+
+
+def test_results_do_not_depend_on_the_sharding():
+    """game id + seed travel together: the same game on a different rank/slot count gives the same record."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    from betaone_amd.rollout import Rollout
+    from engine_harness import emu_lib
+    from fake_model import FakeNet
+
+    class Net(torch.nn.Module):
+        def forward(self, x):
+            return FakeNet(scale=0.0, salt=21)(x)
+
+    def play(ids):
+        ro = Rollout(Net(), len(ids), num_simulations=30, mcts_batch_size=16, max_game_moves=4, device="cpu",
+                     use_graph=False, lib=emu_lib())
+        ro.start_games(list(range(len(ids))), ids, [np.random.RandomState(i) for i in ids])
+        fins = []
+        while any(g is not None for g in ro.games):
+            ro.play_ply(on_finished=fins.append)
+        ro.close()
+        return {f.game_id: f.moves for f in fins}
+
+    one = play([0, 1, 2, 3])
+    two = {**play([0, 2]), **play([1, 3])}
+    assert one == two
+
+
+def test_record_wire_format_roundtrip():
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    from betaone_amd import engine as E, records
+    from betaone_amd.rollout import FinishedGame
+
+    pos = [E.BoPosition() for _ in range(3)]
+    for i, p in enumerate(pos):
+        p.bb[0] = 0xFF00 + i
+        p.turn = (i + 1) % 2
+        p.ep_square, p.ep_key, p.fullmove_number = -1, -1, 1 + i
+    fin = FinishedGame(game_id=7, slot=0, moves=[796, 3364], positions=pos,
+                       pis=[(np.array([5, 900], np.int32), np.array([0.25, 0.75], np.float32)),
+                            (np.array([33], np.int32), np.array([1.0], np.float32))], outcome=1.0, terminal=1)
+    blob = records.pack_game(fin) + records.pack_game(fin)
+    games = records.unpack_games(blob)
+    assert len(games) == 2 and games[1]["game_id"] == 7 and games[0]["outcome"] == 1.0
+    assert list(games[0]["moves"]) == [796, 3364]
+    assert games[0]["positions"][2].bb[0] == 0xFF02 and games[0]["positions"][1].turn == 0
+    assert games[0]["pis"][0][0].tolist() == [5, 900] and games[0]["pis"][0][1].tolist() == [0.25, 0.75]
+    assert len(blob) // 2 < 400     # ~100 B per ply instead of 49 KB per ply
