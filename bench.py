@@ -109,8 +109,17 @@ def select_roofline(args, device):
         ms.append(e0.elapsed_time(e1))
     t = float(np.mean(ms)) * 1e-3
     ach = alg_bytes / t / 1e9
+    # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction) when it
+    # was taken on this very workload; counters cannot be read from inside the process.
+    traffic, traffic_src = None, None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_select_wide_pmc.json")))
+        if pm["n_trees"] == n_trees and pm["nodes"] == args.wide_nodes and pm["levels_per_launch"] == levels:
+            traffic, traffic_src = pm["hbm_read_bytes_per_launch_corrected"], "profiles/r01_select_wide_pmc.md"
+    except Exception:
+        pass
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "traffic": None, "kernel": "bo_k_select_wide",
+            "traffic": traffic, "traffic_source": traffic_src, "kernel": "bo_k_select_wide",
             "workload": f"{args.wide_trees} trees x {args.wide_nodes} nodes x 32 children (512 B child blocks, "
                         f"{w['blocks'].numel() * 4 / 1e9:.1f} GB resident in HBM, 512 MiB written between launches to evict the Infinity Cache), "
                         f"one PUCT descent per tree per launch; bytes = levels x (12 B x 32 children + 8 B), the kernel moves 512 B per level",
