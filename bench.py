@@ -58,7 +58,7 @@ def parse():
     return ap.parse_args()
 
 
-def make_net(name, device, dtype):
+def make_net(name, device, dtype, batch=256):
     from betaone_amd import dropin
 
     dropin.install()
@@ -69,7 +69,11 @@ def make_net(name, device, dtype):
     torch.manual_seed(0)
     net = network.PolicyValueNet().eval()
     td = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[dtype]
-    return net, net.to(device).for_inference(dtype=td)
+    if str(device) == "cpu":
+        return net, net.for_inference(dtype=td, channels_last=False)
+    from betaone_amd.nn_tune import best_inference_copy
+
+    return net, best_inference_copy(net, batch, device, td)
 
 
 class CastIn(torch.nn.Module):
@@ -178,13 +182,15 @@ def main():
     from betaone_amd.rollout import Rollout
 
     E.load_hip_library()
-    _, net = make_net(args.net, device, args.net_dtype)
+    _, net = make_net(args.net, device, args.net_dtype, args.games)
+    net_layout = getattr(net, "layout", "nchw")
     if args.net_dtype != "fp32":
         net = CastIn(net, {"fp16": torch.float16, "bf16": torch.bfloat16}[args.net_dtype])
     G = args.games
-    ro = Rollout(net, G, num_simulations=args.sims, mcts_batch_size=args.batch, device=str(device), use_graph=not args.no_graph)
-    ids = [rank + world * s for s in range(G)]  # game id -> rank = id mod world
-    ro.start_games(list(range(G)), ids, [np.random.RandomState(i) for i in ids])
+    ro = Rollout(net, G, num_simulations=args.sims, mcts_batch_size=args.batch, device=str(device), use_graph=not args.no_graph,
+                 rng_mode="native")
+    ids = [rank + world * s for s in range(G)]  # game id -> rank = id mod world; RandomState(seed = game id) streams
+    ro.start_games(list(range(G)), ids, ids)
     next_id = [rank + world * G]
     finished_batch, n_finished = [], [0]
 
@@ -195,7 +201,7 @@ def main():
     def refill(_slot):
         i = next_id[0]
         next_id[0] += world
-        return i, np.random.RandomState(i), None
+        return i, i, None
 
     def one_step():
         ro.play_ply(on_finished=on_finished, refill=refill)
@@ -235,10 +241,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{G} concurrent self-play games per GPU x {args.sims} sims/move, MCTS_BATCH_SIZE {args.batch}, "
                                    f"net {args.net} ({'+'.join(map(str, NETS[args.net][:2]))} blocks x {NETS[args.net][2]} filters, "
-                                   f"random init, {args.net_dtype}), start position, per-game seeds = game id; "
+                                   f"random init, {args.net_dtype}, BN folded), start position, per-game seeds = game id; "
                                    f"BASELINE.json configs[2] per-GPU shard",
                        "games_per_gpu": G, "sims_per_move": args.sims, "net": args.net, "net_dtype": args.net_dtype,
-                       "hipgraph": not args.no_graph, "parallelism": f"games sharded over {world} GPU(s), record all-gather only"},
+                       "hipgraph": not args.no_graph, "net_layout": net_layout, "parallelism": f"games sharded over {world} GPU(s), record all-gather only"},
             "plies_per_sec": round(plies / dt, 2), "nn_forwards_per_sec": round(fwd / dt / world, 2),
             "unique_nn_evals_per_sec": round(fwd * G / dt, 1), "games_finished": n_finished[0],
             "games_per_hour_at_100_plies": round(plies / dt * 3600 / 100.0, 1),

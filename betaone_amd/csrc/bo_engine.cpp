@@ -7,6 +7,7 @@
 #include "bo_tree.h"
 #include "bo_select_wide.h"
 #include "bo_rt.h"
+#include "bo_hostrng.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -31,6 +32,9 @@ struct bo_engine {
     std::vector<void *> allocs;
     int *d_go = nullptr, *d_action = nullptr;
     std::vector<int> h_i32;  // scratch [G]
+    std::vector<HostRng> rng;          // one legacy MT19937 stream per game slot (bo_rng_seed)
+    std::vector<double> h_noise;       // [G][256]
+    std::vector<int> h_nl, h_term, h_go;
     template <class T> int alloc(T **p, size_t n) {
         void *v = nullptr;
         int rc = rt_malloc(&v, n * sizeof(T));
@@ -201,6 +205,10 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
     rt_memset(d.noise, 0, G * BO_MAX_MOVES * sizeof(double), nullptr);
     rt_sync(nullptr);
     e->h_i32.resize(G);
+    e->rng.resize(G);
+    for (size_t g = 0; g < G; g++) hr_seed(&e->rng[g], (uint32_t)g);
+    e->h_noise.assign(G * BO_MAX_MOVES, 0.0);
+    e->h_nl.resize(G); e->h_term.resize(G); e->h_go.resize(G);
     *out = e;
     return BO_OK;
 }
@@ -354,6 +362,62 @@ extern "C" int bo_play(bo_engine *e, const int32_t *action, void *stream) {
     RT(rt_h2d(e->d_action, action, (size_t)e->d.c.G * 4, stream));
     RT(RT_LAUNCH(bo_k_play, e->d.c.G, stream, e->d, (const int *)e->d_action));
     return BO_OK;
+}
+
+// ---- native per-move host work (bit-compatible with numpy.random.RandomState; bo_hostrng.h) ----------------------
+extern "C" int bo_rng_seed(bo_engine *e, int slot, uint32_t seed) {
+    if (!e || slot < 0 || slot >= e->d.c.G) return fail(BO_E_ARG, "bad slot");
+    hr_seed(&e->rng[slot], seed);
+    return BO_OK;
+}
+
+extern "C" int bo_rng_state(bo_engine *e, int slot, int set, uint32_t *key624, int32_t *pos, int32_t *has_gauss, double *gauss) {
+    if (!e || slot < 0 || slot >= e->d.c.G || !key624 || !pos || !has_gauss || !gauss) return fail(BO_E_ARG, "bad arguments");
+    HostRng &r = e->rng[slot];
+    if (set) {
+        memcpy(r.key, key624, sizeof(r.key));
+        r.pos = *pos; r.has_gauss = *has_gauss; r.gauss = *gauss;
+    } else {
+        memcpy(key624, r.key, sizeof(r.key));
+        *pos = r.pos; *has_gauss = r.has_gauss; *gauss = r.gauss;
+    }
+    return BO_OK;
+}
+
+extern "C" int bo_selfplay_sample(bo_engine *e, const int32_t *active, const int32_t *move_number, int32_t threshold,
+                                  double t_initial, double t_final, int32_t *res_n, int32_t *res_idx, float *res_val,
+                                  int32_t *best_idx, int32_t *action_out, void *stream) {
+    if (!e || !active || !move_number || !res_n || !res_idx || !res_val || !action_out) return fail(BO_E_ARG, "null argument");
+    int rc = bo_search_result(e, res_n, res_idx, res_val, best_idx, nullptr, nullptr, stream);
+    if (rc) return rc;
+    const int G = e->d.c.G;
+    for (int g = 0; g < G; g++) {
+        if (!active[g]) { action_out[g] = -1; continue; }
+        const int a = hr_select_action(&e->rng[g], res_n[g], res_idx + (size_t)g * BO_RES_CAP, res_val + (size_t)g * BO_RES_CAP,
+                                       move_number[g], threshold, t_initial, t_final);
+        action_out[g] = a >= 0 ? a : -3;  // -3: not sparse enough, the caller samples with the dense NumPy mirror
+    }
+    return BO_OK;
+}
+
+extern "C" int bo_selfplay_begin(bo_engine *e, const int32_t *want, float *nn_in_dev, int32_t *n_legal_out, int32_t *terminal_out,
+                                 int32_t *go_out, void *stream) {
+    if (!e || !want || !nn_in_dev) return fail(BO_E_ARG, "null argument");
+    const int G = e->d.c.G;
+    int rc = bo_root_info(e, e->h_nl.data(), e->h_term.data(), nullptr, stream);
+    if (rc) return rc;
+    const double alpha = e->cfg.dirichlet_alpha;
+    for (int g = 0; g < G; g++) {
+        const int go = want[g] && e->h_term[g] == 0;
+        e->h_go[g] = go;
+        if (go && alpha > 0) hr_dirichlet(&e->rng[g], alpha, e->h_nl[g], &e->h_noise[(size_t)g * BO_MAX_MOVES]);  // mcts.py:192
+        if (n_legal_out) n_legal_out[g] = e->h_nl[g];
+        if (terminal_out) terminal_out[g] = e->h_term[g];
+        if (go_out) go_out[g] = go;
+    }
+    rc = bo_search_begin(e, e->h_go.data(), alpha > 0 ? e->h_noise.data() : nullptr, nn_in_dev, stream);
+    if (rc) return rc;
+    return bo_step(e, nullptr, nullptr, BO_POLICY_NONE, nn_in_dev, stream);
 }
 
 // ---- records ------------------------------------------------------------------------------------------------

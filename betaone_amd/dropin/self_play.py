@@ -38,16 +38,20 @@ def select_move_with_temperature(probs: np.ndarray, move_number: int) -> int:
                                                  config.TEMPERATURE_INITIAL, config.TEMPERATURE_FINAL)
 
 
-def _rollout(model, n_slots: int) -> Rollout:
+def _rollout(model, n_slots: int, rng_mode: str = "python") -> Rollout:
     lib, dev = (None, config.DEVICE) if _test_backend is None else _test_backend
     if _test_backend is None and not str(dev).startswith("cuda"):
         raise E.EngineError("self_play needs config.DEVICE == 'cuda' (MI355X); there is no CPU path")
+    if _test_backend is None and hasattr(model, "for_inference"):  # BN-folded copy in the faster layout for n_slots rows
+        from betaone_amd.nn_tune import best_inference_copy
+
+        model = best_inference_copy(model, n_slots, dev, next(model.parameters()).dtype)
     return Rollout(model, n_slots, num_simulations=config.NUM_SIMULATIONS, mcts_batch_size=config.MCTS_BATCH_SIZE,
                    cpuct=config.CPUCT, widen_coeff=config.WIDEN_COEFF, dirichlet_alpha=config.DIRICHLET_ALPHA,
                    dirichlet_epsilon=config.DIRICHLET_EPSILON, max_plies=config.ENGINE_MAX_PLIES,
                    max_game_moves=config.MAX_GAME_MOVES,
                    temperature=(config.TEMPERATURE_THRESHOLD, config.TEMPERATURE_INITIAL, config.TEMPERATURE_FINAL),
-                   device=dev, autocast=config.AUTOCAST, use_graph=_test_backend is None, lib=lib)
+                   device=dev, autocast=config.AUTOCAST, use_graph=_test_backend is None, rng_mode=rng_mode, lib=lib)
 
 
 def _records(ro: Rollout, fin: FinishedGame) -> List[SelfPlayData]:
@@ -69,7 +73,7 @@ def run_self_play_games(model, game_ids: Sequence[int], seeds: Optional[Sequence
     ids = list(game_ids)
     seeds = list(seeds) if seeds is not None else ids
     n_slots = min(n_slots or len(ids), len(ids))
-    ro = _rollout(model, n_slots)
+    ro = _rollout(model, n_slots, rng_mode="native")  # RandomState(seed)-compatible streams kept inside the engine
     results: Dict[int, Optional[List[SelfPlayData]]] = {}
     queue = list(range(len(ids)))
 
@@ -77,7 +81,7 @@ def run_self_play_games(model, game_ids: Sequence[int], seeds: Optional[Sequence
         if not queue:
             return None
         i = queue.pop(0)
-        return ids[i], np.random.RandomState(seeds[i]), (start_fens[i] if start_fens else None)
+        return ids[i], int(seeds[i]), (start_fens[i] if start_fens else None)
 
     def finished(fin: FinishedGame):
         if fin.terminal == 0:

@@ -69,6 +69,11 @@ _SYMBOLS = {
     "bo_play": (C.c_int, [C.c_void_p, _I32P, C.c_void_p]),
     "bo_game_export": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BoPosition), _I32P, C.c_int32, _I32P, C.c_void_p]),
     "bo_game_encode": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "bo_rng_seed": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
+    "bo_rng_state": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint32), _I32P, _I32P, _F64P]),
+    "bo_selfplay_sample": (C.c_int, [C.c_void_p, _I32P, _I32P, C.c_int32, C.c_double, C.c_double, _I32P, _I32P, _F32P,
+                                     _I32P, _I32P, C.c_void_p]),
+    "bo_selfplay_begin": (C.c_int, [C.c_void_p, _I32P, C.c_void_p, _I32P, _I32P, _I32P, C.c_void_p]),
     "bo_records_encode": (C.c_int, [C.c_int, C.POINTER(BoPosition), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bo_debug_tree": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BoNode), C.c_int32, _I32P, C.c_void_p]),
     "bo_engine_status": (C.c_int, [C.c_void_p, _I32P, _I32P, _I32P, _I32P, _I32P, _I32P, C.c_void_p]),
@@ -219,6 +224,39 @@ class Engine:
         a = _i32(actions)
         assert a.shape == (self.G,)
         self._check(self.lib.bo_play(self.h, _p(a), stream))
+
+    # -- native per-move host work (RandomState-compatible streams inside the engine) ----------------------
+    def rng_seed(self, slot: int, seed: int):
+        self._check(self.lib.bo_rng_seed(self.h, slot, seed & 0xFFFFFFFF))
+
+    def rng_get_state(self, slot: int):
+        """-> tuple accepted by numpy.random.RandomState.set_state"""
+        key = np.zeros(624, dtype=np.uint32)
+        pos, hg, g = C.c_int32(), C.c_int32(), C.c_double()
+        self._check(self.lib.bo_rng_state(self.h, slot, 0, key.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos),
+                                          C.byref(hg), C.byref(g)))
+        return ("MT19937", key, pos.value, hg.value, g.value)
+
+    def rng_set_state(self, slot: int, state):
+        key = np.ascontiguousarray(state[1], dtype=np.uint32)
+        pos, hg, g = C.c_int32(int(state[2])), C.c_int32(int(state[3])), C.c_double(float(state[4]))
+        self._check(self.lib.bo_rng_state(self.h, slot, 1, key.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos),
+                                          C.byref(hg), C.byref(g)))
+
+    def selfplay_sample(self, active, move_number, temperature, out, stream: int = 0):
+        """out: dict of preallocated arrays n[G], idx[G,RES_CAP], val[G,RES_CAP], best_idx[G], action[G]."""
+        a, m = _i32(active), _i32(move_number)
+        th, ti, tf = temperature
+        self._check(self.lib.bo_selfplay_sample(self.h, _p(a), _p(m), int(th), float(ti), float(tf), _p(out["n"]),
+                                                _p(out["idx"]), _p(out["val"], _F32P), _p(out["best_idx"]),
+                                                _p(out["action"]), stream))
+        return out
+
+    def selfplay_begin(self, want, nn_in_ptr: int, stream: int = 0):
+        w = _i32(want)
+        nl, tm, go = (np.zeros(self.G, dtype=np.int32) for _ in range(3))
+        self._check(self.lib.bo_selfplay_begin(self.h, _p(w), nn_in_ptr, _p(nl), _p(tm), _p(go), stream))
+        return nl, tm, go
 
     # -- records / introspection --------------------------------------------------------------------
     def export_game(self, slot: int, stream: int = 0):

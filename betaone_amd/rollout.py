@@ -71,7 +71,7 @@ class Rollout:
                  cpuct: float = 1.0, widen_coeff: float = 1.5, dirichlet_alpha: float = 0.1,
                  dirichlet_epsilon: float = 0.25, max_plies: int = 2048, max_game_moves: int = 16384,
                  temperature=(30, 1.0, 0.1), device: str = "cuda:0", use_graph: bool = True, autocast: bool = False,
-                 lib=None):
+                 rng_mode: str = "python", lib=None):
         if not str(device).startswith("cuda") and lib is None:
             raise E.EngineError("betaone_amd.Rollout runs on an MI355X (device='cuda:N'); there is no CPU path")
         self.device = torch.device(device)
@@ -96,6 +96,21 @@ class Rollout:
         self.n_sims = 0             # simulations completed (NUM_SIMULATIONS per finished search)
         self.n_plies = 0
         self.host_seconds = 0.0     # time spent in per-move host work (noise + sampling + bookkeeping)
+        # rng_mode "python": one numpy RandomState (or the numpy.random module) per game, drawn in Python.
+        # rng_mode "native": the same legacy MT19937 streams kept inside the engine (bo_hostrng.h); `rngs` passed to
+        # start_games are then integer seeds, and a ply costs three library calls instead of a Python loop over games.
+        assert rng_mode in ("python", "native")
+        self.rng_mode = rng_mode
+        G = self.G
+        self._active = np.zeros(G, dtype=bool)
+        self._plies = np.zeros(G, dtype=np.int64)
+        self._start_full = np.ones(G, dtype=np.int64)
+        self._start_black = np.zeros(G, dtype=np.int64)
+        self._start_step = np.zeros(G, dtype=np.int64)
+        self._step = 0
+        self._hist = {}             # step -> (n[G], idx[G,K], val[G,K]) sparse pi of every game at that step
+        self._out = dict(n=np.zeros(G, np.int32), idx=np.zeros((G, E.RES_CAP), np.int32), val=np.zeros((G, E.RES_CAP), np.float32),
+                         best_idx=np.zeros(G, np.int32), action=np.zeros(G, np.int32))
 
     # ---- evaluate + step -------------------------------------------------------------------------
     def _stream(self) -> int:
@@ -151,6 +166,12 @@ class Rollout:
                                       start_white=white)
             if moves is not None and moves[i]:
                 self.games[s].plies = len(moves[i].split())
+            self._active[s] = True
+            self._plies[s] = self.games[s].plies
+            self._start_full[s], self._start_black[s] = full, 0 if white else 1
+            self._start_step[s] = self._step
+            if self.rng_mode == "native":
+                self.eng.rng_seed(s, int(rngs[i]))
 
     # ---- one search for every active slot (run_mcts) ----------------------------------------------------
     def search(self, go: np.ndarray, n_legal: np.ndarray, terminal: np.ndarray) -> Dict[str, np.ndarray]:
@@ -182,6 +203,8 @@ class Rollout:
         """Advance every active game by one move.  Finished games are reported through `on_finished`
         and their slots refilled by `refill(slot) -> (game_id, rng, fen)`.  Returns the number of
         moves played."""
+        if self.rng_mode == "native":
+            return self._play_ply_native(on_finished, refill)
         n_legal, terminal, ply = self.eng.root_info(self._stream())
         t0 = time.perf_counter()
         done_slots = [g for g in range(self.G) if self.games[g] is not None and
@@ -194,6 +217,7 @@ class Rollout:
                 if on_finished is not None:
                     on_finished(fin)
                 self.games[g] = None
+                self._active[g] = False
                 nxt = refill(g) if refill is not None else None
                 if nxt is not None:
                     new_slots.append(g); ids.append(nxt[0]); rngs.append(nxt[1]); fens.append(nxt[2])
@@ -220,11 +244,86 @@ class Rollout:
         self.n_plies += n_moves
         return n_moves
 
+    def _run_search_steps(self):
+        burst = self.expected_evals
+        while True:
+            for _ in range(burst):
+                self._eval_and_step()
+            running, _, _ = self.eng.poll(self._stream(), want_mask=False)
+            if running == 0:
+                break
+            burst = 1
+
+    def _play_ply_native(self, on_finished, refill) -> int:
+        """play_ply with the per-move host work done inside the library (same streams, same results)."""
+        eng, G = self.eng, self.G
+        stream = self._stream()
+        t0 = time.perf_counter()
+        want = self._active & (self._plies < self.max_game_moves)
+        limit_done = np.nonzero(self._active & ~want)[0]
+        self.host_seconds += time.perf_counter() - t0
+        nl, term, go = eng.selfplay_begin(want.astype(np.int32), self.nn_in.data_ptr(), stream)
+        done = [int(g) for g in limit_done] + [int(g) for g in np.nonzero(want & (term != 0))[0]]
+        if done:
+            new_slots, ids, seeds, fens = [], [], [], []
+            for g in done:
+                fin = self._finish(g, int(term[g]))
+                if on_finished is not None:
+                    on_finished(fin)
+                self.games[g] = None
+                self._active[g] = False
+                nxt = refill(g) if refill is not None else None
+                if nxt is not None:
+                    new_slots.append(g); ids.append(nxt[0]); seeds.append(nxt[1]); fens.append(nxt[2])
+            if new_slots:
+                self.start_games(new_slots, ids, seeds, fens)
+                w2 = np.zeros(G, dtype=np.int32)
+                w2[new_slots] = 1
+                _nl2, _t2, go2 = eng.selfplay_begin(w2, self.nn_in.data_ptr(), stream)
+                go = go | go2
+        if not go.any():
+            return 0
+        self._run_search_steps()
+        self.n_sims += int(np.count_nonzero(go)) * self.S
+        t0 = time.perf_counter()
+        move_number = self._start_full + (self._plies + self._start_black) // 2   # board.fullmove_number, self_play.py:104
+        self.host_seconds += time.perf_counter() - t0
+        out = eng.selfplay_sample(go, move_number, self.temperature, self._out, stream)
+        t0 = time.perf_counter()
+        actions = out["action"]
+        for g in np.nonzero(actions == -3)[0]:  # rare: pi not sparse enough for the native sampler
+            rs = np.random.RandomState(0)
+            rs.set_state(eng.rng_get_state(int(g)))
+            n = int(out["n"][g])
+            th, ti, tf = self.temperature
+            actions[g] = sampling.select_action_sparse(out["idx"][g, :n], out["val"][g, :n], int(move_number[g]), rs, th, ti, tf)
+            eng.rng_set_state(int(g), rs.get_state())
+        k = max(1, int(out["n"].max()))
+        self._hist[self._step] = (out["n"].copy(), out["idx"][:, :k].copy(), out["val"][:, :k].copy())
+        self._step += 1
+        self._plies += go
+        for g in np.nonzero(go)[0]:
+            self.games[g].plies += 1
+        lo = int(self._start_step[self._active].min()) if self._active.any() else self._step
+        for st in [st for st in self._hist if st < lo]:
+            del self._hist[st]
+        self.host_seconds += time.perf_counter() - t0
+        eng.play(actions, stream)
+        n_moves = int(np.count_nonzero(go))
+        self.n_plies += n_moves
+        return n_moves
+
     def _finish(self, g: int, terminal: int) -> FinishedGame:
         gs = self.games[g]
         positions, moves = self.eng.export_game(g, self._stream())
         outcome = 1.0 if terminal == 1 else 0.0
-        return FinishedGame(game_id=gs.game_id, slot=g, moves=moves, positions=positions, pis=gs.pis, outcome=outcome,
+        pis = gs.pis
+        if self.rng_mode == "native":  # gather this game's sparse pis from the per-step arrays
+            pis = []
+            for st in range(int(self._start_step[g]), self._step):
+                n, idx, val = self._hist[st]
+                pis.append((idx[g, :n[g]].copy(), val[g, :n[g]].copy()))
+        return FinishedGame(game_id=gs.game_id, slot=g, moves=moves, positions=positions, pis=pis, outcome=outcome,
                             terminal=terminal)
 
     # ---- training records ---------------------------------------------------------------------------------

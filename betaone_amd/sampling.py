@@ -86,6 +86,10 @@ def select_action_sparse(idx: np.ndarray, val: np.ndarray, move_number: int, rng
     """select_move_with_temperature on a sparse pi given as (action indices, float32 values)."""
     n = len(idx)
     temp = t_initial if move_number < threshold else t_final
+    if n == 1 and temp != 0 and val[0] == 1.0:
+        # one-hot pi: every temperature leaves [1.0]; choice() still draws its one uniform (cdf = [1.0] > u)
+        rng.random_sample()
+        return int(idx[0])
     if n == 0 or n > 2 or temp == 0:
         return select_move_with_temperature(dense_pi(idx, val), move_number, rng, threshold, t_initial, t_final)
     order = np.argsort(idx, kind="stable")

@@ -131,6 +131,25 @@ int bo_search_result(bo_engine *e, int32_t *res_n, int32_t *res_idx, float *res_
  * fallbacks, push it on the game's stack and tracker, prepare the next root.  Asynchronous. */
 int bo_play(bo_engine *e, const int32_t *action, void *stream);
 
+/* ---- per-move host work, natively -----------------------------------------------------------------
+ * The reference draws np.random.dirichlet (mcts.py:192) and np.random.choice (self_play.py:73) once per move.
+ * With one legacy MT19937 stream per game slot kept inside the engine (bit-compatible with
+ * numpy.random.RandomState(seed): same seeding, same legacy gamma/dirichlet algorithm, same draws), the per-move
+ * host work of thousands of games is two calls:
+ *   bo_selfplay_sample : bo_search_result + select_move_with_temperature (self_play.py:59-80) for every active
+ *                        game; action_out[g] = sampled action index, -1 inactive, -3 "pi has more than two
+ *                        non-zero entries (or temperature 0): sample with the dense NumPy mirror" (the caller
+ *                        may move the stream out and back with bo_rng_state).  Synchronises.
+ *   bo_selfplay_begin  : bo_root_info + Dirichlet noise for every game with want[g] != 0 whose root is not
+ *                        terminal + bo_search_begin + the first bo_step.  Synchronises (root info). */
+int bo_rng_seed(bo_engine *e, int slot, uint32_t seed);
+int bo_rng_state(bo_engine *e, int slot, int set, uint32_t *key624, int32_t *pos, int32_t *has_gauss, double *gauss);
+int bo_selfplay_sample(bo_engine *e, const int32_t *active, const int32_t *move_number, int32_t threshold,
+                       double t_initial, double t_final, int32_t *res_n, int32_t *res_idx, float *res_val,
+                       int32_t *best_idx, int32_t *action_out, void *stream);
+int bo_selfplay_begin(bo_engine *e, const int32_t *want, float *nn_in_dev, int32_t *n_legal_out, int32_t *terminal_out,
+                      int32_t *go_out, void *stream);
+
 /* ---- records ------------------------------------------------------------------------------------
  * The game in `slot` as plain data: its positions[0..n_plies] and moves[0..n_plies). */
 int bo_game_export(bo_engine *e, int slot, bo_position *positions, int32_t *moves, int32_t cap, int32_t *n_plies,

@@ -1,0 +1,122 @@
+"""CPU tests: the engine's native per-game random streams (betaone_amd/csrc/bo_hostrng.h) against
+numpy.random.RandomState draw for draw -- seeding, random_sample, legacy dirichlet, temperature sampling."""
+import numpy as np
+import pytest
+
+from betaone_amd import engine as E, sampling
+from engine_harness import emu_lib
+
+
+@pytest.fixture(scope="module")
+def eng():
+    return E.Engine(4, num_simulations=10, lib=emu_lib())
+
+
+@pytest.mark.parametrize("seed", [0, 1, 7, 12345, 2**31 + 5, 2**32 - 1])
+def test_seeding_and_state_roundtrip_match_randomstate(eng, seed):
+    eng.rng_seed(1, seed)
+    st = eng.rng_get_state(1)
+    ref = np.random.RandomState(seed).get_state()
+    assert np.array_equal(st[1], ref[1]) and st[2:] == tuple(ref[2:])
+    rs = np.random.RandomState(0)
+    rs.set_state(st)
+    assert rs.random_sample() == np.random.RandomState(seed).random_sample()
+
+
+def _native_stream(eng, slot):
+    rs = np.random.RandomState(0)
+    rs.set_state(eng.rng_get_state(slot))
+    return rs
+
+
+def test_sampling_matches_numpy_draw_for_draw(eng):
+    gen = np.random.RandomState(99)
+    out = dict(n=np.zeros(4, np.int32), idx=np.zeros((4, E.RES_CAP), np.int32), val=np.zeros((4, E.RES_CAP), np.float32),
+               best_idx=np.zeros(4, np.int32), action=np.zeros(4, np.int32))
+    import ctypes as C
+    L = eng.lib
+    for trial in range(3000):
+        seed = int(gen.randint(1 << 31))
+        n = int(gen.randint(1, 3))
+        idx = gen.choice(4672, n, replace=False).astype(np.int32)
+        tot = int(gen.randint(1, 801))
+        if n == 2 and tot > 1:
+            a = int(gen.randint(1, tot))
+            cnt = [a, tot - a]
+        else:
+            cnt, idx = [tot], idx[:1]
+        val = np.array([np.float32(c / tot) for c in cnt], dtype=np.float32)
+        mv = int(gen.randint(1, 70))
+        ref = np.random.RandomState(seed)
+        exp = sampling.select_move_with_temperature(sampling.dense_pi(idx, val), mv, ref)
+        # drive hr_select_action through the public entry point is not possible without a finished search:
+        # use the stream check instead -- seed, sample via the sparse Python path on the exported state
+        eng.rng_seed(0, seed)
+        rs = _native_stream(eng, 0)
+        got = sampling.select_action_sparse(idx, val, mv, rs)
+        assert got == exp and rs.random_sample() == ref.random_sample()
+
+
+@pytest.mark.parametrize("alpha", [0.1, 0.3, 1.0, 2.5])
+def test_dirichlet_matches_numpy(eng, alpha):
+    """bo_selfplay_begin draws the root noise natively: compare the stream position afterwards and the noise via
+    a search's visible effect is covered elsewhere; here: state equality after the same number of draws."""
+    e = E.Engine(3, num_simulations=10, dirichlet_alpha=alpha, lib=emu_lib())
+    e.reset([0, 1, 2], [None, "r3k2r/p1ppqpb1/bn2pnp1/3PN3/1p2P3/2N2Q1p/PPPBBPPP/R3K2R w KQkq - 0 1", None])
+    nn_in = np.zeros((3, 120, 8, 8), dtype=np.float32)
+    for g, seed in enumerate([5, 6, 7]):
+        e.rng_seed(g, seed)
+    nl, term, go = e.selfplay_begin([1, 1, 0], nn_in.ctypes.data)
+    assert list(go) == [1, 1, 0] and list(nl[:2]) == [20, 48]
+    for g, seed in enumerate([5, 6, 7]):
+        ref = np.random.RandomState(seed)
+        if go[g]:
+            ref.dirichlet([alpha] * int(nl[g]))
+        st = e.rng_get_state(g)
+        rs = ref.get_state()
+        assert np.array_equal(st[1], rs[1]) and st[2] == rs[2] and st[3] == rs[3] and st[4] == rs[4]
+    e.close()
+
+
+def test_native_rollout_equals_python_rollout_and_oracle():
+    """Whole games: rng_mode='native' (streams inside the engine) == rng_mode='python' (numpy RandomState per game)
+    == the CPU oracle, including games that cross the temperature threshold (fullmove >= 30)."""
+    import torch
+    from betaone_amd.rollout import Rollout
+    from fake_model import FakeNet, fake_logits_values
+    from oracle import oracle as O
+
+    class Net(torch.nn.Module):
+        def forward(self, x):
+            return FakeNet(scale=0.0, salt=31)(x)
+
+    fens = [None, None, "r1bqkbnr/pppp1ppp/2n5/4p3/4P3/5N2/PPPP1PPP/RNBQKB1R w KQkq - 2 29", "k7/8/1K6/8/8/8/8/7R w - - 90 60"]
+    seeds = [3, 4, 5, 6]
+
+    def play(mode):
+        ro = Rollout(Net(), 4, num_simulations=40, mcts_batch_size=16, max_game_moves=7, device="cpu", use_graph=False,
+                     rng_mode=mode, lib=emu_lib())
+        rngs = seeds if mode == "native" else [np.random.RandomState(s) for s in seeds]
+        ro.start_games([0, 1, 2, 3], [0, 1, 2, 3], rngs, fens)
+        fins = {}
+        while any(g is not None for g in ro.games):
+            ro.play_ply(on_finished=lambda f: fins.__setitem__(f.game_id, f))
+        ro.close()
+        return fins
+
+    a, b = play("native"), play("python")
+    assert sorted(a) == sorted(b) == [0, 1, 2, 3]
+    for gid in a:
+        assert a[gid].moves == b[gid].moves and a[gid].terminal == b[gid].terminal
+        assert len(a[gid].pis) == len(b[gid].pis)
+        for (i1, v1), (i2, v2) in zip(a[gid].pis, b[gid].pis):
+            assert i1.tolist() == i2.tolist() and v1.tolist() == v2.tolist()
+
+    def uniform_eval(planes):
+        _, v = fake_logits_values(planes, 0.0, 31)
+        return np.full((planes.shape[0], 4672), np.float32(1.0) / np.float32(4672.0), dtype=np.float32), v
+
+    for gid in (0, 2, 3):
+        ref = O.self_play(uniform_eval, np.random.RandomState(seeds[gid]),
+                          O.default_config(num_simulations=40, batch_size=16, max_game_moves=7), start_fen=fens[gid] or "")
+        assert [E.move_to_uci(m) for m in a[gid].moves] == [O.move_to_uci(m) for m in ref["moves"]]
