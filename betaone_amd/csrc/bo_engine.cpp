@@ -6,6 +6,7 @@
 
 #include "bo_tree.h"
 #include "bo_select_wide.h"
+#include "bo_nn_fused.h"
 #include "bo_rt.h"
 #include "bo_hostrng.h"
 
@@ -550,6 +551,45 @@ extern "C" int bo_select_wide(const void *blocks_dev, const int32_t *root_block_
     hipLaunchKernelGGL(kern, dim3((unsigned)grid_blocks), dim3(256), 0, (hipStream_t)stream,
                        (const WideBlock *)blocks_dev, (const int *)root_block_dev, (const int *)root_n_dev, sqrt_lut_dev,
                        n_trees, max_depth, cpuct, (int *)out_leaf_dev, (int *)out_levels_dev);
+    RT((int)hipGetLastError());
+    return BO_OK;
+#endif
+}
+
+// ---- fused epilogues of the evaluate stage (bo_nn_fused.h); independent of an engine instance -----------------------
+extern "C" int bo_nn_bias_act(float *x_dev, const float *bias_dev, const float *residual_dev, int batch, int channels,
+                              void *stream) {
+#if defined(BO_WAVE_EMU)
+    (void)x_dev; (void)bias_dev; (void)residual_dev; (void)batch; (void)channels; (void)stream;
+    return fail(BO_E_CONFIG, "bo_nn_bias_act is a gfx950-only kernel");
+#else
+    if (!x_dev || !bias_dev || batch < 1 || channels < 1) return fail(BO_E_ARG, "bad arguments");
+    const long n4 = (long)batch * channels * 16;
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(bo_k_bias_act, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_dev, bias_dev, residual_dev, n4,
+                       channels);
+    RT((int)hipGetLastError());
+    return BO_OK;
+#endif
+}
+
+extern "C" int bo_nn_se_residual(float *x_dev, const float *bias_dev, const float *w1_dev, const float *w2_dev,
+                                 const float *residual_dev, int batch, int channels, int hidden, void *stream) {
+#if defined(BO_WAVE_EMU)
+    (void)x_dev; (void)bias_dev; (void)w1_dev; (void)w2_dev; (void)residual_dev; (void)batch; (void)channels; (void)hidden; (void)stream;
+    return fail(BO_E_CONFIG, "bo_nn_se_residual is a gfx950-only kernel");
+#else
+    if (!x_dev || !bias_dev || !w1_dev || !w2_dev || !residual_dev || batch < 1) return fail(BO_E_ARG, "bad arguments");
+    if (channels < 1 || channels > BO_SE_MAX_C || hidden < 1 || hidden > BO_SE_MAX_H) return fail(BO_E_CONFIG, "SE block: channels <= 256, hidden <= 32");
+    const size_t lds = (size_t)channels * 65 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)bo_k_se_residual, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 65 * 4);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(bo_k_se_residual, dim3((unsigned)batch), dim3(256), lds, (hipStream_t)stream, x_dev, bias_dev, w1_dev, w2_dev,
+                       residual_dev, channels, hidden);
     RT((int)hipGetLastError());
     return BO_OK;
 #endif

@@ -78,6 +78,9 @@ _SYMBOLS = {
     "bo_debug_tree": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BoNode), C.c_int32, _I32P, C.c_void_p]),
     "bo_engine_status": (C.c_int, [C.c_void_p, _I32P, _I32P, _I32P, _I32P, _I32P, _I32P, C.c_void_p]),
     "bo_movegen_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BoPosition), _I32P, _I32P, _I32P, C.c_void_p]),
+    "bo_nn_bias_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "bo_nn_se_residual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p]),
     "bo_select_wide": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
 }

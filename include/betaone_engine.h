@@ -191,6 +191,14 @@ int bo_select_wide(const void *blocks_dev, const int32_t *root_block_dev, const 
                    const float *sqrt_lut_dev, int n_trees, int max_depth, float cpuct, int grid_blocks,
                    int32_t *out_leaf_dev, int32_t *out_levels_dev, void *stream);
 
+/* ---- fused epilogues of the evaluate stage (network.py:64-118 with BatchNorm folded), NCHW float32, 8x8 ----------
+ * x = relu(x + bias[c] (+ residual)) in place; residual_dev may be NULL.  Asynchronous on `stream`. */
+int bo_nn_bias_act(float *x_dev, const float *bias_dev, const float *residual_dev, int batch, int channels, void *stream);
+/* x = relu((x + bias[c]) * sigmoid(W2 relu(W1 mean_hw(x + bias))) + residual) in place: the SE residual block's tail
+ * (network.py:33-45,100-118).  w1 [hidden][channels], w2 [channels][hidden].  Asynchronous on `stream`. */
+int bo_nn_se_residual(float *x_dev, const float *bias_dev, const float *w1_dev, const float *w2_dev,
+                      const float *residual_dev, int batch, int channels, int hidden, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

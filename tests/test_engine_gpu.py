@@ -158,3 +158,32 @@ def test_records_roundtrip_and_expand(backend):
         for i, (st, pi, z) in enumerate(recs):
             assert torch.equal(st, dense[f.game_id][i])  # re-expanded on "another rank" == encoded in the slot
             assert z == f.z(i)
+
+
+@pytest.mark.parametrize("size", [(3, 1, 64), (8, 2, 128), (2, 2, 256)])
+def test_fused_epilogue_net_matches_plain_net(backend, size):
+    """csrc/bo_nn_fused.h: conv (MIOpen) + one fused epilogue kernel == PolicyValueNet.forward, within 1e-5."""
+    import torch
+    from betaone_amd import dropin
+    dropin.install()
+    import config, network
+    from betaone_amd.fused_net import FusedPolicyValueNet
+    from fake_model import hash_init_
+
+    saved = (config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS)
+    config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = size
+    try:
+        net = hash_init_(network.PolicyValueNet().eval()).to("cuda:0")
+        fused = FusedPolicyValueNet(net).to("cuda:0")
+        z = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "g1_net.npz"))
+        x = torch.from_numpy(z["inputs"]).to("cuda:0").repeat(11, 1, 1, 1)  # 33 boards
+        with torch.no_grad():
+            l0, v0 = net(x)
+            l1, v1 = fused(x.clone())
+        assert (l0 - l1).abs().max().item() < 1e-5 and (v0 - v1).abs().max().item() < 1e-5
+        name = {(3, 1, 64): "3+1x64", (8, 2, 128): "8+2x128"}.get(size)
+        if name:  # and against the reference's own outputs (fixture G1)
+            assert np.abs(l1[:3].cpu().numpy() - z[f"logits_{name}"]).max() < 1e-4
+            assert np.abs(v1[:3].cpu().numpy() - z[f"value_{name}"]).max() < 1e-4
+    finally:
+        config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = saved
