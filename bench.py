@@ -55,6 +55,10 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--wide-trees", type=int, default=0, help="0 = 262144 if >= 150 GB of HBM is free, else 131072")
     ap.add_argument("--wide-nodes", type=int, default=800)
+    ap.add_argument("--max-game-moves", type=int, default=16384, help="config.MAX_GAME_MOVES (small values make games finish: record path)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 path on one GPU")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with WORLD_SIZE=1")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -169,11 +173,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if args.share_gpu:
+        local = 0
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
 
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group("gloo")
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
 
@@ -188,7 +197,7 @@ def main():
         net = CastIn(net, {"fp16": torch.float16, "bf16": torch.bfloat16}[args.net_dtype])
     G = args.games
     ro = Rollout(net, G, num_simulations=args.sims, mcts_batch_size=args.batch, device=str(device), use_graph=not args.no_graph,
-                 rng_mode="native")
+                 rng_mode="native", max_game_moves=args.max_game_moves)
     ids = [rank + world * s for s in range(G)]  # game id -> rank = id mod world; RandomState(seed = game id) streams
     ro.start_games(list(range(G)), ids, ids)
     next_id = [rank + world * G]
@@ -205,7 +214,7 @@ def main():
 
     def one_step():
         ro.play_ply(on_finished=on_finished, refill=refill)
-        if world > 1:  # the path's only exchange step: finished games' records to every rank (RCCL over xGMI)
+        if dist is not None:  # the path's only exchange step: finished games' records to every rank (RCCL over xGMI)
             records.all_gather_games(finished_batch, device)
         finished_batch.clear()
 
@@ -223,10 +232,11 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        rdev = device if args.dist_backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tot = torch.tensor([ro.n_sims - s0, ro.n_plies - p0, ro.n_forward - f0], dtype=torch.float64, device=device)
+        tot = torch.tensor([ro.n_sims - s0, ro.n_plies - p0, ro.n_forward - f0], dtype=torch.float64, device=rdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         sims, plies, fwd = [float(x) for x in tot.tolist()]
     else:

@@ -95,7 +95,7 @@ def all_gather_bytes(payload: bytes, device: Optional[torch.device] = None, grou
     xGMI when the process group's backend is nccl, gloo on CPU in the tests."""
     import torch.distributed as dist
 
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized():
         return [payload]
     world = dist.get_world_size(group)
     backend = dist.get_backend(group)

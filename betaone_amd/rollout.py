@@ -71,7 +71,7 @@ class Rollout:
                  cpuct: float = 1.0, widen_coeff: float = 1.5, dirichlet_alpha: float = 0.1,
                  dirichlet_epsilon: float = 0.25, max_plies: int = 2048, max_game_moves: int = 16384,
                  temperature=(30, 1.0, 0.1), device: str = "cuda:0", use_graph: bool = True, autocast: bool = False,
-                 rng_mode: str = "python", lib=None):
+                 rng_mode: str = "python", policy_kind: str = "logits", lib=None):
         if not str(device).startswith("cuda") and lib is None:
             raise E.EngineError("betaone_amd.Rollout runs on an MI355X (device='cuda:N'); there is no CPU path")
         self.device = torch.device(device)
@@ -101,6 +101,10 @@ class Rollout:
         # start_games are then integer seeds, and a ply costs three library calls instead of a Python loop over games.
         assert rng_mode in ("python", "native")
         self.rng_mode = rng_mode
+        # policy_kind "logits": the engine's own in-kernel softmax (one pass over the row);
+        # "probs": torch.softmax(logits, dim=1) exactly as mcts.py:185,287 and the engine gathers probabilities.
+        assert policy_kind in ("logits", "probs")
+        self.policy_kind = E.POLICY_LOGITS if policy_kind == "logits" else E.POLICY_PROBS
         G = self.G
         self._active = np.zeros(G, dtype=bool)
         self._plies = np.zeros(G, dtype=np.int64)
@@ -123,12 +127,15 @@ class Rollout:
                     logits, value = self.model(self.nn_in)
             else:
                 logits, value = self.model(self.nn_in)
-        return logits.float().contiguous(), value.float().contiguous()
+        logits = logits.float()
+        if self.policy_kind == E.POLICY_PROBS:
+            logits = torch.softmax(logits, dim=1)
+        return logits.contiguous(), value.float().contiguous()
 
     def _eval_and_step_eager(self):
         logits, value = self._forward()
         self._logits, self._value = logits, value  # keep alive until the step kernel has run
-        self.eng.step(logits.data_ptr(), value.data_ptr(), E.POLICY_LOGITS, self.nn_in.data_ptr(), self._stream())
+        self.eng.step(logits.data_ptr(), value.data_ptr(), self.policy_kind, self.nn_in.data_ptr(), self._stream())
 
     def _capture(self):
         """Capture `net forward -> tree step` once; afterwards a step is one hipGraphLaunch."""
@@ -142,7 +149,7 @@ class Rollout:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             logits, value = self._forward()
-            self.eng.step(logits.data_ptr(), value.data_ptr(), E.POLICY_LOGITS, self.nn_in.data_ptr(), self._stream())
+            self.eng.step(logits.data_ptr(), value.data_ptr(), self.policy_kind, self.nn_in.data_ptr(), self._stream())
         self._graph, self._logits, self._value = g, logits, value
 
     def _eval_and_step(self):

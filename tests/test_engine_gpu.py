@@ -187,3 +187,71 @@ def test_fused_epilogue_net_matches_plain_net(backend, size):
             assert np.abs(v1[:3].cpu().numpy() - z[f"value_{name}"]).max() < 1e-4
     finally:
         config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = saved
+
+
+def test_full_size_config_parity_with_real_net(backend):
+    """BASELINE.json configs[1] (256 concurrent games, 400 sims/move, 10-block x 128 net) on the GPU for a few plies.
+    The (planes -> torch.softmax probabilities, value) pairs the engine consumed are recorded for three slots and
+    those games are replayed through the CPU oracle: moves and pi must agree bit for bit given identical net
+    outputs; every game must satisfy the size-independent invariants."""
+    import torch
+    from betaone_amd import dropin
+    dropin.install()
+    import config, network
+    from betaone_amd import engine as E_
+    from betaone_amd.rollout import Rollout
+    from fake_model import planes_key
+    from oracle import oracle as O
+
+    saved = (config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS)
+    config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 8, 2, 128
+    G, SIMS, PLIES, WATCH = 256, 400, 4, (0, 37, 255)
+    try:
+        torch.manual_seed(0)
+        net = network.PolicyValueNet().to("cuda:0").eval().for_inference(channels_last=False)
+        seam = {}
+
+        # the engine is fed torch.softmax probabilities (BO_POLICY_PROBS), the reference's own seam (mcts.py:185,287)
+        class ProbsNet(torch.nn.Module):
+            def forward(self, x):
+                logits, value = net(x)
+                probs = torch.softmax(logits.float(), dim=1)
+                for g in WATCH:
+                    seam[planes_key(x[g].cpu().numpy())] = (probs[g].cpu().numpy().copy(), value[g].float().reshape(-1).cpu().numpy().copy())
+                return probs, value
+
+        ro = Rollout(ProbsNet(), G, num_simulations=SIMS, mcts_batch_size=96, device="cuda:0", use_graph=False, rng_mode="native")
+        ro.policy_kind = 2  # BO_POLICY_PROBS with the probabilities computed above (no second softmax)
+        ro._forward = lambda: tuple(t.float().contiguous() for t in ProbsNet()(ro.nn_in))
+        ro.start_games(list(range(G)), list(range(G)), list(range(G)))
+        for _ in range(PLIES):
+            assert ro.play_ply() == G
+        ro.eng.check_status()
+        st = ro.eng.status()
+        assert (st["evals"] >= PLIES * 2).all() and (st["flushes"] >= PLIES).all()
+        games = {g: ro._finish(g, 0) for g in WATCH}
+        for st_ in range(ro._step):
+            n, idx, val = ro._hist[st_]
+            assert (n >= 1).all() and (n <= 2).all()
+            sums = np.array([val[g, :n[g]].sum() for g in range(G)])
+            assert np.abs(sums - 1.0).max() < 1e-6
+        ro.close()
+
+        def eval_fn(planes):
+            probs = np.zeros((planes.shape[0], 4672), np.float32)
+            vals = np.zeros(planes.shape[0], np.float32)
+            for i in range(planes.shape[0]):
+                probs[i], v = seam[planes_key(planes[i])]
+                vals[i] = v.reshape(-1)[0]
+            return probs, vals
+
+        for g in WATCH:
+            ref = O.self_play(eval_fn, np.random.RandomState(g), O.default_config(num_simulations=SIMS, max_game_moves=PLIES))
+            assert [O.move_to_uci(m) for m in ref["moves"]] == [E_.move_to_uci(m) for m in games[g].moves], g
+            for (_, rpi, _), (idx, val) in zip(ref["records"], games[g].pis):
+                nz = np.nonzero(rpi)[0]
+                assert sorted(nz.tolist()) == sorted(idx.tolist())
+                for i, v in zip(idx, val):
+                    assert np.float32(rpi[i]).view(np.uint32) == np.float32(v).view(np.uint32)
+    finally:
+        config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = saved
