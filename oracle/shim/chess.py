@@ -172,6 +172,14 @@ class Board:
         self._L.bo_stack_init(C.byref(self._s), C.byref(p))
         self.move_stack = []
 
+    def set_fen(self, fen: str):
+        p = _O.Pos()
+        if self._L.bo_pos_from_fen(fen.encode(), C.byref(p)) != 0:
+            raise ValueError(f"invalid fen: {fen!r}")
+        self._L.bo_stack_free(C.byref(self._s))
+        self._L.bo_stack_init(C.byref(self._s), C.byref(p))
+        self.move_stack = []
+
     def copy(self, *, stack=True) -> "Board":
         b = Board.__new__(Board)
         b._L = self._L
