@@ -269,7 +269,7 @@ def main():
     torch.cuda.empty_cache()
     if rank == 0 and not args.no_roofline:
         out["roofline"] = select_roofline(args, device)
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # "on rank 0 at N=1 only"
         out["cpu_baseline"] = cpu_baseline(args)
     if dist is not None:
         dist.barrier()
