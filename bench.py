@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--wide-trees", type=int, default=0, help="0 = 262144 if >= 150 GB of HBM is free, else 131072")
     ap.add_argument("--wide-nodes", type=int, default=800)
+    ap.add_argument("--fast", action="store_true", help="FAST search mode (virtual loss; not the reference's semantics; not the headline)")
+    ap.add_argument("--leaves", type=int, default=16, help="FAST mode: leaves per game per step")
     ap.add_argument("--max-game-moves", type=int, default=16384, help="config.MAX_GAME_MOVES (small values make games finish: record path)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 path on one GPU")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with WORLD_SIZE=1")
@@ -191,13 +193,13 @@ def main():
     from betaone_amd.rollout import Rollout
 
     E.load_hip_library()
-    _, net = make_net(args.net, device, args.net_dtype, args.games)
+    _, net = make_net(args.net, device, args.net_dtype, args.games * (args.leaves if args.fast else 1))
     net_layout = getattr(net, "layout", "nchw")
     if args.net_dtype != "fp32":
         net = CastIn(net, {"fp16": torch.float16, "bf16": torch.bfloat16}[args.net_dtype])
     G = args.games
     ro = Rollout(net, G, num_simulations=args.sims, mcts_batch_size=args.batch, device=str(device), use_graph=not args.no_graph,
-                 rng_mode="native", max_game_moves=args.max_game_moves)
+                 rng_mode="native", max_game_moves=args.max_game_moves, fast=args.fast, leaves_per_step=args.leaves)
     ids = [rank + world * s for s in range(G)]  # game id -> rank = id mod world; RandomState(seed = game id) streams
     ro.start_games(list(range(G)), ids, ids)
     next_id = [rank + world * G]
@@ -254,9 +256,11 @@ def main():
                                    f"random init, {args.net_dtype}, BN folded), start position, per-game seeds = game id; "
                                    f"BASELINE.json configs[2] per-GPU shard",
                        "games_per_gpu": G, "sims_per_move": args.sims, "net": args.net, "net_dtype": args.net_dtype,
-                       "hipgraph": not args.no_graph, "net_layout": net_layout, "parallelism": f"games sharded over {world} GPU(s), record all-gather only"},
+                       "hipgraph": not args.no_graph, "net_layout": net_layout,
+                       "search_mode": ("fast: virtual loss, %d leaves/step, full-width expansion (NOT the reference's semantics)" % args.leaves)
+                                      if args.fast else "reference semantics (bit-exact)", "parallelism": f"games sharded over {world} GPU(s), record all-gather only"},
             "plies_per_sec": round(plies / dt, 2), "nn_forwards_per_sec": round(fwd / dt / world, 2),
-            "unique_nn_evals_per_sec": round(fwd * G / dt, 1), "games_finished": n_finished[0],
+            "unique_nn_evals_per_sec": round(fwd * G * (args.leaves if args.fast else 1) / dt, 1), "games_finished": n_finished[0],
             "games_per_hour_at_100_plies": round(plies / dt * 3600 / 100.0, 1),
             "host_fraction": round((ro.host_seconds - h0) / dt, 4),
         }

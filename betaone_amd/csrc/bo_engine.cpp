@@ -5,6 +5,7 @@
 #include "../../include/betaone_engine.h"
 
 #include "bo_tree.h"
+#include "bo_fast.h"
 #include "bo_select_wide.h"
 #include "bo_nn_fused.h"
 #include "bo_rt.h"
@@ -28,6 +29,8 @@ static int fail(int code, const std::string &msg) {
 
 struct bo_engine {
     Eng d;
+    FastEng f;
+    bool fast = false;
     bo_config cfg;
     int device;
     std::vector<void *> allocs;
@@ -153,9 +156,12 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
     if (!cfg || !out) return fail(BO_E_ARG, "null argument");
     if (cfg->n_games < 1 || cfg->num_simulations < 0 || cfg->mcts_batch_size < 1 || cfg->max_plies < 2)
         return fail(BO_E_ARG, "n_games/num_simulations/mcts_batch_size/max_plies out of range");
-    const int root_m = (int)(cfg->widen_coeff * sqrt(1.0));
-    const int ch_max = (int)(cfg->widen_coeff * sqrt((double)cfg->mcts_batch_size));
-    if (cfg->widen_coeff < 1.0 || ch_max > BO_CH_CAP)
+    const bool fast = cfg->mode == 1;
+    if (cfg->mode != 0 && cfg->mode != 1) return fail(BO_E_ARG, "mode must be 0 (reference semantics) or 1 (fast)");
+    if (fast && (cfg->leaves_per_step < 1 || cfg->leaves_per_step > 256)) return fail(BO_E_ARG, "leaves_per_step out of range");
+    const int root_m = fast ? 1 : (int)(cfg->widen_coeff * sqrt(1.0));
+    const int ch_max = fast ? 1 : (int)(cfg->widen_coeff * sqrt((double)cfg->mcts_batch_size));
+    if (!fast && (cfg->widen_coeff < 1.0 || ch_max > BO_CH_CAP))
         return fail(BO_E_CONFIG, "WIDEN_COEFF must be >= 1 and int(WIDEN_COEFF*sqrt(MCTS_BATCH_SIZE)) <= 32");
     RT(rt_set_device(device));
     bo_engine *e = new bo_engine();
@@ -163,9 +169,10 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
     e->device = device;
     EngCfg &c = e->d.c;
     c.G = cfg->n_games; c.S = cfg->num_simulations; c.B = cfg->mcts_batch_size;
-    c.NCAP = c.S + 2 * root_m + 4;
+    e->fast = fast;
+    c.NCAP = fast ? 1 + (c.S + cfg->leaves_per_step + 1) * 64 : c.S + 2 * root_m + 4;
     c.PLY_CAP = cfg->max_plies; c.TRK_CAP = cfg->max_plies;
-    c.UL_MAX = c.B; c.CH_MAX = ch_max < 1 ? 1 : ch_max;
+    c.UL_MAX = fast ? 1 : c.B; c.CH_MAX = ch_max < 1 ? 1 : ch_max;
     c.cpuct = (float)cfg->cpuct;
     c.keep = (float)(1.0 - cfg->dirichlet_epsilon);
     c.eps = cfg->dirichlet_epsilon;
@@ -193,6 +200,15 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
     rc |= e->alloc(&d.root_child_rank, G * 2 * BO_CH_CAP); rc |= e->alloc(&d.noise, G * BO_MAX_MOVES);
     rc |= e->alloc(&d.played, G * c.PLY_CAP);
     rc |= e->alloc(&d.res_idx, G * BO_RES_CAP); rc |= e->alloc(&d.res_val, G * BO_RES_CAP);
+    if (fast) {
+        FastEng &f = e->f;
+        const size_t L = (size_t)cfg->leaves_per_step;
+        f.L = (int)L;
+        rc |= e->alloc(&f.n_rows, G); rc |= e->alloc(&f.n_step_sims, G);
+        rc |= e->alloc(&f.row_leaf, G * L); rc |= e->alloc(&f.row_nlegal, G * L); rc |= e->alloc(&f.row_moves, G * L * BO_MAX_MOVES);
+        rc |= e->alloc(&f.sim_row, G * L); rc |= e->alloc(&f.sim_plen, G * L); rc |= e->alloc(&f.sim_path, G * L * BO_FAST_PATH_CAP);
+        if (!rc) { rt_memset(f.n_rows, 0, G * 4, nullptr); rt_memset(f.n_step_sims, 0, G * 4, nullptr); }
+    }
     if (rc) { bo_engine_destroy(e); return fail(BO_E_HIP, "device allocation failed"); }
     // host-built lookup tables: Python's math.sqrt / int() in double, rounded to binary32 once
     std::vector<float> hs((size_t)c.S + 2);
@@ -312,7 +328,8 @@ extern "C" int bo_search_begin(bo_engine *e, const int32_t *go, const double *no
     if (e->d.c.use_noise && !noise) return fail(BO_E_ARG, "noise required when dirichlet_alpha > 0");
     RT(rt_h2d(e->d_go, go, G * 4, stream));
     if (noise) RT(rt_h2d(e->d.noise, noise, G * BO_MAX_MOVES * sizeof(double), stream));
-    RT(RT_LAUNCH(bo_k_search_begin, e->d.c.G, stream, e->d, (const int *)e->d_go, nn_in_dev));
+    if (e->fast) RT(RT_LAUNCH(bo_k_fast_search_begin, e->d.c.G, stream, e->d, e->f, (const int *)e->d_go, nn_in_dev));
+    else RT(RT_LAUNCH(bo_k_search_begin, e->d.c.G, stream, e->d, (const int *)e->d_go, nn_in_dev));
     return BO_OK;
 }
 
@@ -320,7 +337,8 @@ extern "C" int bo_step(bo_engine *e, const float *policy_dev, const float *value
                        void *stream) {
     if (!e || !nn_in_dev) return fail(BO_E_ARG, "null argument");
     if (policy_kind != BO_POLICY_NONE && (!policy_dev || !value_dev)) return fail(BO_E_ARG, "policy/value required");
-    RT(RT_LAUNCH(bo_k_step, e->d.c.G, stream, e->d, policy_dev, value_dev, policy_kind, nn_in_dev));
+    if (e->fast) RT(RT_LAUNCH(bo_k_fast_step, e->d.c.G, stream, e->d, e->f, policy_dev, value_dev, policy_kind, nn_in_dev));
+    else RT(RT_LAUNCH(bo_k_step, e->d.c.G, stream, e->d, policy_dev, value_dev, policy_kind, nn_in_dev));
     return BO_OK;
 }
 
@@ -347,7 +365,8 @@ extern "C" int bo_search_result(bo_engine *e, int32_t *res_n, int32_t *res_idx, 
                                 int32_t *best_move, int32_t *total_visits, void *stream) {
     if (!e) return fail(BO_E_ARG, "null engine");
     const size_t G = (size_t)e->d.c.G;
-    RT(RT_LAUNCH(bo_k_result, e->d.c.G, stream, e->d));
+    if (e->fast) RT(RT_LAUNCH(bo_k_fast_result, e->d.c.G, stream, e->d));
+    else RT(RT_LAUNCH(bo_k_result, e->d.c.G, stream, e->d));
     if (res_n) RT(rt_d2h(res_n, e->d.res_n, G * 4, stream));
     if (res_idx) RT(rt_d2h(res_idx, e->d.res_idx, G * BO_RES_CAP * 4, stream));
     if (res_val) RT(rt_d2h(res_val, e->d.res_val, G * BO_RES_CAP * 4, stream));
@@ -394,8 +413,10 @@ extern "C" int bo_selfplay_sample(bo_engine *e, const int32_t *active, const int
     const int G = e->d.c.G;
     for (int g = 0; g < G; g++) {
         if (!active[g]) { action_out[g] = -1; continue; }
-        const int a = hr_select_action(&e->rng[g], res_n[g], res_idx + (size_t)g * BO_RES_CAP, res_val + (size_t)g * BO_RES_CAP,
-                                       move_number[g], threshold, t_initial, t_final);
+        const int32_t *ri = res_idx + (size_t)g * BO_RES_CAP;
+        const float *rv = res_val + (size_t)g * BO_RES_CAP;
+        const int a = e->fast ? hr_select_action_general(&e->rng[g], res_n[g], ri, rv, move_number[g], threshold, t_initial, t_final)
+                              : hr_select_action(&e->rng[g], res_n[g], ri, rv, move_number[g], threshold, t_initial, t_final);
         action_out[g] = a >= 0 ? a : -3;  // -3: not sparse enough, the caller samples with the dense NumPy mirror
     }
     return BO_OK;

@@ -154,3 +154,39 @@ static inline int hr_select_action(HostRng *s, int n, const int32_t *idx, const 
     if (n == 1) return i0;
     return (c0 / last > u) ? i0 : i1;
 }
+
+// Same for any number of non-zero entries (FAST search mode: pi over all legal moves).  Entries are processed in
+// action-index order; sums are sequential in double (not NumPy's pairwise order: the fast mode has no NumPy
+// counterpart to be bit-compatible with).  One uniform draw, like RandomState.choice.
+static inline int hr_select_action_general(HostRng *s, int n, const int32_t *idx, const float *val, int move_number,
+                                           int threshold, double t_initial, double t_final) {
+    if (n < 1 || n > 256) return -1;
+    int order[256];
+    for (int i = 0; i < n; i++) {
+        int j = i;
+        while (j > 0 && idx[order[j - 1]] > idx[i]) { order[j] = order[j - 1]; j--; }
+        order[j] = i;
+    }
+    const double temp = move_number < threshold ? t_initial : t_final;
+    double p[256], sum = 0.0;
+    if (temp == 0.0) {
+        int best = 0;
+        for (int i = 1; i < n; i++) if (val[order[i]] > val[order[best]]) best = i;
+        (void)hr_double(s);
+        return idx[order[best]];
+    }
+    for (int i = 0; i < n; i++) {
+        double x = (double)val[order[i]];
+        if (!(fabs(temp - 1.0) < 1e-6)) { x = pow(x, 1.0 / temp); if (!isfinite(x)) x = 0.0; }
+        p[i] = x;
+        sum += x;
+    }
+    if (!(sum > 0.0)) return -1;
+    const double u = hr_double(s);
+    double c = 0.0;
+    for (int i = 0; i < n; i++) {
+        c += p[i] / sum;
+        if (c > u) return idx[order[i]];
+    }
+    return idx[order[n - 1]];
+}

@@ -57,5 +57,9 @@ SAVE_DIR = "checkpoints"
 LOG_DIR = "logs"
 DATA_DIR = "data"
 
-# --- engine sizing (new; no counterpart in the reference) ---
+# --- engine options (new; no counterpart in the reference) ---
+# "reference": BetaOne's own search semantics, bit-exact (default).  "fast": csrc/bo_fast.h -- virtual loss,
+# FAST_LEAVES distinct leaves per game per step, full-width expansion; a different (conventional AlphaZero) search.
+SEARCH_MODE = "reference"
+FAST_LEAVES = 16
 ENGINE_MAX_PLIES = 2048   # capacity of one game's position stack on the GPU

@@ -45,13 +45,15 @@ def _rollout(model, n_slots: int, rng_mode: str = "python") -> Rollout:
     if _test_backend is None and hasattr(model, "for_inference"):  # BN-folded copy in the faster layout for n_slots rows
         from betaone_amd.nn_tune import best_inference_copy
 
-        model = best_inference_copy(model, n_slots, dev, next(model.parameters()).dtype)
+        rows = n_slots * (config.FAST_LEAVES if config.SEARCH_MODE == "fast" else 1)
+        model = best_inference_copy(model, rows, dev, next(model.parameters()).dtype)
     return Rollout(model, n_slots, num_simulations=config.NUM_SIMULATIONS, mcts_batch_size=config.MCTS_BATCH_SIZE,
                    cpuct=config.CPUCT, widen_coeff=config.WIDEN_COEFF, dirichlet_alpha=config.DIRICHLET_ALPHA,
                    dirichlet_epsilon=config.DIRICHLET_EPSILON, max_plies=config.ENGINE_MAX_PLIES,
                    max_game_moves=config.MAX_GAME_MOVES,
                    temperature=(config.TEMPERATURE_THRESHOLD, config.TEMPERATURE_INITIAL, config.TEMPERATURE_FINAL),
-                   device=dev, autocast=config.AUTOCAST, use_graph=_test_backend is None, rng_mode=rng_mode, lib=lib)
+                   device=dev, autocast=config.AUTOCAST, use_graph=_test_backend is None, rng_mode=rng_mode,
+                   fast=config.SEARCH_MODE == "fast", leaves_per_step=config.FAST_LEAVES, lib=lib)
 
 
 def _records(ro: Rollout, fin: FinishedGame) -> List[SelfPlayData]:

@@ -36,7 +36,8 @@ class EngineError(RuntimeError):
 class BoConfig(C.Structure):
     _fields_ = [("n_games", C.c_int32), ("num_simulations", C.c_int32), ("mcts_batch_size", C.c_int32),
                 ("max_plies", C.c_int32), ("cpuct", C.c_double), ("widen_coeff", C.c_double),
-                ("dirichlet_alpha", C.c_double), ("dirichlet_epsilon", C.c_double)]
+                ("dirichlet_alpha", C.c_double), ("dirichlet_epsilon", C.c_double), ("mode", C.c_int32),
+                ("leaves_per_step", C.c_int32)]
 
 
 class BoPosition(C.Structure):
@@ -132,11 +133,14 @@ class Engine:
 
     def __init__(self, n_games: int, num_simulations: int = 250, mcts_batch_size: int = 96, cpuct: float = 1.0,
                  widen_coeff: float = 1.5, dirichlet_alpha: float = 0.1, dirichlet_epsilon: float = 0.25,
-                 max_plies: int = 1024, device: int = 0, lib: Optional[C.CDLL] = None):
+                 max_plies: int = 1024, device: int = 0, lib: Optional[C.CDLL] = None, fast: bool = False,
+                 leaves_per_step: int = 8):
         self.lib = lib if lib is not None else load_hip_library()
         self.G = int(n_games)
+        self.fast, self.L = bool(fast), int(leaves_per_step) if fast else 1
         self.cfg = BoConfig(n_games, num_simulations, mcts_batch_size, max_plies, cpuct, widen_coeff, dirichlet_alpha,
-                            dirichlet_epsilon)
+                            dirichlet_epsilon, 1 if fast else 0, self.L)
+        self.rows = self.G * self.L  # rows of the NN tensors
         self.num_simulations, self.dirichlet_alpha = num_simulations, dirichlet_alpha
         h = C.c_void_p()
         self._check(self.lib.bo_engine_create(C.byref(self.cfg), device, C.byref(h)))

@@ -71,7 +71,8 @@ class Rollout:
                  cpuct: float = 1.0, widen_coeff: float = 1.5, dirichlet_alpha: float = 0.1,
                  dirichlet_epsilon: float = 0.25, max_plies: int = 2048, max_game_moves: int = 16384,
                  temperature=(30, 1.0, 0.1), device: str = "cuda:0", use_graph: bool = True, autocast: bool = False,
-                 rng_mode: str = "python", policy_kind: str = "logits", lib=None):
+                 rng_mode: str = "python", policy_kind: str = "logits", fast: bool = False, leaves_per_step: int = 16,
+                 lib=None):
         if not str(device).startswith("cuda") and lib is None:
             raise E.EngineError("betaone_amd.Rollout runs on an MI355X (device='cuda:N'); there is no CPU path")
         self.device = torch.device(device)
@@ -85,9 +86,11 @@ class Rollout:
         dev_index = self.device.index or 0
         self.eng = E.Engine(self.G, num_simulations=self.S, mcts_batch_size=self.B, cpuct=cpuct, widen_coeff=widen_coeff,
                             dirichlet_alpha=dirichlet_alpha, dirichlet_epsilon=dirichlet_epsilon, max_plies=max_plies,
-                            device=dev_index, lib=lib)
-        self.nn_in = torch.zeros((self.G, E.INPUT_CHANNELS, 8, 8), dtype=torch.float32, device=self.device)
-        self.expected_evals = 1 + math.ceil(self.S / self.B)
+                            device=dev_index, lib=lib, fast=fast, leaves_per_step=leaves_per_step)
+        # fast=True: csrc/bo_fast.h (virtual loss, L leaves per game per step) -- NOT the reference's search semantics
+        self.fast, self.L = bool(fast), self.eng.L
+        self.nn_in = torch.zeros((self.G * self.L, E.INPUT_CHANNELS, 8, 8), dtype=torch.float32, device=self.device)
+        self.expected_evals = 1 + math.ceil(self.S / (self.L if self.fast else self.B))
         self.games: List[Optional[GameState]] = [None] * self.G
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
         self._graph = None

@@ -58,6 +58,10 @@ typedef struct {
     double widen_coeff;         /* config.WIDEN_COEFF (>= 1.0, int(w*sqrt(batch)) <= 32) */
     double dirichlet_alpha;     /* config.DIRICHLET_ALPHA (only its sign is used on the device) */
     double dirichlet_epsilon;   /* config.DIRICHLET_EPSILON */
+    int32_t mode;               /* 0 = the reference's search semantics (bit-exact); 1 = FAST mode (csrc/bo_fast.h):
+                                 * virtual loss, leaves_per_step distinct leaves per game per step, full-width
+                                 * expansion -- NOT the reference's semantics */
+    int32_t leaves_per_step;    /* FAST mode: L; NN tensors then have n_games*L rows, row = g*L + r */
 } bo_config;
 
 /* A position as plain data.  bb: pawns, knights, bishops, rooks, queens, kings, white, black. */

@@ -255,3 +255,59 @@ def test_full_size_config_parity_with_real_net(backend):
                     assert np.float32(rpi[i]).view(np.uint32) == np.float32(v).view(np.uint32)
     finally:
         config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = saved
+
+
+def test_fast_mode_kernels_on_gpu_match_numpy_restatement(backend):
+    """FAST search mode (csrc/bo_fast.h) on the product library: same trees as tests/fast_reference.py, bit for bit."""
+    import test_fast_mode_emu as T
+    from betaone_amd import engine as E
+    from fast_reference import fast_search
+    from oracle import oracle as O
+
+    for fen, moves, sims, L in T.CASES[:3]:
+        fn = T.softmax_eval(7)
+        eng, noise, _ = T.run_engine_search("hip", fen, moves, sims, L, fn, seed=3)
+        got = eng.debug_tree(0)
+        b = O.Board(fen)
+        trk = O.PyTracker(); trk.add_board(b)
+        for u in moves:
+            b.push(u); trk.add_board(b)
+        pos = b.positions()
+        ref = fast_search(b, pos[max(0, len(pos) - 8):-1], trk, fn, noise[0], sims, L)
+        assert len(got) == len(ref)
+        for g, r in zip(got, ref):
+            assert g["n"] == r.n and np.float32(g["q"]).view(np.uint32) == np.float32(r.w).view(np.uint32)
+            assert np.float32(g["prior"]).view(np.uint32) == np.float32(r.prior).view(np.uint32)
+
+
+def test_fast_mode_rollout_on_gpu(backend):
+    import torch
+    from betaone_amd import dropin
+    dropin.install()
+    import config, network
+    from betaone_amd.rollout import Rollout
+
+    saved = (config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS)
+    config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 3, 1, 64
+    try:
+        torch.manual_seed(0)
+        net = network.PolicyValueNet().to("cuda:0").eval().for_inference(channels_last=False)
+        outs = []
+        for use_graph in (True, False):
+            ro = Rollout(net, 8, num_simulations=128, device="cuda:0", use_graph=use_graph, rng_mode="native", fast=True,
+                         leaves_per_step=16, max_game_moves=5)
+            ro.start_games(list(range(8)), list(range(8)), list(range(8)))
+            fins = {}
+            while any(g is not None for g in ro.games):
+                ro.play_ply(on_finished=lambda f: fins.__setitem__(f.game_id, f))
+            ro.eng.check_status()
+            ro.close()
+            assert sorted(fins) == list(range(8))
+            for f in fins.values():
+                assert len(f.moves) == 5
+                for idx, val in f.pis:
+                    assert len(idx) >= 2 and abs(float(val.sum()) - 1.0) < 1e-5   # pi over many root moves, unlike the reference
+            outs.append({k: (v.moves, [i.tolist() for i, _ in v.pis]) for k, v in fins.items()})
+        assert outs[0] == outs[1]
+    finally:
+        config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = saved

@@ -1,0 +1,105 @@
+"""CPU tests of the FAST search mode kernels (csrc/bo_fast.h) under the wave emulator, against the NumPy
+restatement tests/fast_reference.py and against structural invariants."""
+import numpy as np
+import pytest
+
+import engine_cases as EC
+from betaone_amd import engine as E
+from engine_harness import Buf, emu_lib
+from fake_model import fake_logits_values
+from fast_reference import fast_search
+from oracle import oracle as O
+
+
+def softmax_eval(salt, scale=6.0):
+    def fn(planes):
+        logits, v = fake_logits_values(planes, scale, salt)
+        x = logits.astype(np.float64)
+        e = np.exp(x - x.max(axis=1, keepdims=True))
+        return (e / e.sum(axis=1, keepdims=True)).astype(np.float32), v
+    return fn
+
+
+def run_engine_search(backend, fen, moves, sims, L, eval_fn, seed, alpha=0.1, G=1):
+    kw = dict(num_simulations=sims, dirichlet_alpha=alpha, fast=True, leaves_per_step=L, max_plies=256)
+    eng = E.Engine(G, lib=emu_lib(), **kw) if backend == "emu" else E.Engine(G, **kw)
+    eng.reset(list(range(G)), [fen] * G, [" ".join(moves) or None] * G)
+    nl, term, _ = eng.root_info()
+    rngs = [np.random.RandomState(seed + g) for g in range(G)]
+    noise = np.zeros((G, E.MAX_LEGAL))
+    for g in range(G):
+        if term[g] == 0 and alpha > 0:
+            noise[g, :nl[g]] = rngs[g].dirichlet([alpha] * int(nl[g]))
+    nn_in, pol, val = Buf(backend, (G * L, 120, 8, 8)), Buf(backend, (G * L, E.NUM_ACTIONS)), Buf(backend, (G * L,))
+    eng.search_begin([1] * G, noise if alpha > 0 else None, nn_in.ptr)
+    kind, steps = E.POLICY_NONE, 0
+    while True:
+        eng.step(pol.ptr, val.ptr, kind, nn_in.ptr)
+        steps += 1
+        running, _, _ = eng.poll()
+        if not running:
+            break
+        p, v = eval_fn(nn_in.numpy())          # evaluate every row (stale rows are ignored by the engine)
+        pol.set(p); val.set(v)
+        kind = E.POLICY_PROBS
+        assert steps < 10000
+    eng.check_status()
+    return eng, noise, steps
+
+
+CASES = [
+    (O.STARTING_FEN, [], 64, 8),
+    (O.STARTING_FEN, "e2e4 e7e5 g1f3 b8c6 f1b5".split(), 150, 16),
+    ("k7/8/1K6/8/8/8/8/7R w - - 0 1", [], 120, 8),                         # mates in the tree
+    (O.STARTING_FEN, "g1f3 g8f6 f3g1 f6g8 g1f3 g8f6".split(), 100, 4),     # claimable repetitions in the tree
+    ("8/8/4k3/8/8/3K4/8/6R1 w - - 97 80", [], 60, 8),                      # 50-move claims in the tree
+]
+
+
+@pytest.mark.parametrize("fen,moves,sims,L", CASES)
+def test_fast_kernels_match_numpy_restatement(fen, moves, sims, L):
+    fn = softmax_eval(7)
+    eng, noise, _ = run_engine_search("emu", fen, moves, sims, L, fn, seed=3)
+    got = eng.debug_tree(0)
+    b = O.Board(fen)
+    trk = O.PyTracker(); trk.add_board(b)
+    for u in moves:
+        b.push(u); trk.add_board(b)
+    pos = b.positions()
+    ref = fast_search(b, pos[max(0, len(pos) - 8):-1], trk, fn, noise[0], sims, L)
+    assert len(got) == len(ref)
+    for i, (g, r) in enumerate(zip(got, ref)):
+        assert g["n"] == r.n, i
+        assert np.float32(g["q"]).view(np.uint32) == np.float32(r.w).view(np.uint32), (i, g["q"], r.w)
+        assert np.float32(g["prior"]).view(np.uint32) == np.float32(r.prior).view(np.uint32), i
+        assert g["parent"] == r.parent and g["n_children"] == r.nc
+        if i:
+            assert E.move_to_uci(g["move"]) == r.move
+    res = eng.result()
+    root = ref[0]
+    visits = [ref[root.first + i].n for i in range(root.nc)]
+    n = int(res["n"][0])
+    assert n == sum(v > 0 for v in visits) and int(res["total"][0]) == sum(visits) == sims
+    best = int(np.argmax(visits))
+    assert E.move_to_uci(int(res["best_move"][0])) == ref[root.first + best].move
+    assert abs(float(res["val"][0, :n].sum()) - 1.0) < 1e-6
+
+
+def test_fast_mode_invariants_many_games():
+    G, sims, L = 6, 200, 16
+    eng, _, steps = run_engine_search("emu", O.STARTING_FEN, ["d2d4"], sims, L, softmax_eval(11), seed=1, G=G)
+    assert steps <= 2 + (sims + L - 1) // L + 2
+    for g in range(G):
+        t = eng.debug_tree(g)
+        root = t[0]
+        kids = t[root["first_child"]:root["first_child"] + root["n_children"]]
+        assert root["n_children"] == 20 and sum(k["n"] for k in kids) == sims and root["n"] == sims + 1
+        assert abs(sum(float(k["prior"]) for k in kids) - 1.0) < 1e-5
+        for nd in t[1:]:
+            assert nd["n"] >= 0 and abs(float(nd["q"])) <= nd["n"] + 1e-4        # no virtual loss left behind
+            if nd["n_children"]:
+                ch = t[nd["first_child"]:nd["first_child"] + nd["n_children"]]
+                assert nd["n"] == 1 + sum(c["n"] for c in ch)                      # expanded by 1 visit, rest went below
+    # different seeds (noise) -> different games, same seed -> identical
+    a = [tuple((k["n"]) for k in eng.debug_tree(g)[1:21]) for g in range(G)]
+    assert len(set(a)) > 1
