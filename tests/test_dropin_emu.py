@@ -201,3 +201,33 @@ def test_product_paths_refuse_to_run_without_the_gpu():
             mcts.run_mcts(board, FakeNet(scale=0.0), history, tracker)
         with pytest.raises(E.EngineError):
             self_play.run_self_play_game(FakeNet(scale=0.0), 0)
+
+
+def test_selfplay_orchestration_writes_reference_pickles_and_resumes(tmp_path):
+    """betaone_amd/selfplay_main.py (row f4): one iteration's games -> DATA_DIR/iter_i/game_j.pkl in the reference's
+    format (train.py:196-217 expects a non-empty list per file); a second call skips what is on disk (main.py:26-36)."""
+    import pickle
+    from betaone_amd import selfplay_main as M
+
+    config.NUM_SIMULATIONS, config.MCTS_BATCH_SIZE, config.MAX_GAME_MOVES = 30, 16, 4
+    config.DATA_DIR = str(tmp_path / "data")
+    model = FakeNet(scale=0.0, salt=2)
+    logs = []
+    done = M.run_iteration(model, 7, n_games=5, n_slots=3, log=logs.append)
+    assert sorted(done) == [0, 1, 2, 3, 4] and all(v == 4 for v in done.values())
+    for j in range(5):
+        data = pickle.load(open(tmp_path / "data" / "iter_7" / f"game_{j}.pkl", "rb"))
+        assert isinstance(data, list) and len(data) == 4
+        st, pi, z = data[0]
+        assert isinstance(st, torch.Tensor) and tuple(st.shape) == (120, 8, 8) and pi.shape == (4672,) and isinstance(z, float)
+    os.remove(tmp_path / "data" / "iter_7" / "game_3.pkl")
+    assert M.pending_game_ids(config.DATA_DIR, 7, 5) == [3]
+    again = M.run_iteration(model, 7, n_games=5, n_slots=3, log=logs.append)
+    assert sorted(again) == [3]
+    # sharding: rank 1 of 2 plays the odd ids only, with the same per-game seeds
+    config.DATA_DIR = str(tmp_path / "data2")
+    odd = M.run_iteration(model, 7, n_games=5, n_slots=3, rank=1, world=2, log=logs.append)
+    assert sorted(odd) == [1, 3]
+    a = pickle.load(open(tmp_path / "data" / "iter_7" / "game_1.pkl", "rb"))
+    b = pickle.load(open(tmp_path / "data2" / "iter_7" / "game_1.pkl", "rb"))
+    assert all(torch.equal(x[0], y[0]) and np.array_equal(x[1], y[1]) for x, y in zip(a, b))
