@@ -245,3 +245,34 @@ def check_multi_game_vs_oracle(backend, n_games=5, plies=6, sims=60, batch=16, s
             assert np.array_equal(pi.view(np.uint32), gpi.view(np.uint32))
             assert np.array_equal(st, gst)
             assert z == gz
+
+
+def check_full_games_vs_oracle(backend, n_games=4, sims=12, batch=8, scale=4.0, max_game_moves=400):
+    from fake_model import fake_logits_values
+
+    def eval_fn_for(salt):
+        def fn(planes):
+            logits, v = fake_logits_values(planes, scale, salt)
+            x = logits.astype(np.float64)
+            e = np.exp(x - x.max(axis=1, keepdims=True))
+            return (e / e.sum(axis=1, keepdims=True)).astype(np.float32), v
+        return fn
+
+    cfg = dict(num_simulations=sims, batch_size=batch, max_game_moves=max_game_moves)
+    eng = make_engine(backend, n_games, cfg, max_plies=max_game_moves + 8)
+    eng.reset(list(range(n_games)))
+    fns = [eval_fn_for(500 + g) for g in range(n_games)]
+    got = play_games(backend, eng, fns, [np.random.RandomState(100 + g) for g in range(n_games)], 0.1, max_game_moves)
+    ocfg = O.default_config(**cfg)
+    lengths = []
+    for g in range(n_games):
+        ref = O.self_play(fns[g], np.random.RandomState(100 + g), ocfg)
+        assert [O.move_to_uci(m) for m in ref["moves"]] == got[g]["moves"], g
+        assert ref["outcome"] == got[g]["outcome"]
+        for (st, pi, z), gpi, gst, gz in zip(ref["records"], got[g]["pis"], got[g]["states"], got[g]["z"]):
+            assert np.array_equal(pi.view(np.uint32), gpi.view(np.uint32))
+            assert np.array_equal(st, gst)
+            assert z == gz and np.signbit(z) == np.signbit(gz)
+        lengths.append((len(ref["moves"]), ref["termination"]))
+    assert all(l > 20 for l, _ in lengths), lengths
+    return lengths

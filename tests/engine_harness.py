@@ -22,6 +22,8 @@ _emu = None
 
 def emu_lib():
     global _emu
+    if _emu is None and os.environ.get("BO_EMU_LIB"):  # e.g. an AddressSanitizer build (tests/wave_emulator/README)
+        _emu = E.bind(C.CDLL(os.environ["BO_EMU_LIB"]))
     if _emu is None:
         srcs = [os.path.join(ROOT, "betaone_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "betaone_amd", "csrc"))
                 if f.endswith((".h", ".cpp"))] + [os.path.join(EMU_DIR, "wave_emu.h"),

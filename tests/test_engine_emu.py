@@ -33,3 +33,9 @@ def test_self_play_game_matches_reference(backend, name):
 
 def test_many_games_in_lockstep_match_oracle(backend):
     EC.check_multi_game_vs_oracle(backend, n_games=5, plies=6, sims=60, batch=16)
+
+
+def test_full_games_to_termination_match_oracle(backend):
+    """Whole games until is_game_over(claim_draw=True): long-game logic (claimable draws in the REAL game, tracker and
+    position-stack growth, end-of-game tracker in the training encodings) against the oracle."""
+    EC.check_full_games_vs_oracle(backend, n_games=4, sims=12, batch=8)

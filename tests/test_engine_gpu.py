@@ -311,3 +311,8 @@ def test_fast_mode_rollout_on_gpu(backend):
         assert outs[0] == outs[1]
     finally:
         config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = saved
+
+
+def test_full_games_to_termination_match_oracle(backend):
+    lengths = EC.check_full_games_vs_oracle(backend, n_games=12, sims=24, batch=8)
+    assert any(t != 0 for _, t in lengths)  # at least one game actually ended by the rules
