@@ -10,7 +10,7 @@ dev = "cuda:0"
 flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
 for n_trees in [int(x) for x in (sys.argv[1:] or ["32768", "131072"])]:
     w = SW.build(n_trees, 800, seed=0, device=dev)
-    for grid in (0, 16384, (1 << 20), (1 << 20) + 16384, (2 << 20), (2 << 20) + 8192, (3 << 20), (3 << 20) + 16384):
+    for grid in (0, 4096, 8192, 12288, 16384, 32768):
         out = SW.run(w, grid_blocks=grid)
         torch.cuda.synchronize()
         levels = int(out[1].sum().item())
