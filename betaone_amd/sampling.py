@@ -23,56 +23,49 @@ NUM_ACTIONS = 4672
 
 
 def apply_temperature(probs: np.ndarray, temperature: float, rng=np.random) -> np.ndarray:
-    """self_play.py:25-56, literal."""
+    """self_play.py:25-56: the same NumPy operations in the same order (argmax one-hot for T == 0, identity for
+    T == 1, otherwise p**(1/T) in float64, non-finite -> 0, normalise, cast to float32, re-normalise if the
+    float32 sum is off by more than 1e-6; uniform over the support when everything underflowed)."""
     if temperature == 0:
-        new_probs = np.zeros_like(probs)
-        max_prob_indices = np.where(probs == np.max(probs))[0]
-        if len(max_prob_indices) == 0:
-            return new_probs
-        chosen_index = rng.choice(max_prob_indices)
-        new_probs[chosen_index] = 1.0
-        return new_probs
-    elif abs(temperature - 1.0) < 1e-6:
+        onehot = np.zeros_like(probs)
+        ties = np.where(probs == np.max(probs))[0]
+        if len(ties):
+            onehot[rng.choice(ties)] = 1.0
+        return onehot
+    if abs(temperature - 1.0) < 1e-6:
         return probs
-    else:
-        with np.errstate(divide="ignore", invalid="ignore"):
-            scaled_probs = np.power(probs.astype(np.float64), 1.0 / temperature)
-        scaled_probs[~np.isfinite(scaled_probs)] = 0.0
-        sum_scaled_probs = np.sum(scaled_probs)
-        if sum_scaled_probs > 1e-9:
-            normalized_probs = (scaled_probs / sum_scaled_probs).astype(np.float32)
-            renorm_sum = np.sum(normalized_probs)
-            if abs(renorm_sum - 1.0) > 1e-6 and renorm_sum > 1e-9:
-                normalized_probs /= renorm_sum
-            return normalized_probs
-        else:
-            non_zero_indices = np.where(probs > 1e-9)[0]
-            num_non_zero = len(non_zero_indices)
-            if num_non_zero > 0:
-                uniform_probs = np.zeros_like(probs, dtype=np.float32)
-                uniform_probs[non_zero_indices] = 1.0 / num_non_zero
-                return uniform_probs
-            else:
-                return probs.astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        powered = np.power(probs.astype(np.float64), 1.0 / temperature)
+    powered[~np.isfinite(powered)] = 0.0
+    total = np.sum(powered)
+    if total > 1e-9:
+        out = (powered / total).astype(np.float32)
+        check = np.sum(out)
+        if abs(check - 1.0) > 1e-6 and check > 1e-9:
+            out /= check
+        return out
+    support = np.where(probs > 1e-9)[0]
+    if len(support) == 0:
+        return probs.astype(np.float32)
+    flat = np.zeros_like(probs, dtype=np.float32)
+    flat[support] = 1.0 / len(support)
+    return flat
 
 
 def select_move_with_temperature(probs: np.ndarray, move_number: int, rng=np.random, threshold: int = 30,
                                  t_initial: float = 1.0, t_final: float = 0.1) -> int:
-    """self_play.py:59-80, literal (dense)."""
-    temp = t_initial if move_number < threshold else t_final
-    temp_scaled_probs = apply_temperature(probs, temp, rng)
+    """self_play.py:59-80 (dense): temperature by full-move number, one legacy `choice` draw, argmax fallbacks."""
+    p = apply_temperature(probs, t_initial if move_number < threshold else t_final, rng)
     try:
-        prob_sum = np.sum(temp_scaled_probs)
-        if abs(prob_sum - 1.0) > 1e-6:
-            if prob_sum > 1e-9:
-                temp_scaled_probs /= prob_sum
-            else:
+        mass = np.sum(p)
+        if abs(mass - 1.0) > 1e-6:
+            if not mass > 1e-9:
                 return int(np.argmax(probs))
-        action_index = rng.choice(len(temp_scaled_probs), p=temp_scaled_probs)
-    except ValueError as e:
-        print(f"Error sampling move: {e}\nFalling back to argmax of original probabilities.")
-        action_index = np.argmax(probs)
-    return int(action_index)
+            p /= mass
+        return int(rng.choice(len(p), p=p))
+    except ValueError as err:
+        print(f"Error sampling move: {err}; falling back to the most visited move")
+        return int(np.argmax(probs))
 
 
 def dense_pi(idx: np.ndarray, val: np.ndarray) -> np.ndarray:

@@ -331,53 +331,47 @@ def np_sum_f32(a: np.ndarray) -> np.float32:
 # the process-global legacy RNG the reference uses).
 # ---------------------------------------------------------------------------------------------
 def apply_temperature(probs: np.ndarray, temperature: float, rng) -> np.ndarray:
+    """self_play.py:25-56 restated (same NumPy calls, same order)."""
     if temperature == 0:
-        new_probs = np.zeros_like(probs)
-        max_prob_indices = np.where(probs == np.max(probs))[0]
-        if len(max_prob_indices) == 0:
-            return new_probs
-        chosen_index = rng.choice(max_prob_indices)
-        new_probs[chosen_index] = 1.0
-        return new_probs
-    elif abs(temperature - 1.0) < 1e-6:
+        res = np.zeros_like(probs)
+        where_max = np.where(probs == np.max(probs))[0]
+        if len(where_max) > 0:
+            res[rng.choice(where_max)] = 1.0
+        return res
+    if abs(temperature - 1.0) < 1e-6:
         return probs
-    else:
-        with np.errstate(divide="ignore", invalid="ignore"):
-            scaled_probs = np.power(probs.astype(np.float64), 1.0 / temperature)
-        scaled_probs[~np.isfinite(scaled_probs)] = 0.0
-        sum_scaled_probs = np.sum(scaled_probs)
-        if sum_scaled_probs > 1e-9:
-            normalized_probs = (scaled_probs / sum_scaled_probs).astype(np.float32)
-            renorm_sum = np.sum(normalized_probs)
-            if abs(renorm_sum - 1.0) > 1e-6 and renorm_sum > 1e-9:
-                normalized_probs /= renorm_sum
-            return normalized_probs
-        else:
-            non_zero_indices = np.where(probs > 1e-9)[0]
-            num_non_zero = len(non_zero_indices)
-            if num_non_zero > 0:
-                uniform_probs = np.zeros_like(probs, dtype=np.float32)
-                uniform_probs[non_zero_indices] = 1.0 / num_non_zero
-                return uniform_probs
-            else:
-                return probs.astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        x = np.power(probs.astype(np.float64), 1.0 / temperature)
+    x[~np.isfinite(x)] = 0.0
+    sx = np.sum(x)
+    if not sx > 1e-9:
+        nz = np.where(probs > 1e-9)[0]
+        if len(nz) > 0:
+            u = np.zeros_like(probs, dtype=np.float32)
+            u[nz] = 1.0 / len(nz)
+            return u
+        return probs.astype(np.float32)
+    y = (x / sx).astype(np.float32)
+    sy = np.sum(y)
+    if abs(sy - 1.0) > 1e-6 and sy > 1e-9:
+        y /= sy
+    return y
 
 
 def select_move_with_temperature(probs: np.ndarray, move_number: int, rng, threshold=30, t_init=1.0,
                                  t_final=0.1) -> int:
-    temp = t_init if move_number < threshold else t_final
-    temp_scaled_probs = apply_temperature(probs, temp, rng)
+    """self_play.py:59-80 restated."""
+    scaled = apply_temperature(probs, t_init if move_number < threshold else t_final, rng)
     try:
-        prob_sum = np.sum(temp_scaled_probs)
-        if abs(prob_sum - 1.0) > 1e-6:
-            if prob_sum > 1e-9:
-                temp_scaled_probs /= prob_sum
+        tot = np.sum(scaled)
+        if abs(tot - 1.0) > 1e-6:
+            if tot > 1e-9:
+                scaled /= tot
             else:
                 return int(np.argmax(probs))
-        action_index = rng.choice(len(temp_scaled_probs), p=temp_scaled_probs)
+        return int(rng.choice(len(scaled), p=scaled))
     except ValueError:
-        action_index = np.argmax(probs)
-    return int(action_index)
+        return int(np.argmax(probs))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""scripts/uci_latency.py -- BASELINE.json configs[3]: single-position analysis through the drop-in run_mcts
+"""tests/uci_latency.py -- BASELINE.json configs[3]: single-position analysis through the drop-in run_mcts
 (the call uci.py makes, uci.py:63,84): 1600 sims/move, 20-block x 256 net, one MI355X, hipGraph on."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
