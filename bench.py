@@ -203,11 +203,14 @@ def main():
     ids = [rank + world * s for s in range(G)]  # game id -> rank = id mod world; RandomState(seed = game id) streams
     ro.start_games(list(range(G)), ids, ids)
     next_id = [rank + world * G]
-    finished_batch, n_finished = [], [0]
+    finished_batch, n_finished, finished_timed, plies_finished, timing = [], [0], [0], [0], [False]
 
     def on_finished(fin):
         finished_batch.append(fin)
         n_finished[0] += 1
+        if timing[0]:
+            finished_timed[0] += 1
+            plies_finished[0] += len(fin.moves)
 
     def refill(_slot):
         i = next_id[0]
@@ -226,6 +229,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(device)
     s0, p0, f0, h0 = ro.n_sims, ro.n_plies, ro.n_forward, ro.host_seconds
+    timing[0] = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
@@ -262,6 +266,8 @@ def main():
             "plies_per_sec": round(plies / dt, 2), "nn_forwards_per_sec": round(fwd / dt / world, 2),
             "unique_nn_evals_per_sec": round(fwd * G * (args.leaves if args.fast else 1) / dt, 1), "games_finished": n_finished[0],
             "games_per_hour_at_100_plies": round(plies / dt * 3600 / 100.0, 1),
+            "games_per_hour_measured": (round(finished_timed[0] * world * 3600.0 / dt, 1) if finished_timed[0] else None),
+            "mean_plies_of_finished_games": (round(plies_finished[0] / finished_timed[0], 1) if finished_timed[0] else None),
             "host_fraction": round((ro.host_seconds - h0) / dt, 4),
         }
     if rank == 0 and not args.no_roofline:

@@ -178,6 +178,7 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
     c.eps = cfg->dirichlet_epsilon;
     c.use_noise = cfg->dirichlet_alpha > 0 ? 1 : 0;
     c.root_m = root_m;
+    c.profile = 0;
     const size_t G = (size_t)c.G, N = G * (size_t)c.NCAP;
     Eng &d = e->d;
     int rc = 0;
@@ -200,6 +201,7 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
     rc |= e->alloc(&d.root_child_rank, G * 2 * BO_CH_CAP); rc |= e->alloc(&d.noise, G * BO_MAX_MOVES);
     rc |= e->alloc(&d.played, G * c.PLY_CAP);
     rc |= e->alloc(&d.res_idx, G * BO_RES_CAP); rc |= e->alloc(&d.res_val, G * BO_RES_CAP);
+    rc |= e->alloc(&d.prof, G * 8);
     if (fast) {
         FastEng &f = e->f;
         const size_t L = (size_t)cfg->leaves_per_step;
@@ -523,6 +525,20 @@ extern "C" int bo_engine_status(bo_engine *e, int32_t *status, int32_t *evals, i
     if (levels) RT(rt_d2h(levels, e->d.stat_levels, G * 4, stream));
     if (children_scanned) RT(rt_d2h(children_scanned, e->d.stat_children_scanned, G * 4, stream));
     RT(rt_sync(stream));
+    return BO_OK;
+}
+
+extern "C" int bo_debug_profile(bo_engine *e, int enable, uint64_t *cycles_out, void *stream) {
+    if (!e) return fail(BO_E_ARG, "null engine");
+    const size_t G = (size_t)e->d.c.G;
+    if (cycles_out) {
+        RT(rt_d2h(cycles_out, e->d.prof, G * 8 * sizeof(uint64_t), stream));
+        RT(rt_sync(stream));
+    }
+    if (enable >= 0) {
+        if (enable && !e->d.c.profile) RT(rt_memset(e->d.prof, 0, G * 8 * sizeof(uint64_t), stream));
+        e->d.c.profile = enable ? 1 : 0;
+    }
     return BO_OK;
 }
 

@@ -90,7 +90,7 @@ BO_KERNEL void bo_k_fast_step(Eng e, FastEng f, const float *policy, const float
                 float mx = -__builtin_inff();
                 for (int j = lane; j < n; j += 64) { float x = prow[move_to_index(mv[j])]; sh.pv[j] = x; mx = x > mx ? x : mx; }
                 mx = bo_wave_max_f(mx);
-                for (int j = lane; j < n; j += 64) sh.pv[j] = expf(sh.pv[j] - mx);
+                for (int j = lane; j < n; j += 64) sh.pv[j] = bo_expf(sh.pv[j] - mx);
             }
             bo_sync();
             const float sum = fast_sum(sh.pv, n);

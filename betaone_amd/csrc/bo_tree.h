@@ -46,6 +46,7 @@ struct EngCfg {
     double eps;                  // DIRICHLET_EPSILON
     int use_noise;               // DIRICHLET_ALPHA > 0
     int root_m;                  // children admitted by one root expand call: int(WIDEN*sqrt(1))
+    int profile;                 // bo_debug_profile: accumulate per-phase shader cycles (s_memtime) per game
 };
 
 struct Eng {
@@ -79,9 +80,41 @@ struct Eng {
     // search results
     int *res_n, *res_idx, *res_best_idx, *res_best_mv, *res_total;
     float *res_val;
+    unsigned long long *prof;         // [G][8] cycles: apply, select, first-visit (movegen+draw rules), terminal backups, encode, flush, total, steps
 };
 
 #define NOFF(e, g) ((size_t)(g) * (size_t)(e).c.NCAP)
+
+// exp for the policy softmax: the hardware v_exp_f32 (exp2) path on gfx950, libm in the emulator build.  The
+// in-kernel softmax (policy_kind LOGITS) is held to the north-star tolerance (1e-4), not to bit-equality.
+BO_DEV float bo_expf(float x) {
+#if defined(BO_WAVE_EMU)
+    return expf(x);
+#else
+    return __expf(x);
+#endif
+}
+struct bo_f4 { float x, y, z, w; };
+// max and sum(exp(x - max)) over one 4672-float policy row: 16-byte loads, 1168 float4 over 64 lanes
+BO_DEV void row_max_sum(const float *row, float *mx_out, float *sum_out) {
+    const bo_f4 *r4 = reinterpret_cast<const bo_f4 *>(row);
+    const int lane = bo_lane();
+    float mx = -__builtin_inff();
+    for (int k = lane; k < BO_NUM_ACTIONS / 4; k += 64) {
+        const bo_f4 v = r4[k];
+        const float a = v.x > v.y ? v.x : v.y, b = v.z > v.w ? v.z : v.w;
+        const float c = a > b ? a : b;
+        mx = c > mx ? c : mx;
+    }
+    mx = bo_wave_max_f(mx);
+    float sum = 0.0f;
+    for (int k = lane; k < BO_NUM_ACTIONS / 4; k += 64) {
+        const bo_f4 v = r4[k];
+        sum += (bo_expf(v.x - mx) + bo_expf(v.y - mx)) + (bo_expf(v.z - mx) + bo_expf(v.w - mx));
+    }
+    *mx_out = mx;
+    *sum_out = bo_wave_sum_f(sum);
+}
 
 BO_DEV int bo_uniform(int v) {
 #if defined(BO_WAVE_EMU)
@@ -204,10 +237,11 @@ BO_DEV void encode_leaf(const Eng &e, int g, float *row, const DPos &P) {
 }
 
 // MCTSNode.select_child repeated down to a leaf (mcts.py:218-230, 72-118)
-BO_DEV int select_leaf(const Eng &e, int g, int *flags) {
+BO_DEV int select_leaf(const Eng &e, int g, int *flags, int *path, int *depth_out) {
     const size_t no = NOFF(e, g);
     const int lane = bo_lane();
     int cur = 0, levels = 0, scanned = 0;
+    if (lane == 0) path[0] = 0;
     for (;;) {
         const int nc = e.n_children[no + cur];
         if (nc == 0) break;
@@ -229,19 +263,108 @@ BO_DEV int select_leaf(const Eng &e, int g, int *flags) {
             if (!(score == score)) score = -__builtin_inff();  // NaN never wins `score > best`
         }
         int bi = lane;
-        for (int m = 1; m < 64; m <<= 1) {
+        for (int m = 1; m < nc; m <<= 1) {  // lanes >= nc hold -inf: log2(next pow2 of nc) butterfly steps reach lane 0
             float os = bo_shfl_xor_f(score, m);
             int oi = bo_shfl_xor(bi, m);
             if (os > score || (os == score && oi < bi)) { score = os; bi = oi; }
         }
+        score = bo_shfl_f(score, 0);
+        bi = bo_shfl(bi, 0);
         if (!(score > -__builtin_inff())) { *flags |= ST_NAN_SCORE; bi = 0; }  // reference: random.choice
         cur = bo_uniform(fc + bi);
         levels++;
+        if (lane == 0) path[levels] = cur;
         scanned += nc;
         if (levels >= BO_PATH_CAP - 1) { *flags |= ST_DEPTH_OVERFLOW; break; }
     }
     if (lane == 0) { e.stat_levels[g] += levels; e.stat_children_scanned[g] += scanned; }
+    *depth_out = levels;
+    bo_sync();
     return cur;
+}
+
+// Repeated terminal simulations (mcts.py:235-238) without memory round trips.  A terminal leaf absorbs a simulation,
+// its path is updated, and the next descent very often ends in the same leaf (a mating move, a claimable draw): in
+// late games a search can spend hundreds of simulations this way, one dependent-load chain each.  Here the children
+// of every node on the path (<= 4 levels x <= 16 children) are held in registers, 16 lanes per level: each
+// simulation is applied to them in the reference's order of operations, the descent is re-evaluated from the
+// registers, and as long as it reproduces the same path the loop continues.  Returns the number of simulations
+// applied (>= 1); the caller re-selects from memory afterwards.  Bit-identical to backup_run + select_leaf.
+#define BO_BURST_LEVELS 4
+BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, int sims_left) {
+    const size_t no = NOFF(e, g);
+    const int lane = bo_lane(), grp = lane >> 4, j = lane & 15;
+    // uniform copies of the path nodes' visit counts and (for the root) q
+    int nv[BO_BURST_LEVELS + 1];
+    int fc[BO_BURST_LEVELS], ncs[BO_BURST_LEVELS], chosen[BO_BURST_LEVELS];
+#pragma unroll
+    for (int k = 0; k <= BO_BURST_LEVELS; k++) nv[k] = k <= d ? e.n_visits[no + path[k]] : 0;
+#pragma unroll
+    for (int k = 0; k < BO_BURST_LEVELS; k++) {
+        fc[k] = k < d ? e.first_child[no + path[k]] : 0;
+        ncs[k] = k < d ? e.n_children[no + path[k]] : 0;
+        chosen[k] = k < d ? path[k + 1] - fc[k] : -1;
+    }
+    float rootq = e.q[no];
+    // this lane's child: group = level, j = child index
+    int my_fc = 0, my_nc = 0, my_chosen = -1;
+#pragma unroll
+    for (int k = 0; k < BO_BURST_LEVELS; k++)
+        if (grp == k) { my_fc = fc[k]; my_nc = ncs[k]; my_chosen = chosen[k]; }
+    const bool have = grp < d && j < my_nc;
+    int cn = have ? e.n_visits[no + my_fc + j] : 0;
+    float cq = have ? e.q[no + my_fc + j] : 0.0f;
+    const float cp = have ? e.prior[no + my_fc + j] : 0.0f;
+    // value seen by path node k: leaf gets v, its parent -v, ...
+    const float my_val = ((d - (grp + 1)) & 1) ? -v : v;   // for the chosen child of level grp == path node grp+1
+    const float root_val = (d & 1) ? -v : v;
+    int done = 0;
+    for (;;) {
+        // ---- apply one terminal simulation (MCTSNode.update along the path, mcts.py:120-144) ----
+        if (have && j == my_chosen) {
+            cn += 1;
+            const float dd = my_val - cq;
+            const float ee = dd / (float)cn;
+            cq = cq + ee;
+        }
+#pragma unroll
+        for (int k = 0; k <= BO_BURST_LEVELS; k++) nv[k] += k <= d ? 1 : 0;
+        {
+            const float dd = root_val - rootq;
+            const float ee = dd / (float)nv[0];
+            rootq = rootq + ee;
+        }
+        done++;
+        if (done >= sims_left) break;
+        // ---- re-evaluate the descent from the registers (select_child at every level of the path) ----
+        int pv = nv[0];
+#pragma unroll
+        for (int k = 1; k < BO_BURST_LEVELS; k++)
+            if (grp == k) pv = nv[k - 1];
+        const float sp = e.sqrt_lut[pv];
+        float score = -__builtin_inff();
+        if (have) {
+            const float t1 = e.c.cpuct * cp;
+            const float t2 = t1 * sp;
+            float qv = 0.0f, u = t2;
+            if (cn > 0) { qv = cq; u = t2 / (float)(1 + cn); }
+            score = qv + u;
+            if (!(score == score)) score = -__builtin_inff();
+        }
+        int bi = j;
+        for (int m = 1; m < 16; m <<= 1) {
+            const float os = bo_shfl_xor_f(score, m);
+            const int oi = bo_shfl_xor(bi, m);
+            if (os > score || (os == score && oi < bi)) { score = os; bi = oi; }
+        }
+        const bool level_ok = !(grp < d) || (bi == my_chosen && score > -__builtin_inff());
+        if (bo_ballot(!level_ok) != 0) break;  // the next descent leaves this path: back to the general loop
+    }
+    // ---- write the path back ----
+    if (have && j == my_chosen) { e.n_visits[no + my_fc + j] = cn; e.q[no + my_fc + j] = cq; }
+    if (lane == 0) { e.n_visits[no] = nv[0]; e.q[no] = rootq; }
+    bo_sync();
+    return done;
 }
 
 // MCTSNode.update_recursive applied `cnt` times with the same leaf value (mcts.py:120-144)
@@ -349,6 +472,7 @@ struct StepShared {
     bo_mv moves2[BO_MAX_MOVES];
     float pv[BO_MAX_MOVES];
     int path[BO_PATH_CAP];
+    int path2[BO_PATH_CAP];
     float probs[BO_NUM_ACTIONS];
     int rank_of[2 * BO_CH_CAP];
 };
@@ -359,13 +483,9 @@ BO_DEV void load_probs(const float *row, int kind, float *out) {
     if (kind == POLICY_PROBS) {
         for (int i = lane; i < BO_NUM_ACTIONS; i += 64) out[i] = row[i];
     } else {
-        float mx = -__builtin_inff();
-        for (int i = lane; i < BO_NUM_ACTIONS; i += 64) { float x = row[i]; mx = x > mx ? x : mx; }
-        mx = bo_wave_max_f(mx);
-        float sum = 0.0f;
-        for (int i = lane; i < BO_NUM_ACTIONS; i += 64) { float ex = expf(row[i] - mx); out[i] = ex; sum += ex; }
-        sum = bo_wave_sum_f(sum);
-        for (int i = lane; i < BO_NUM_ACTIONS; i += 64) out[i] = out[i] / sum;
+        float mx, sum;
+        row_max_sum(row, &mx, &sum);
+        for (int i = lane; i < BO_NUM_ACTIONS; i += 64) out[i] = bo_expf(row[i] - mx) / sum;
     }
     bo_sync();
 }
@@ -444,13 +564,9 @@ BO_DEV void apply_leaf(const Eng &e, int g, int leaf, const float *row, int kind
     if (kind == POLICY_PROBS) {
         for (int j = lane; j < n; j += 64) sh.pv[j] = row[move_to_index(mv[j])];
     } else {  // softmax restricted to what is needed: max and sum over the row, exp at the legal indices
-        float mx = -__builtin_inff();
-        for (int i = lane; i < BO_NUM_ACTIONS; i += 64) { float x = row[i]; mx = x > mx ? x : mx; }
-        mx = bo_wave_max_f(mx);
-        float sum = 0.0f;
-        for (int i = lane; i < BO_NUM_ACTIONS; i += 64) sum += expf(row[i] - mx);
-        sum = bo_wave_sum_f(sum);
-        for (int j = lane; j < n; j += 64) sh.pv[j] = expf(row[move_to_index(mv[j])] - mx) / sum;
+        float mx, sum;
+        row_max_sum(row, &mx, &sum);
+        for (int j = lane; j < n; j += 64) sh.pv[j] = bo_expf(row[move_to_index(mv[j])] - mx) / sum;
     }
     bo_sync();
     const int M = n < e.c.CH_MAX ? n : e.c.CH_MAX;
@@ -485,20 +601,30 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
     int *rl = e.run_leaf + (size_t)g * e.c.B, *rc = e.run_cnt + (size_t)g * e.c.B;
     float *row = nn_in + (size_t)g * BO_ROW;
 
+    const bool prof = e.c.profile != 0;
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tk = prof ? bo_clock() : 0ull;
+    const unsigned long long t_start = tk;
+#define BO_PROF(slot)                                                    \
+    if (prof) { const unsigned long long _n = bo_clock(); pc[slot] += _n - tk; tk = _n; }
     if (req >= 0) {
         if (kind == POLICY_NONE) return;  // evaluation still outstanding
         if (req == 0) apply_root(e, g, policy + (size_t)g * BO_NUM_ACTIONS, kind, sh, &n_nodes, &flags);
         else apply_leaf(e, g, req, policy + (size_t)g * BO_NUM_ACTIONS, kind, value[g], sh, &n_ul, &flags);
         req = -1;
     }
+    BO_PROF(0)
     int phase = PH_RUN;
     for (;;) {
         if (sims >= e.c.S) {  // mcts.py:256-257
             if (rows > 0) { flush_pending(e, g, n_runs, n_ul, &n_nodes, sh.path, &flags); rows = n_runs = n_ul = 0; }
+            BO_PROF(5)
             phase = PH_DONE;
             break;
         }
-        const int leaf = select_leaf(e, g, &flags);
+        int depth;
+        const int leaf = select_leaf(e, g, &flags, sh.path, &depth);
+        BO_PROF(1)
         int t = e.term[no + leaf];
         if (t < 0) {  // first visit: legal moves + is_terminal()  (mcts.py:235, cached per node)
             const DPos P = e.npos[no + leaf];
@@ -511,17 +637,25 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
                 if (lane == 0) e.req_nlegal[g] = n;
             }
             bo_sync();
+            BO_PROF(2)
         }
         if (t > 0) {  // mcts.py:235-238: terminal leaves absorb the simulation, no NN row
-            backup_run(e, g, leaf, t == 1 ? 1.0f : 0.0f, 1, sh.path, &flags);
-            sims++;
-            if (lane == 0) e.stat_term_sims[g] += 1;
+            const float tv = t == 1 ? 1.0f : 0.0f;
+            int applied = 1;
+            bool small = depth <= BO_BURST_LEVELS;
+            for (int k = 0; k < depth && small; k++) small = e.n_children[no + sh.path[k]] <= 16;
+            if (small) applied = terminal_burst(e, g, sh.path, depth, tv, e.c.S - sims);
+            else backup_run(e, g, leaf, tv, 1, sh.path2, &flags);
+            sims += applied;
+            if (lane == 0) e.stat_term_sims[g] += applied;
+            BO_PROF(3)
             continue;
         }
         if (e.eval_slot[no + leaf] < 0) {  // needs the net: emit planes 98..119 into row g and pause
             encode_leaf(e, g, row, e.npos[no + leaf]);
             req = leaf;
             if (lane == 0) e.stat_evals[g] += 1;
+            BO_PROF(4)
             break;
         }
         // mcts.py:247-254: until the next flush nothing changes, so every remaining row of this batch
@@ -534,6 +668,14 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
         sims += cnt;
         bo_sync();
         if (rows >= e.c.B) { flush_pending(e, g, n_runs, n_ul, &n_nodes, sh.path, &flags); rows = n_runs = n_ul = 0; }
+        BO_PROF(5)
+    }
+#undef BO_PROF
+    if (prof && lane == 0) {
+        unsigned long long *pp = e.prof + (size_t)g * 8;
+        for (int i = 0; i < 6; i++) pp[i] += pc[i];
+        pp[6] += bo_clock() - t_start;
+        pp[7] += 1;
     }
     if (lane == 0) {
         e.sims_done[g] = sims; e.rows[g] = rows; e.n_runs[g] = n_runs; e.n_ul[g] = n_ul; e.n_nodes[g] = n_nodes;

@@ -31,6 +31,7 @@ BO_DEV int bo_shfl_up(int v, int d) { return __shfl_up(v, d, 64); }
 BO_DEV int bo_atomic_add(int *p, int v) { return atomicAdd(p, v); }
 BO_DEV int bo_atomic_or(int *p, int v) { return atomicOr(p, v); }
 BO_DEV uint64_t bo_bitrev64(uint64_t x) { return __builtin_bitreverse64(x); }
+BO_DEV unsigned long long bo_clock() { return (unsigned long long)clock64(); }
 #endif
 
 // ---- derived primitives (identical in both builds) ---------------------------------------------

@@ -78,6 +78,7 @@ _SYMBOLS = {
     "bo_records_encode": (C.c_int, [C.c_int, C.POINTER(BoPosition), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bo_debug_tree": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BoNode), C.c_int32, _I32P, C.c_void_p]),
     "bo_engine_status": (C.c_int, [C.c_void_p, _I32P, _I32P, _I32P, _I32P, _I32P, _I32P, C.c_void_p]),
+    "bo_debug_profile": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.c_void_p]),
     "bo_movegen_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BoPosition), _I32P, _I32P, _I32P, C.c_void_p]),
     "bo_nn_bias_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "bo_nn_se_residual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -298,6 +299,11 @@ class Engine:
             g = int(bad[0])
             msg = ", ".join(v for b, v in STATUS_BITS.items() if st[g] & b)
             raise EngineError(f"game slot {g}: {msg}")
+
+    def profile(self, enable: int = -1, read: bool = True, stream: int = 0):
+        out = np.zeros((self.G, 8), dtype=np.uint64) if read else None
+        self._check(self.lib.bo_debug_profile(self.h, enable, out.ctypes.data_as(C.POINTER(C.c_uint64)) if read else None, stream))
+        return out
 
     def movegen(self, positions: Sequence[BoPosition], stream: int = 0):
         n = len(positions)

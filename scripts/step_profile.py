@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""scripts/step_profile.py -- where bo_k_step spends its cycles in steady-state self-play (per-phase s_memtime counters)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+sys.argv = [sys.argv[0]] + sys.argv[1:]
+import bench
+from betaone_amd.rollout import Rollout
+
+warm = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+_, net = bench.make_net("10x128", torch.device("cuda:0"), "fp32", 256)
+ro = Rollout(net, 256, num_simulations=800, mcts_batch_size=96, device="cuda:0", use_graph=False, rng_mode="native")
+ro.start_games(list(range(256)), list(range(256)), list(range(256)))
+nid = [256]
+def refill(_s):
+    nid[0] += 1
+    return nid[0], nid[0], None
+for _ in range(warm):
+    ro.play_ply(refill=refill)
+ro.eng.profile(enable=1, read=False)
+for _ in range(steps):
+    ro.play_ply(refill=refill)
+p = ro.eng.profile(enable=0).astype(np.float64)
+names = ["apply", "select", "first-visit", "terminal-backup", "encode", "flush", "total", "steps"]
+per_step = p[:, :7] / np.maximum(p[:, 7:8], 1)
+print("cycles per step per game (100 MHz s_memtime ticks? shader clock): mean over games / max over games")
+for i, n in enumerate(names[:7]):
+    print(f"  {n:16s} mean {per_step[:, i].mean():10.0f}   max {per_step[:, i].max():10.0f}")
+st = ro.eng.status()
+print("term_sims per game-step:", st["term_sims"].sum() / max(1, p[:, 7].sum()), " evals:", st["evals"].sum())

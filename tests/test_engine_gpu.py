@@ -59,8 +59,8 @@ def test_select_wide_matches_numpy_reference(backend):
 
 
 def test_in_kernel_softmax_close_to_torch(backend):
-    """policy_kind LOGITS: the engine's own softmax (the seam is NOT shared here) -- priors within 1e-6 relative
-    of torch.softmax, visit counts identical for well-separated logits."""
+    """policy_kind LOGITS: the engine's own softmax (hardware exp, the seam is NOT shared here) -- priors within
+    1e-5 relative of torch.softmax (north-star tolerance: 1e-4), visit counts identical for well-separated logits."""
     import torch
     from betaone_amd import engine as E
     from engine_harness import Buf, make_engine, canonical_tree
@@ -96,7 +96,7 @@ def test_in_kernel_softmax_close_to_torch(backend):
         assert got[k][0] == exp[k][0] and got[k][3] == exp[k][3]
         pg = np.array([got[k][2]], dtype=np.uint32).view(np.float32)[0]
         pe = np.array([exp[k][2]], dtype=np.uint32).view(np.float32)[0]
-        assert abs(pg - pe) <= 1e-6 * abs(pe) + 1e-12
+        assert abs(pg - pe) <= 1e-5 * abs(pe) + 1e-12
 
 
 def test_rollout_with_torch_net_graph_equals_eager(backend):

@@ -136,6 +136,7 @@ BO_DEV int bo_shfl_up(int v, int d) {
     int o = bo_shfl(v, (l - d) & 63);
     return l - d >= 0 ? o : v;
 }
+BO_DEV unsigned long long bo_clock() { return 0ull; }
 BO_DEV int bo_atomic_add(int *p, int v) { int o = *p; *p = o + v; return o; }
 BO_DEV int bo_atomic_or(int *p, int v) { int o = *p; *p = o | v; return o; }
 BO_DEV uint64_t bo_bitrev64(uint64_t x) {
