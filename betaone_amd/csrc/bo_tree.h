@@ -294,8 +294,7 @@ BO_DEV int select_leaf(const Eng &e, int g, int *flags, int *path, int *depth_ou
 BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, int sims_left) {
     const size_t no = NOFF(e, g);
     const int lane = bo_lane(), grp = lane >> 4, j = lane & 15;
-    // uniform copies of the path nodes' visit counts and (for the root) q
-    int nv[BO_BURST_LEVELS + 1];
+    int nv[BO_BURST_LEVELS + 1];  // uniform copies of the path nodes' visit counts
     int fc[BO_BURST_LEVELS], ncs[BO_BURST_LEVELS], chosen[BO_BURST_LEVELS];
 #pragma unroll
     for (int k = 0; k <= BO_BURST_LEVELS; k++) nv[k] = k <= d ? e.n_visits[no + path[k]] : 0;
@@ -306,31 +305,33 @@ BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, 
         chosen[k] = k < d ? path[k + 1] - fc[k] : -1;
     }
     float rootq = e.q[no];
-    // this lane's child: group = level, j = child index
-    int my_fc = 0, my_nc = 0, my_chosen = -1;
+    int my_fc = 0, my_nc = 0, my_chosen = -1;  // this lane's child: group = level, j = child index
 #pragma unroll
     for (int k = 0; k < BO_BURST_LEVELS; k++)
         if (grp == k) { my_fc = fc[k]; my_nc = ncs[k]; my_chosen = chosen[k]; }
     const bool have = grp < d && j < my_nc;
+    const bool last = grp == d - 1;  // the level whose children are leaves of the current path
     int cn = have ? e.n_visits[no + my_fc + j] : 0;
     float cq = have ? e.q[no + my_fc + j] : 0.0f;
     const float cp = have ? e.prior[no + my_fc + j] : 0.0f;
-    // value seen by path node k: leaf gets v, its parent -v, ...
-    const float my_val = ((d - (grp + 1)) & 1) ? -v : v;   // for the chosen child of level grp == path node grp+1
-    const float root_val = (d & 1) ? -v : v;
+    // at the last level any child that is ALREADY KNOWN to be a terminal leaf may take the next simulation
+    const int cterm = (have && last && e.n_children[no + my_fc + j] == 0) ? (int)e.term[no + my_fc + j] : -1;
+    float v_cur = v;
     int done = 0;
     for (;;) {
         // ---- apply one terminal simulation (MCTSNode.update along the path, mcts.py:120-144) ----
         if (have && j == my_chosen) {
+            const float val = ((d - (grp + 1)) & 1) ? -v_cur : v_cur;  // the leaf sees v, its parent -v, ...
             cn += 1;
-            const float dd = my_val - cq;
+            const float dd = val - cq;
             const float ee = dd / (float)cn;
             cq = cq + ee;
         }
 #pragma unroll
         for (int k = 0; k <= BO_BURST_LEVELS; k++) nv[k] += k <= d ? 1 : 0;
         {
-            const float dd = root_val - rootq;
+            const float val = (d & 1) ? -v_cur : v_cur;
+            const float dd = val - rootq;
             const float ee = dd / (float)nv[0];
             rootq = rootq + ee;
         }
@@ -357,11 +358,20 @@ BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, 
             const int oi = bo_shfl_xor(bi, m);
             if (os > score || (os == score && oi < bi)) { score = os; bi = oi; }
         }
-        const bool level_ok = !(grp < d) || (bi == my_chosen && score > -__builtin_inff());
-        if (bo_ballot(!level_ok) != 0) break;  // the next descent leaves this path: back to the general loop
+        // upper levels must reproduce the path; the last level may move to another known terminal leaf
+        const bool upper_ok = !(grp < d) || last || (bi == my_chosen && score > -__builtin_inff());
+        const int bterm = bo_shfl(cterm, (lane & 48) | (bi & 15));  // term of the child this group selected
+        const bool last_ok = !(have || (grp < d && j == 0)) || !last || (bterm > 0 && score > -__builtin_inff());
+        if (bo_ballot(!(upper_ok && last_ok)) != 0) break;  // the next descent needs the general loop
+        if (d > 0) {
+            const int src = 16 * (d - 1);  // lane 0 of the last level's group holds its argmax
+            const int nb = bo_shfl(bi, src), nt = bo_shfl(bterm, src);
+            if (last) my_chosen = nb;
+            v_cur = nt == 1 ? 1.0f : 0.0f;
+        }
     }
     // ---- write the path back ----
-    if (have && j == my_chosen) { e.n_visits[no + my_fc + j] = cn; e.q[no + my_fc + j] = cq; }
+    if (have) { e.n_visits[no + my_fc + j] = cn; e.q[no + my_fc + j] = cq; }
     if (lane == 0) { e.n_visits[no] = nv[0]; e.q[no] = rootq; }
     bo_sync();
     return done;
