@@ -840,7 +840,7 @@ BO_KERNEL void bo_k_play(Eng e, const int *action) {
     const int g = bo_block(), lane = bo_lane();
     const int a = action[g];
     if (a == -1) return;
-    const int ply = e.ply[g];
+    const int ply = e.ply[g], tn = e.trk_n[g];  // read before lane 0 updates them further down
     DPos *gp = e.gpos + (size_t)g * e.c.PLY_CAP;
     const DPos P = gp[ply];
     const int n = e.root_nlegal[g];
@@ -858,13 +858,12 @@ BO_KERNEL void bo_k_play(Eng e, const int *action) {
         if (best != m && best_ok) m = best;
         else { if (lane == 0) { e.status[g] |= ST_ILLEGAL_ACTION; e.phase[g] = PH_IDLE; } return; }
     }
-    if (ply + 1 >= e.c.PLY_CAP || e.trk_n[g] >= e.c.TRK_CAP) { if (lane == 0) e.status[g] |= ST_PLY_OVERFLOW; return; }
+    if (ply + 1 >= e.c.PLY_CAP || tn >= e.c.TRK_CAP) { if (lane == 0) e.status[g] |= ST_PLY_OVERFLOW; return; }
     if (lane == 0) {
         const DPos c = make_move(P, m);
         gp[ply + 1] = c;
         e.played[(size_t)g * e.c.PLY_CAP + ply] = m;
         e.ply[g] = ply + 1;
-        const int tn = e.trk_n[g];
         e.trk[(size_t)g * e.c.TRK_CAP + tn] = c;  // tracker.add_board (self_play.py:182)
         e.trk_cnt[(size_t)g * e.c.TRK_CAP + tn] = 1;
         e.trk_n[g] = tn + 1;

@@ -100,6 +100,10 @@ SPECIAL_FENS = [
     "4k3/4r3/8/8/8/8/4P3/4K3 w - - 0 1",            # pawn pinned on the file: pushes allowed
     "4k3/8/8/8/8/2n5/8/R3K2R w KQ - 0 1",           # double check is impossible here; knight checks
     "2r1k3/8/8/8/8/8/8/R3K2R w KQ - 0 1",           # c1 attacked: no queenside castling
+    "R6R/3Q4/1Q4Q1/4Q3/2Q4Q/Q4Q2/pp1Q4/kBNN1KB1 w - - 0 1",  # 218 legal moves: the known maximum
+    "8/8/8/8/8/8/8/K1k4R w - - 0 1",                 # rook check along the rank from far away
+    "4k3/8/8/8/1b6/8/3P4/4K3 w - - 0 1",            # pawn pinned diagonally: no push, no capture
+    "8/8/8/KPp4r/8/8/8/7k w - c6 0 1",              # ep capture would expose the king on the rank
 ]
 
 
@@ -276,3 +280,52 @@ def check_full_games_vs_oracle(backend, n_games=4, sims=12, batch=8, scale=4.0, 
         lengths.append((len(ref["moves"]), ref["termination"]))
     assert all(l > 20 for l, _ in lengths), lengths
     return lengths
+
+
+def check_edge_cases(backend):
+    """Maximum sizes and error paths of the C ABI."""
+    # 218 children in the FAST mode (full-width expansion) and a reference-mode search on the same position
+    fen = "R6R/3Q4/1Q4Q1/4Q3/2Q4Q/Q4Q2/pp1Q4/kBNN1KB1 w - - 0 1"
+    import test_fast_mode_emu as T
+    eng, _, _ = T.run_engine_search(backend, fen, [], 64, 8, T.softmax_eval(5), seed=2)
+    t = eng.debug_tree(0)
+    assert t[0]["n_children"] == 218 and sum(k["n"] for k in t[1:219]) == 64
+    eng = make_engine(backend, 1, dict(num_simulations=100))
+    eng.reset([0], [fen], [None])
+    nl, term, _ = eng.root_info()
+    assert nl[0] == 218 and term[0] == 0
+    s = Searcher(backend, eng)
+    res = s.search([1], [T.softmax_eval(5)], [np.random.RandomState(0)], 0.1)
+    assert int(res["total"][0]) == 100
+    # unsupported configurations are refused at create time, with a message
+    lib = eng.lib
+    for kw in (dict(widen_coeff=0.5), dict(widen_coeff=4.0, mcts_batch_size=96), dict(n_games=0)):
+        with pytest_raises(E.EngineError):
+            E.Engine(kw.pop("n_games", 1), lib=lib, **kw)
+    with pytest_raises(E.EngineError):
+        eng.reset([0], ["this is not a fen"], [None])
+    with pytest_raises(E.EngineError):
+        eng.reset([0], [None], ["e2e4 zz99"])
+    with pytest_raises(E.EngineError):
+        eng.reset([5], [None], [None])
+    # a game longer than max_plies sets a status bit instead of writing out of bounds
+    small = E.Engine(1, num_simulations=8, mcts_batch_size=8, max_plies=6, lib=lib)
+    small.reset([0])
+    ss = Searcher(backend, small)
+    for _ in range(8):
+        nl, term, ply = small.root_info()
+        res = ss.search([1], [T.softmax_eval(1)], [np.random.RandomState(0)], 0.1) if small.status()["status"][0] == 0 else None
+        small.play(np.array([-2], dtype=np.int32))
+    assert small.status()["status"][0] & 8 and small.root_info()[2][0] <= 5
+
+
+class pytest_raises:
+    def __init__(self, exc):
+        self.exc = exc
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        assert et is not None and issubclass(et, self.exc), f"expected {self.exc}"
+        return True

@@ -39,3 +39,7 @@ def test_full_games_to_termination_match_oracle(backend):
     """Whole games until is_game_over(claim_draw=True): long-game logic (claimable draws in the REAL game, tracker and
     position-stack growth, end-of-game tracker in the training encodings) against the oracle."""
     EC.check_full_games_vs_oracle(backend, n_games=4, sims=12, batch=8)
+
+
+def test_edge_cases_maximum_sizes_and_error_paths(backend):
+    EC.check_edge_cases(backend)

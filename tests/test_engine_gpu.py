@@ -316,3 +316,7 @@ def test_fast_mode_rollout_on_gpu(backend):
 def test_full_games_to_termination_match_oracle(backend):
     lengths = EC.check_full_games_vs_oracle(backend, n_games=12, sims=24, batch=8)
     assert any(t != 0 for _, t in lengths)  # at least one game actually ended by the rules
+
+
+def test_edge_cases_maximum_sizes_and_error_paths(backend):
+    EC.check_edge_cases(backend)
