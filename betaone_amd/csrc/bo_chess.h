@@ -265,11 +265,8 @@ BO_DEV bool insufficient_material(const DPos &p) {
 BO_DEV int move_to_index(bo_mv m) {
     int from = MV_FROM(m), to = MV_TO(m), promo = MV_PROMO(m);
     int fr = from >> 3, ff = from & 7, dr = (to >> 3) - fr, df = (to & 7) - ff;
-    if (promo && promo != 5) {  // under-promotion planes 64..72: piece (N,B,R) x direction (left, straight, right)
-        int d_r = fr == 6 ? dr : -dr;
-        (void)d_r;
+    if (promo && promo != 5)  // under-promotion planes 64..72: piece (N,B,R) x file direction (left, straight, right)
         return from * 73 + 64 + (promo - 2) * 3 + (df + 1);
-    }
     int adr = dr < 0 ? -dr : dr, adf = df < 0 ? -df : df;
     if ((adr == 1 && adf == 2) || (adr == 2 && adf == 1)) {
         // KNIGHT_DIRECTIONS (2,1),(1,2),(-1,2),(-2,1),(-2,-1),(-1,-2),(1,-2),(2,-1)

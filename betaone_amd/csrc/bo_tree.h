@@ -482,7 +482,6 @@ struct StepShared {
     bo_mv moves2[BO_MAX_MOVES];
     float pv[BO_MAX_MOVES];
     int path[BO_PATH_CAP];
-    int path2[BO_PATH_CAP];
     float probs[BO_NUM_ACTIONS];
     int rank_of[2 * BO_CH_CAP];
 };
@@ -655,7 +654,7 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
             bool small = depth <= BO_BURST_LEVELS;
             for (int k = 0; k < depth && small; k++) small = e.n_children[no + sh.path[k]] <= 16;
             if (small) applied = terminal_burst(e, g, sh.path, depth, tv, e.c.S - sims);
-            else backup_run(e, g, leaf, tv, 1, sh.path2, &flags);
+            else backup_run(e, g, leaf, tv, 1, sh.path, &flags);  // deep or wide path: one simulation the general way
             sims += applied;
             if (lane == 0) e.stat_term_sims[g] += applied;
             BO_PROF(3)
