@@ -1,0 +1,145 @@
+// betaone_amd/csrc/bo_conv.h -- 3x3 convolution of the residual tower on the fp32 matrix cores (gfx950 only).
+//
+// The evaluate stage of the path (PolicyValueNet, /root/reference/network.py:48-118,167-198) spends ~90 % of its
+// time in 3x3 convolutions over 8x8 boards.  Under PyTorch-ROCm they run in MIOpen's fp32 Winograd kernel (54 us
+// for [256,128,8,8] * [128,128,3,3]) followed by a separate bias/ReLU/residual pass.  This kernel is a direct
+// implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation) with the epilogue fused:
+//
+//   D[oc][pos] = sum_{tap, ic} W[oc][ic][tap] * X[ic][pos shifted by tap]        M = oc, N = pos (64), K = 9*Cin
+//
+//   * one workgroup per board; wave w owns output channels 32w..32w+31 and both 32-position halves of the board
+//     (two independent 32x32 accumulators = 32 AGPRs; the A fragment is shared by the two MFMAs of a K-step);
+//   * the whole input board lives in LDS as a zero-padded 10x10 image, channel-interleaved so that the B operands
+//     of four consecutive K-steps are ONE ds_read_b128: X[t4][k][padded pos][e] holds channel 8*t4 + 2*e + k.
+//     The 9 taps are 9 constant offsets of one base address; no bounds checks in the loop;
+//   * weights are pre-packed on the host as Wp[tap][Cin/8][oc][k=2][e=4] (value W[oc][8*t4 + 2*e + k][tap]): the
+//     A fragments of the same four K-steps are ONE coalesced global_load_dwordx4 per lane (L2-resident, every
+//     workgroup reads the same 9*Cin*Cout*4 bytes); the 9 taps of the NEXT channel group are loaded into a second
+//     register set while the 72 MFMAs of the current group issue, and the B operands are read one tap ahead;
+//   * epilogue in registers: y = relu(acc + bias[oc] (+ residual)), or acc + bias for the SE blocks.
+// MFMA time at 100 % issue: 9*Cin/2 K-steps x 2 MFMAs x 64 cycles = 73.7k cycles = 30.7 us at Cin = Cout = 128.
+#pragma once
+#if !defined(BO_WAVE_EMU)
+#include <hip/hip_runtime.h>
+
+typedef float bo_f32x16 __attribute__((ext_vector_type(16)));
+typedef float bo_f32x4 __attribute__((ext_vector_type(4)));
+
+enum { BO_CONV_RAW_BIAS = 0, BO_CONV_BIAS_RELU = 1, BO_CONV_BIAS_RES_RELU = 2 };
+
+// LAB (scripts/conv_lab.hip only): 0 = the kernel; 1 = no main loop; 2 = main loop without LDS reads;
+// 3 = main loop without weight loads.
+template <int CIN, int COUT, int LAB = 0>
+__global__ void __launch_bounds__(COUT * 2)
+bo_k_conv3x3(const float *__restrict__ x, const bo_f32x4 *__restrict__ wp, const float *__restrict__ bias,
+             const float *__restrict__ res, float *__restrict__ y, int mode) {
+    constexpr int T4 = CIN / 8;       // channel groups of 8 = 4 K-steps of 2 channels
+    constexpr int PITCH = 100;        // padded 10x10 board
+    constexpr int NT = COUT * 2;      // threads: one wave per 32 output channels
+    __shared__ bo_f32x4 X[T4 * 2 * PITCH];  // [t4][k][padded pos] x 4 channels e
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    const int k = lane >> 5, j = lane & 31;
+    const int oc = wave * 32 + j;                       // A operand row of this lane
+    const bo_f32x4 *xl = &X[k * PITCH + ((j >> 3) + 1) * 10 + (j & 7) + 1];   // B operand: first half; second half = +40
+    bo_f32x16 acc0 = {0}, acc1 = {0};
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) bv[r] = bias[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * k];
+    const bo_f32x4 *wl = wp + (size_t)oc * 2 + k;       // Wp float4 index: ((tap*T4 + t4)*COUT + oc)*2 + k
+
+    // Weight fragments ping-pong between two register sets; the loads of the next channel group are pinned ahead of
+    // the 72 MFMAs of the current one (left alone, the scheduler folds the two sets into one and issues the loads
+    // right before their first use, which exposes the L2 latency once per group).
+    bo_f32x4 fa[9], fb[9];
+    bo_f32x4 bn0, bn1;                                  // B operands of the next tap
+    auto load = [&](bo_f32x4(&a)[9], int t4) {
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++)
+            a[tap] = (LAB == 3) ? bo_f32x4{1.0f, 0.5f, 0.25f, 2.0f} : wl[(size_t)(tap * T4 + t4) * COUT * 2];
+    };
+    auto read_b = [&](int t4, int tap) {
+        const int off = (tap / 3 - 1) * 10 + (tap % 3 - 1);
+        if (LAB == 2) { bn0 = bo_f32x4{1.0f, 2.0f, 3.0f, 4.0f}; bn1 = bn0; return; }
+        bn0 = xl[t4 * 2 * PITCH + off];
+        bn1 = xl[t4 * 2 * PITCH + off + 40];
+    };
+    auto compute = [&](const bo_f32x4(&a)[9], int t4) {
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const bo_f32x4 b0 = bn0, b1 = bn1;
+            if (tap < 8) read_b(t4, tap + 1);
+            else read_b(t4 + 1 < T4 ? t4 + 1 : t4, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tap][e], b0[e], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tap][e], b1[e], acc1, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (LAB != 1) load(fa, 0);  // first weight fragments fly while the board is staged
+
+    // ---- stage the board: issue the global loads, zero the halo image while they fly, then scatter the squares ----
+    constexpr int NLD = (CIN * 16 + NT - 1) / NT;  // 16 float4 (4 squares each) per channel
+    const bo_f32x4 *xb = reinterpret_cast<const bo_f32x4 *>(x + (size_t)b * CIN * 64);
+    bo_f32x4 stage[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; u++) {
+        const int i = tid + u * NT;
+        stage[u] = (CIN * 16 % NT == 0 || i < CIN * 16) ? xb[i] : bo_f32x4{0, 0, 0, 0};
+    }
+    for (int i = tid; i < T4 * 2 * PITCH; i += NT) X[i] = bo_f32x4{0, 0, 0, 0};
+    __syncthreads();
+    {
+        float *Xf = reinterpret_cast<float *>(X);
+#pragma unroll
+        for (int u = 0; u < NLD; u++) {
+            const int i = tid + u * NT;
+            if (CIN * 16 % NT == 0 || i < CIN * 16) {
+                const int ic = i >> 4, q = i & 15, r = q >> 1, c0 = (q & 1) * 4;
+                float *dst = Xf + (((ic >> 3) * 2 + (ic & 1)) * PITCH + (r + 1) * 10 + c0 + 1) * 4 + ((ic & 7) >> 1);
+                dst[0] = stage[u][0]; dst[4] = stage[u][1]; dst[8] = stage[u][2]; dst[12] = stage[u][3];
+            }
+        }
+    }
+    __syncthreads();
+
+    if (LAB != 1) {
+        read_b(0, 0);
+        int t4 = 0;
+        for (; t4 + 2 <= T4; t4 += 2) {
+            load(fb, t4 + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(fa, t4);
+            if (t4 + 2 < T4) load(fa, t4 + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(fb, t4 + 1);
+        }
+        if (t4 < T4) compute(fa, t4);
+    }
+
+    // ---- epilogue: D row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 ----
+    float *yb = y + (size_t)b * COUT * 64;
+    const float *rb = res + (size_t)b * COUT * 64;
+    float r0[16], r1[16];
+    if (mode == BO_CONV_BIAS_RES_RELU) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int o = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * k;
+            r0[r] = rb[o * 64 + j];
+            r1[r] = rb[o * 64 + 32 + j];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int o = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * k;
+        float v0 = acc0[r] + bv[r], v1 = acc1[r] + bv[r];
+        if (mode == BO_CONV_BIAS_RES_RELU) { v0 += r0[r]; v1 += r1[r]; }
+        if (mode != BO_CONV_RAW_BIAS) { v0 = v0 > 0.0f ? v0 : 0.0f; v1 = v1 > 0.0f ? v1 : 0.0f; }
+        yb[o * 64 + j] = v0;
+        yb[o * 64 + 32 + j] = v1;
+    }
+}
+#endif

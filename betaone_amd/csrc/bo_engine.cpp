@@ -8,6 +8,7 @@
 #include "bo_fast.h"
 #include "bo_select_wide.h"
 #include "bo_nn_fused.h"
+#include "bo_conv.h"
 #include "bo_rt.h"
 #include "bo_hostrng.h"
 
@@ -631,5 +632,29 @@ extern "C" int bo_nn_se_residual(float *x_dev, const float *bias_dev, const floa
                        residual_dev, channels, hidden);
     RT((int)hipGetLastError());
     return BO_OK;
+#endif
+}
+
+// ---- direct 3x3 convolution on the fp32 matrix cores (bo_conv.h); independent of an engine instance ---------------
+extern "C" int bo_nn_conv3x3(const float *x_dev, const float *wpacked_dev, const float *bias_dev, const float *residual_dev,
+                             float *y_dev, int batch, int c_in, int c_out, int mode, void *stream) {
+#if defined(BO_WAVE_EMU)
+    (void)x_dev; (void)wpacked_dev; (void)bias_dev; (void)residual_dev; (void)y_dev; (void)batch; (void)c_in; (void)c_out; (void)mode; (void)stream;
+    return fail(BO_E_CONFIG, "bo_nn_conv3x3 is a gfx950-only kernel");
+#else
+    if (!x_dev || !wpacked_dev || !bias_dev || !y_dev || batch < 1) return fail(BO_E_ARG, "bad arguments");
+    if (mode < 0 || mode > 2 || (mode == 2 && !residual_dev)) return fail(BO_E_ARG, "bad epilogue mode");
+    const bo_f32x4 *wp = reinterpret_cast<const bo_f32x4 *>(wpacked_dev);
+    hipStream_t st = (hipStream_t)stream;
+#define BO_CONV_CASE(CI, CO)                                                                                              \
+    if (c_in == CI && c_out == CO) {                                                                                      \
+        hipLaunchKernelGGL((bo_k_conv3x3<CI, CO>), dim3((unsigned)batch), dim3(CO * 2), 0, st, x_dev, wp, bias_dev, residual_dev, \
+                           y_dev, mode);                                                                                  \
+        RT((int)hipGetLastError());                                                                                       \
+        return BO_OK;                                                                                                     \
+    }
+    BO_CONV_CASE(120, 64) BO_CONV_CASE(64, 64) BO_CONV_CASE(120, 128) BO_CONV_CASE(128, 128) BO_CONV_CASE(120, 256) BO_CONV_CASE(256, 256)
+#undef BO_CONV_CASE
+    return fail(BO_E_CONFIG, "bo_nn_conv3x3: supported (c_in, c_out): (120|C, C) for C in {64, 128, 256}");
 #endif
 }

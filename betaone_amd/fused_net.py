@@ -2,9 +2,14 @@
 betaone_amd/fused_net.py -- the evaluate stage with hand-written fused epilogues.
 
 Same function as PolicyValueNet.forward (/root/reference/network.py:167-198) in eval mode: BatchNorm is folded into
-the convolutions, the 3x3 convolutions stay in MIOpen (fp32 Winograd asm kernel under PyTorch-ROCm, the only MFMA/
-matrix work on the path), and every conv is followed by ONE gfx950 kernel from csrc/bo_nn_fused.h instead of the
-3-8 separate elementwise launches PyTorch issues (bias, ReLU, residual add, SE pooling / FCs / sigmoid / scale).
+the convolutions and every conv is followed by (or fused with) a gfx950 epilogue instead of the 3-8 separate
+elementwise launches PyTorch issues (bias, ReLU, residual add, SE pooling / FCs / sigmoid / scale).  Two variants:
+
+  conv="miopen": the 3x3 convolutions stay in MIOpen (fp32 Winograd asm kernel under PyTorch-ROCm), each followed
+                 by ONE kernel from csrc/bo_nn_fused.h;
+  conv="mfma":   the 3x3 convolutions run in csrc/bo_conv.h (direct implicit GEMM on the fp32 matrix cores, bias /
+                 ReLU / residual fused into its epilogue); SE blocks add csrc/bo_nn_fused.h's SE kernel.
+
 NCHW float32 only; other dtypes/layouts use PolicyValueNet.for_inference().
 """
 from __future__ import annotations
@@ -16,11 +21,36 @@ import torch.nn.functional as F
 from . import engine as E
 
 
+MFMA_CONV_SHAPES = {(120, 64), (64, 64), (120, 128), (128, 128), (120, 256), (256, 256)}
+
+
+def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """[c_out, c_in, 3, 3] -> [tap 9][c_in/8][c_out][k 2][e 4], element = W[oc][8*t4 + 2*e + k][tap]: the A fragments
+    of four consecutive 32x32x2 MFMA K-steps as one 16-byte load per lane (csrc/bo_conv.h)."""
+    co, ci = w.shape[0], w.shape[1]
+    return w.reshape(co, ci // 8, 4, 2, 9).permute(4, 1, 0, 3, 2).contiguous()
+
+
+def conv3x3_mfma(lib, x, wpacked, bias, c_out, mode=0, residual=None, out=None):
+    """y = epilogue(conv3x3(x)) through the C ABI (bo_nn_conv3x3); x NCHW float32 [B, c_in, 8, 8], contiguous."""
+    B, c_in = x.shape[0], x.shape[1]
+    if not x.is_contiguous() or x.dtype != torch.float32 or x.shape[2:] != (8, 8):
+        raise E.EngineError("conv3x3_mfma: x must be a contiguous float32 [B, C, 8, 8] tensor")
+    y = out if out is not None else torch.empty((B, c_out, 8, 8), dtype=torch.float32, device=x.device)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    rc = lib.bo_nn_conv3x3(x.data_ptr(), wpacked.data_ptr(), bias.data_ptr(), residual.data_ptr() if residual is not None else None,
+                           y.data_ptr(), B, c_in, c_out, mode, stream)
+    if rc:
+        raise E.EngineError(lib.bo_last_error().decode())
+    return y
+
+
 class FusedPolicyValueNet(nn.Module):
-    def __init__(self, net, lib=None):
+    def __init__(self, net, lib=None, conv="miopen"):
         """net: a PolicyValueNet (any device); weights are copied, BN folded."""
         super().__init__()
         self.lib = lib if lib is not None else E.load_hip_library()
+        self.conv = conv
         f = net.for_inference(dtype=torch.float32, channels_last=False)
         dev = next(f.parameters()).device
         if dev.type != "cuda":
@@ -51,6 +81,23 @@ class FusedPolicyValueNet(nn.Module):
         self.n_policy_ch = f.policy_conv.out_channels
         self.policy_fc, self.value_fc1, self.value_fc2 = f.policy_fc, f.value_fc1, f.value_fc2
         self.layout = "nchw+fused"
+        if conv == "mfma":
+            shapes = {(self.w_in.shape[1], self.w_in.shape[0])} | {(b[0].shape[1], b[0].shape[0]) for b in self.blocks}
+            if not shapes <= MFMA_CONV_SHAPES:
+                raise E.EngineError(f"conv='mfma' supports (c_in, c_out) in {sorted(MFMA_CONV_SHAPES)}, got {sorted(shapes)}")
+            self.c = self.w_in.shape[0]
+            self.p_in = nn.Parameter(pack_conv_weight(self.w_in), requires_grad=False)
+            self.packed = []
+            for i, (w1, _, w2, _, _) in enumerate(self.blocks):
+                p1 = nn.Parameter(pack_conv_weight(w1), requires_grad=False)
+                p2 = nn.Parameter(pack_conv_weight(w2), requires_grad=False)
+                self.register_parameter(f"blk{i}_p1", p1)
+                self.register_parameter(f"blk{i}_p2", p2)
+                self.packed.append((p1, p2))
+            self.zero_bias = nn.Parameter(torch.zeros(self.c, device=dev), requires_grad=False)
+            self.layout = "nchw+mfma"
+        elif conv != "miopen":
+            raise ValueError("conv must be 'miopen' or 'mfma'")
 
     def _epi(self, x, bias, res=None):
         B, C = x.shape[0], x.shape[1]
@@ -69,8 +116,25 @@ class FusedPolicyValueNet(nn.Module):
             raise E.EngineError(self.lib.bo_last_error().decode())
         return x
 
+    def _tower_mfma(self, x):
+        L, C = self.lib, self.c
+        x = conv3x3_mfma(L, x.contiguous(), self.p_in, self.b_in, C, 1)
+        for (w1, b1, w2, b2, se), (p1, p2) in zip(self.blocks, self.packed):
+            y = conv3x3_mfma(L, x, p1, b1, C, 1)
+            if se is not None:
+                x = self._se(conv3x3_mfma(L, y, p2, self.zero_bias, C, 0), b2, se, x)
+            else:
+                x = conv3x3_mfma(L, y, p2, b2, C, 2, residual=x)
+        return x
+
     @torch.no_grad()
     def forward(self, x):
+        if self.conv == "mfma":
+            x = self._tower_mfma(x)
+            h = self._epi(F.conv2d(x, self.w_head, None), self.b_head)
+            p = h[:, :self.n_policy_ch].flatten(1)
+            v = h[:, self.n_policy_ch:].flatten(1)
+            return self.policy_fc(p), torch.tanh(self.value_fc2(F.relu(self.value_fc1(v))))
         x = self._epi(F.conv2d(x, self.w_in, None, padding=1), self.b_in)
         for w1, b1, w2, b2, se in self.blocks:
             y = self._epi(F.conv2d(x, w1, None, padding=1), b1)

@@ -42,13 +42,20 @@ def best_inference_copy(model, batch: int, device, dtype: torch.dtype = torch.fl
         if best_t is None or t < best_t:
             best, best_t, best_cl = net, t, cl
     best.layout = "channels_last" if best_cl else "nchw"
-    if dtype == torch.float32:  # NCHW fp32 with the hand-written fused epilogues (csrc/bo_nn_fused.h)
+    if dtype == torch.float32:  # NCHW fp32 with the hand-written kernels (csrc/bo_nn_fused.h, csrc/bo_conv.h)
+        from . import engine as E
         from .fused_net import FusedPolicyValueNet
 
-        fused = FusedPolicyValueNet(model.to(device)).to(device)
-        t = _time_forward(fused, x)
-        if verbose:
-            print(f"[nn_tune] batch={batch} nchw+fused epilogues: {t * 1e3:.3f} ms")
-        if t < best_t:
-            best = fused
+        for conv in ("miopen", "mfma"):
+            try:
+                fused = FusedPolicyValueNet(model.to(device), conv=conv).to(device)
+            except E.EngineError:
+                if conv == "mfma":  # filter count without an MFMA instantiation
+                    continue
+                raise
+            t = _time_forward(fused, x)
+            if verbose:
+                print(f"[nn_tune] batch={batch} nchw fused epilogues, conv={conv}: {t * 1e3:.3f} ms")
+            if t < best_t:
+                best, best_t = fused, t
     return best

@@ -209,6 +209,14 @@ int bo_nn_bias_act(float *x_dev, const float *bias_dev, const float *residual_de
 int bo_nn_se_residual(float *x_dev, const float *bias_dev, const float *w1_dev, const float *w2_dev,
                       const float *residual_dev, int batch, int channels, int hidden, void *stream);
 
+/* 3x3 convolution (padding 1) over 8x8 boards on the fp32 matrix cores with the epilogue fused, NCHW float32:
+ *   mode 0: y = conv(x) + bias      1: y = relu(conv(x) + bias)      2: y = relu(conv(x) + bias + residual)
+ * wpacked_dev: the [c_out][c_in][3][3] weights re-ordered as [tap 9][c_in/8][c_out][2][4] with element
+ * (tap, t4, oc, k, e) = W[oc][8*t4 + 2*e + k][tap] (betaone_amd/fused_net.py:pack_conv_weight).
+ * Supported (c_in, c_out): (120 | C, C) for C in {64, 128, 256}.  Asynchronous on `stream`. */
+int bo_nn_conv3x3(const float *x_dev, const float *wpacked_dev, const float *bias_dev, const float *residual_dev,
+                  float *y_dev, int batch, int c_in, int c_out, int mode, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,7 +24,7 @@ config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 8, 2, 1
 torch.manual_seed(0)
 base = network.PolicyValueNet().cuda().eval()
 gflop = 0.398
-for bm in (False, True):
+for bm in (() if '--fused-only' in sys.argv else (False, True)):
     torch.backends.cudnn.benchmark = bm
     for cl in (True, False):
         for dt in (torch.float32, torch.float16):
@@ -34,3 +34,25 @@ for bm in (False, True):
                 if cl: x = x.contiguous(memory_format=torch.channels_last)
                 ms = bench(net, x)
                 print(f"benchmark={bm} channels_last={cl} dtype={str(dt)[6:]} B={B}: {ms:.3f} ms  {B/ms*1e3:.0f} pos/s  {gflop*B/ms:.1f} TFLOP/s", flush=True)
+
+# hand-written variants (csrc/bo_nn_fused.h, csrc/bo_conv.h), NCHW fp32
+from betaone_amd.fused_net import FusedPolicyValueNet, conv3x3_mfma, pack_conv_weight
+from betaone_amd import engine as E
+import torch.nn.functional as F
+lib = E.load_hip_library()
+for conv in ("miopen", "mfma"):
+    net = FusedPolicyValueNet(base, conv=conv).cuda()
+    for B in (256, 512, 1024, 2048):
+        x = torch.randn(B, 120, 8, 8, device="cuda")
+        ms = bench(net, x)
+        print(f"fused conv={conv} B={B}: {ms:.3f} ms  {B/ms*1e3:.0f} pos/s  {gflop*B/ms:.1f} TFLOP/s", flush=True)
+for B in (256, 1024):
+    x = torch.randn(B, 128, 8, 8, device="cuda"); w = torch.randn(128, 128, 3, 3, device="cuda") * 0.03
+    bias = torch.zeros(128, device="cuda"); wp = pack_conv_weight(w); y = torch.empty_like(x)
+    class One(torch.nn.Module):
+        def forward(self, x): return conv3x3_mfma(lib, x, wp, bias, 128, 1, out=y)
+    class Lib(torch.nn.Module):
+        def forward(self, x): return F.conv2d(x, w, None, padding=1)
+    for nm, m in (("mfma", One()), ("miopen", Lib())):
+        ms = bench(m, x, 100)
+        print(f"single conv 128->128 {nm} B={B}: {ms*1e3:.1f} us  {B*128*128*9*64*2/ms/1e9:.1f} TFLOP/s", flush=True)

@@ -160,9 +160,41 @@ def test_records_roundtrip_and_expand(backend):
             assert z == f.z(i)
 
 
+@pytest.mark.parametrize("shape", [(120, 64), (64, 64), (120, 128), (128, 128), (120, 256), (256, 256)])
+def test_mfma_conv3x3_matches_float64_convolution(backend, shape):
+    """csrc/bo_conv.h through the C ABI (bo_nn_conv3x3): all three epilogues against a float64 convolution, and not
+    further from it than MIOpen's own fp32 result is."""
+    import torch
+    import torch.nn.functional as F
+    from betaone_amd import engine as E
+    from betaone_amd.fused_net import conv3x3_mfma, pack_conv_weight
+
+    lib = E.load_hip_library()
+    ci, co = shape
+    g = torch.Generator().manual_seed(ci * 1000 + co)
+    for B in (1, 37):
+        x = torch.randn((B, ci, 8, 8), generator=g).cuda()
+        w = (torch.randn((co, ci, 3, 3), generator=g) / (3.0 * ci ** 0.5)).cuda()
+        bias = torch.randn(co, generator=g).cuda()
+        res = torch.randn((B, co, 8, 8), generator=g).cuda()
+        ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+        wp = pack_conv_weight(w)
+        refs = (ref, ref.relu(), (ref + res.double()).relu())
+        lib_err = (F.conv2d(x, w, bias, padding=1).double() - ref).abs().max().item()
+        for mode in (0, 1, 2):
+            y = conv3x3_mfma(lib, x, wp, bias, co, mode, residual=res if mode == 2 else None)
+            torch.cuda.synchronize()
+            err = (y.double() - refs[mode]).abs().max().item()
+            assert err < 2e-5 and err <= 4 * lib_err + 1e-6, (shape, B, mode, err, lib_err)
+    with pytest.raises(E.EngineError):
+        conv3x3_mfma(lib, torch.zeros((1, 24, 8, 8)).cuda(), wp, bias, co)
+
+
+@pytest.mark.parametrize("conv", ["miopen", "mfma"])
 @pytest.mark.parametrize("size", [(3, 1, 64), (8, 2, 128), (2, 2, 256)])
-def test_fused_epilogue_net_matches_plain_net(backend, size):
-    """csrc/bo_nn_fused.h: conv (MIOpen) + one fused epilogue kernel == PolicyValueNet.forward, within 1e-5."""
+def test_fused_epilogue_net_matches_plain_net(backend, size, conv):
+    """csrc/bo_nn_fused.h + csrc/bo_conv.h: conv (MIOpen, or the fp32-MFMA direct kernel) with fused epilogues ==
+    PolicyValueNet.forward, within 1e-5."""
     import torch
     from betaone_amd import dropin
     dropin.install()
@@ -174,7 +206,7 @@ def test_fused_epilogue_net_matches_plain_net(backend, size):
     config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = size
     try:
         net = hash_init_(network.PolicyValueNet().eval()).to("cuda:0")
-        fused = FusedPolicyValueNet(net).to("cuda:0")
+        fused = FusedPolicyValueNet(net, conv=conv).to("cuda:0")
         z = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "g1_net.npz"))
         x = torch.from_numpy(z["inputs"]).to("cuda:0").repeat(11, 1, 1, 1)  # 33 boards
         with torch.no_grad():
