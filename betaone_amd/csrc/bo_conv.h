@@ -25,6 +25,20 @@
 typedef float bo_f32x16 __attribute__((ext_vector_type(16)));
 typedef float bo_f32x4 __attribute__((ext_vector_type(4)));
 
+// Issue order of one tap: the two LDS reads and the weight load each go into the 64-cycle shadow of a different MFMA
+// (issued as one clump after the 8th MFMA they take longer than that shadow and the matrix pipe idles ~10 %).
+#define BO_CONV_TAP_SCHEDULE()                                 \
+    do {                                                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);     \
+        __builtin_amdgcn_sched_barrier(0);                     \
+    } while (0)
+
 enum { BO_CONV_RAW_BIAS = 0, BO_CONV_BIAS_RELU = 1, BO_CONV_BIAS_RES_RELU = 2 };
 
 // LAB (scripts/conv_lab.hip only): 0 = the kernel; 1 = no main loop; 2 = main loop without LDS reads;
@@ -46,17 +60,19 @@ bo_k_conv3x3(const float *__restrict__ x, const bo_f32x4 *__restrict__ wp, const
     float bv[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) bv[r] = bias[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * k];
-    const bo_f32x4 *wl = wp + (size_t)oc * 2 + k;       // Wp float4 index: ((tap*T4 + t4)*COUT + oc)*2 + k
+    const unsigned wlane = (unsigned)oc * 2 + k;        // Wp float4 index: ((tap*T4 + t4)*COUT)*2 [uniform] + oc*2 + k [lane]
 
-    // Weight fragments ping-pong between two register sets; the loads of the next channel group are pinned ahead of
-    // the 72 MFMAs of the current one (left alone, the scheduler folds the two sets into one and issues the loads
-    // right before their first use, which exposes the L2 latency once per group).
+    // Weight fragments ping-pong between two register sets.  The load of tap t of the NEXT channel group is issued
+    // together with the LDS reads of the next tap, in the shadow of the 8 MFMAs of the current tap (a block of 9 loads
+    // with their address arithmetic between two groups drains the MFMA pipe for ~600 cycles per group); the
+    // sched_barriers pin that placement (left alone, the scheduler folds the two sets into one and issues each load
+    // right before its first use).  Addresses are uniform base + constant lane offset: no VALU work per load.
     bo_f32x4 fa[9], fb[9];
     bo_f32x4 bn0, bn1;                                  // B operands of the next tap
     auto load = [&](bo_f32x4(&a)[9], int t4) {
 #pragma unroll
         for (int tap = 0; tap < 9; tap++)
-            a[tap] = (LAB == 3) ? bo_f32x4{1.0f, 0.5f, 0.25f, 2.0f} : wl[(size_t)(tap * T4 + t4) * COUT * 2];
+            a[tap] = (LAB == 3) ? bo_f32x4{1.0f, 0.5f, 0.25f, 2.0f} : (wp + (size_t)(tap * T4 + t4) * COUT * 2)[wlane];
     };
     auto read_b = [&](int t4, int tap) {
         const int off = (tap / 3 - 1) * 10 + (tap % 3 - 1);
@@ -64,19 +80,20 @@ bo_k_conv3x3(const float *__restrict__ x, const bo_f32x4 *__restrict__ wp, const
         bn0 = xl[t4 * 2 * PITCH + off];
         bn1 = xl[t4 * 2 * PITCH + off + 40];
     };
-    auto compute = [&](const bo_f32x4(&a)[9], int t4) {
+    // 72 MFMAs of channel group t4 with fragments a; prefetches group t4 + 1 into an (if it exists)
+    auto compute = [&](const bo_f32x4(&a)[9], bo_f32x4(&an)[9], int t4) {
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             const bo_f32x4 b0 = bn0, b1 = bn1;
             if (tap < 8) read_b(t4, tap + 1);
             else read_b(t4 + 1 < T4 ? t4 + 1 : t4, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            if (t4 + 1 < T4) an[tap] = (LAB == 3) ? bo_f32x4{1.0f, 0.5f, 0.25f, 2.0f} : (wp + (size_t)(tap * T4 + t4 + 1) * COUT * 2)[wlane];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tap][e], b0[e], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tap][e], b1[e], acc1, 0, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            BO_CONV_TAP_SCHEDULE();
         }
     };
     if (LAB != 1) load(fa, 0);  // first weight fragments fly while the board is staged
@@ -110,14 +127,10 @@ bo_k_conv3x3(const float *__restrict__ x, const bo_f32x4 *__restrict__ wp, const
         read_b(0, 0);
         int t4 = 0;
         for (; t4 + 2 <= T4; t4 += 2) {
-            load(fb, t4 + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(fa, t4);
-            if (t4 + 2 < T4) load(fa, t4 + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(fb, t4 + 1);
+            compute(fa, fb, t4);
+            compute(fb, fa, t4 + 1);
         }
-        if (t4 < T4) compute(fa, t4);
+        if (t4 < T4) compute(fa, fb, t4);
     }
 
     // ---- epilogue: D row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 ----

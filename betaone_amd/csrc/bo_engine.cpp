@@ -9,6 +9,7 @@
 #include "bo_select_wide.h"
 #include "bo_nn_fused.h"
 #include "bo_conv.h"
+#include "bo_tower.h"
 #include "bo_rt.h"
 #include "bo_hostrng.h"
 
@@ -657,4 +658,92 @@ extern "C" int bo_nn_conv3x3(const float *x_dev, const float *wpacked_dev, const
 #undef BO_CONV_CASE
     return fail(BO_E_CONFIG, "bo_nn_conv3x3: supported (c_in, c_out): (120|C, C) for C in {64, 128, 256}");
 #endif
+}
+
+// ---- the whole residual tower as one persistent kernel (bo_tower.h) ------------------------------------------------
+#if !defined(BO_WAVE_EMU)
+struct bo_tower_s {
+    int channels = 0, n_layers = 0, n_cu = 0, device = 0;
+    bo_f32x4 *wts = nullptr;
+    float *params = nullptr;
+    bo_tower_layer *layers = nullptr;
+};
+#else
+struct bo_tower_s { int unused; };
+#endif
+
+extern "C" int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layers, const float *weights, int64_t n_weights,
+                                  const float *params, int64_t n_params, int channels, int device, bo_tower **out) {
+#if defined(BO_WAVE_EMU)
+    (void)layers; (void)n_layers; (void)weights; (void)n_weights; (void)params; (void)n_params; (void)channels; (void)device; (void)out;
+    return fail(BO_E_CONFIG, "bo_nn_tower is a gfx950-only kernel");
+#else
+    static_assert(sizeof(bo_tower_layer_desc) == sizeof(bo_tower_layer), "descriptor layouts must agree");
+    if (!layers || !weights || !params || !out || n_layers < 1 || n_layers > 4096) return fail(BO_E_ARG, "bad arguments");
+    if (channels != 64 && channels != 128) return fail(BO_E_CONFIG, "bo_nn_tower: channels must be 64 or 128 (two padded boards must fit in 160 KB of LDS)");
+    if (n_weights % 4) return fail(BO_E_ARG, "n_weights must be a multiple of 4");
+    const int C = channels;
+    for (int l = 0; l < n_layers; l++) {  // every offset the kernel will form stays inside the two buffers
+        const bo_tower_layer_desc &L = layers[l];
+        const int want_t4 = L.kind == 0 ? 16 : C / 8;
+        if (L.kind < 0 || L.kind > 3 || (l == 0) != (L.kind == 0)) return fail(BO_E_ARG, "layer " + std::to_string(l) + ": bad kind");
+        if (L.kind == 1 && (l + 1 >= n_layers || layers[l + 1].kind < 2)) return fail(BO_E_ARG, "a first conv must be followed by a second conv");
+        if (L.kind >= 2 && layers[l - 1].kind != 1) return fail(BO_E_ARG, "a second conv must follow a first conv");
+        if (L.t4 != want_t4) return fail(BO_E_ARG, "layer " + std::to_string(l) + ": t4 must be " + std::to_string(want_t4));
+        if (L.w_off4 < 0 || ((int64_t)L.w_off4 + (int64_t)9 * L.t4 * C * 2) * 4 > n_weights) return fail(BO_E_ARG, "weights offset out of range");
+        if (L.bias_off < 0 || (int64_t)L.bias_off + C > n_params) return fail(BO_E_ARG, "bias offset out of range");
+        if (L.kind == 3) {
+            if (L.hidden < 1 || L.hidden > 16) return fail(BO_E_CONFIG, "SE hidden width must be 1..16");
+            if (L.se_w1_off < 0 || (int64_t)L.se_w1_off + (int64_t)L.hidden * C > n_params || L.se_w2_off < 0 ||
+                (int64_t)L.se_w2_off + (int64_t)L.hidden * C > n_params)
+                return fail(BO_E_ARG, "SE weight offset out of range");
+        }
+        if ((L.last != 0) != (l == n_layers - 1)) return fail(BO_E_ARG, "exactly the final layer stores the output");
+    }
+    if (layers[n_layers - 1].kind < 2) return fail(BO_E_ARG, "the tower must end with a second conv");
+    RT(rt_set_device(device));
+    hipDeviceProp_t prop;
+    RT((int)hipGetDeviceProperties(&prop, device));
+    bo_tower_s *t = new bo_tower_s();
+    t->channels = C; t->n_layers = n_layers; t->n_cu = prop.multiProcessorCount; t->device = device;
+    int rc = (int)hipMalloc((void **)&t->wts, (size_t)n_weights * 4);
+    if (!rc) rc = (int)hipMalloc((void **)&t->params, (size_t)n_params * 4);
+    if (!rc) rc = (int)hipMalloc((void **)&t->layers, (size_t)n_layers * sizeof(bo_tower_layer));
+    if (!rc) rc = (int)hipMemcpy(t->wts, weights, (size_t)n_weights * 4, hipMemcpyHostToDevice);
+    if (!rc) rc = (int)hipMemcpy(t->params, params, (size_t)n_params * 4, hipMemcpyHostToDevice);
+    if (!rc) rc = (int)hipMemcpy(t->layers, layers, (size_t)n_layers * sizeof(bo_tower_layer), hipMemcpyHostToDevice);
+    if (rc) {
+        (void)hipFree(t->wts); (void)hipFree(t->params); (void)hipFree(t->layers);
+        delete t;
+        return fail(BO_E_HIP, std::string("bo_nn_tower_create: ") + rt_errstr(rc));
+    }
+    *out = t;
+    return BO_OK;
+#endif
+}
+
+extern "C" int bo_nn_tower_forward(bo_tower *t, const float *x_dev, float *y_dev, int batch, void *stream) {
+#if defined(BO_WAVE_EMU)
+    (void)t; (void)x_dev; (void)y_dev; (void)batch; (void)stream;
+    return fail(BO_E_CONFIG, "bo_nn_tower is a gfx950-only kernel");
+#else
+    if (!t || !x_dev || !y_dev || batch < 1) return fail(BO_E_ARG, "bad arguments");
+    const int slots = t->n_cu * (t->channels == 64 ? 2 : 1);  // 64 filters: two 2-wave workgroups share a CU
+    const unsigned grid = (unsigned)(batch < slots ? batch : slots);
+    hipStream_t st = (hipStream_t)stream;
+    if (t->channels == 128)
+        hipLaunchKernelGGL((bo_k_tower<128>), dim3(grid), dim3(256), 0, st, x_dev, t->wts, t->params, t->layers, t->n_layers, y_dev, batch);
+    else
+        hipLaunchKernelGGL((bo_k_tower<64>), dim3(grid), dim3(128), 0, st, x_dev, t->wts, t->params, t->layers, t->n_layers, y_dev, batch);
+    RT((int)hipGetLastError());
+    return BO_OK;
+#endif
+}
+
+extern "C" void bo_nn_tower_destroy(bo_tower *t) {
+#if !defined(BO_WAVE_EMU)
+    if (!t) return;
+    (void)hipFree(t->wts); (void)hipFree(t->params); (void)hipFree(t->layers);
+#endif
+    delete t;
 }

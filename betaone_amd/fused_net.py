@@ -10,6 +10,9 @@ elementwise launches PyTorch issues (bias, ReLU, residual add, SE pooling / FCs 
   conv="mfma":   the 3x3 convolutions run in csrc/bo_conv.h (direct implicit GEMM on the fp32 matrix cores, bias /
                  ReLU / residual fused into its epilogue); SE blocks add csrc/bo_nn_fused.h's SE kernel.
 
+  conv="tower":  input conv + all residual blocks are ONE persistent kernel that keeps each board's activations in
+                 LDS (csrc/bo_tower.h); 64 or 128 filters.
+
 NCHW float32 only; other dtypes/layouts use PolicyValueNet.for_inference().
 """
 from __future__ import annotations
@@ -17,6 +20,10 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+import ctypes as C
+
+import numpy as np
 
 from . import engine as E
 
@@ -96,8 +103,76 @@ class FusedPolicyValueNet(nn.Module):
                 self.packed.append((p1, p2))
             self.zero_bias = nn.Parameter(torch.zeros(self.c, device=dev), requires_grad=False)
             self.layout = "nchw+mfma"
+        elif conv == "tower":
+            self._build_tower(dev)
+            self.layout = "nchw+tower"
         elif conv != "miopen":
-            raise ValueError("conv must be 'miopen' or 'mfma'")
+            raise ValueError("conv must be 'miopen', 'mfma' or 'tower'")
+
+    def _build_tower(self, dev):
+        """Flatten the trunk into the three host arrays of bo_nn_tower_create (include/betaone_engine.h)."""
+        c = self.w_in.shape[0]
+        if c not in (64, 128) or self.w_in.shape[1] != 120:
+            raise E.EngineError("conv='tower' supports 120 input planes and 64 or 128 filters")
+        wts, params, layers = [], [], []
+        n_w = n_p = 0
+
+        def add_w(w):
+            nonlocal n_w
+            off = n_w // 4
+            flat = pack_conv_weight(w.detach().float().cpu()).reshape(-1).numpy()
+            wts.append(flat)
+            n_w += flat.size
+            return off
+
+        def add_p(t):
+            nonlocal n_p
+            off = n_p
+            flat = t.detach().float().cpu().contiguous().reshape(-1).numpy()
+            params.append(flat)
+            n_p += flat.size
+            return off
+
+        w0 = torch.zeros((c, 128, 3, 3))
+        w0[:, :120] = self.w_in.detach().float().cpu()
+        layers.append([add_w(w0), 16, add_p(self.b_in), 0, 0, 0, 0, 0])
+        for w1, b1, w2, b2, se in self.blocks:
+            layers.append([add_w(w1), c // 8, add_p(b1), 1, 0, 0, 0, 0])
+            if se is not None:
+                if se[0].shape[0] > 16:
+                    raise E.EngineError("conv='tower' supports SE hidden widths up to 16")
+                layers.append([add_w(w2), c // 8, add_p(b2), 3, add_p(se[0]), add_p(se[1]), se[0].shape[0], 0])
+            else:
+                layers.append([add_w(w2), c // 8, add_p(b2), 2, 0, 0, 0, 0])
+        layers[-1][7] = 1
+        wts = np.ascontiguousarray(np.concatenate(wts), dtype=np.float32)
+        params = np.ascontiguousarray(np.concatenate(params), dtype=np.float32)
+        table = np.ascontiguousarray(np.array(layers, dtype=np.int32))
+        handle = C.c_void_p()
+        rc = self.lib.bo_nn_tower_create(table.ctypes.data, len(layers), wts.ctypes.data, wts.size, params.ctypes.data, params.size, c,
+                                         dev.index if dev.index is not None else torch.cuda.current_device(), C.byref(handle))
+        if rc:
+            raise E.EngineError(self.lib.bo_last_error().decode())
+        self.c, self._tower, self._tower_dev = c, handle, dev
+
+    def __del__(self):
+        try:
+            t = self.__dict__.get("_tower")
+            if t:
+                self.__dict__["_tower"] = None
+                self.lib.bo_nn_tower_destroy(t)
+        except Exception:  # interpreter shutdown
+            pass
+
+    def _tower_forward(self, x):
+        if x.device != self._tower_dev or x.dtype != torch.float32 or x.shape[1:] != (120, 8, 8):
+            raise E.EngineError("tower: x must be float32 [B, 120, 8, 8] on the tower's device")
+        x = x.contiguous()
+        y = torch.empty((x.shape[0], self.c, 8, 8), dtype=torch.float32, device=x.device)
+        rc = self.lib.bo_nn_tower_forward(self._tower, x.data_ptr(), y.data_ptr(), x.shape[0], torch.cuda.current_stream(x.device).cuda_stream)
+        if rc:
+            raise E.EngineError(self.lib.bo_last_error().decode())
+        return y
 
     def _epi(self, x, bias, res=None):
         B, C = x.shape[0], x.shape[1]
@@ -129,8 +204,8 @@ class FusedPolicyValueNet(nn.Module):
 
     @torch.no_grad()
     def forward(self, x):
-        if self.conv == "mfma":
-            x = self._tower_mfma(x)
+        if self.conv in ("mfma", "tower"):
+            x = self._tower_mfma(x) if self.conv == "mfma" else self._tower_forward(x)
             h = self._epi(F.conv2d(x, self.w_head, None), self.b_head)
             p = h[:, :self.n_policy_ch].flatten(1)
             v = h[:, self.n_policy_ch:].flatten(1)

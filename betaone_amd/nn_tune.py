@@ -46,11 +46,11 @@ def best_inference_copy(model, batch: int, device, dtype: torch.dtype = torch.fl
         from . import engine as E
         from .fused_net import FusedPolicyValueNet
 
-        for conv in ("miopen", "mfma"):
+        for conv in ("miopen", "mfma", "tower"):
             try:
                 fused = FusedPolicyValueNet(model.to(device), conv=conv).to(device)
             except E.EngineError:
-                if conv == "mfma":  # filter count without an MFMA instantiation
+                if conv != "miopen":  # filter count without an MFMA instantiation
                     continue
                 raise
             t = _time_forward(fused, x)

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <vector>
 #include "../betaone_amd/csrc/bo_conv.h"
+#include "../betaone_amd/csrc/bo_tower.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
@@ -20,6 +21,37 @@ static float run(int B, const float *x, const bo_f32x4 *w, const float *bias, co
     return ms * 1000.0f / reps;
 }
 
+// sustained MFMA ceiling: 256 workgroups x 4 waves, nothing but v_mfma_f32_32x32x2_f32 on NACC accumulators
+template <int NACC>
+__global__ void __launch_bounds__(256) k_mfma_peak(float *out, int iters, float a, float b) {
+    bo_f32x16 acc[NACC];
+    for (int i = 0; i < NACC; i++) acc[i] = bo_f32x16{0};
+    float av = a + threadIdx.x, bw = b;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw + i, acc[i], 0, 0, 0);
+    }
+    float s = 0;
+    for (int i = 0; i < NACC; i++) for (int r = 0; r < 16; r++) s += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int NACC>
+static void peak(float *out, int grid) {
+    const int iters = 1152 / (8 * NACC) * 20;  // 20 conv layers' worth of MFMAs per wave
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k_mfma_peak<NACC>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0f, 2.0f);
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < 10; i++) hipLaunchKernelGGL(k_mfma_peak<NACC>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0f, 2.0f);
+    (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double us = ms * 1000 / 10, n_mfma = (double)iters * 8 * NACC;
+    printf("pure MFMA, %d accumulators, grid %d: %.1f us for %.0f MFMAs/wave = %.1f ns/MFMA -> %.1f TFLOP/s (%.2f GHz at 64 cycles)\n", NACC, grid, us,
+           n_mfma, us * 1000 / n_mfma, n_mfma * 4096 * 4 * grid / us / 1e6, 64.0 / (us * 1000 / n_mfma));
+}
+
 int main() {
     const int BMAX = 2048, C = 256;
     float *x, *y, *res, *bias; bo_f32x4 *w;
@@ -27,6 +59,7 @@ int main() {
     CK(hipMalloc(&bias, C * 4)); CK(hipMalloc(&w, (size_t)9 * C * C * 4));
     CK(hipMemset(x, 0, (size_t)BMAX * C * 64 * 4)); CK(hipMemset(res, 0, (size_t)BMAX * C * 64 * 4)); CK(hipMemset(bias, 0, C * 4));
     CK(hipMemset(w, 0, (size_t)9 * C * C * 4));
+    peak<1>(y, 256); peak<2>(y, 256); peak<4>(y, 256); peak<2>(y, 32); peak<2>(y, 512);
     for (int B : {256, 512, 768, 1024, 2048}) {
         float t0 = run<128, 128, 0>(B, x, w, bias, res, y, 2, 50);
         float t1 = run<128, 128, 1>(B, x, w, bias, res, y, 2, 50);
@@ -41,6 +74,34 @@ int main() {
         float d = run<120, 128, 0>(B, x, w, bias, res, y, 1, 50);
         printf("B=%4d: 256x256 %.1f us (%.1f TF)  64x64 %.1f us (%.1f TF)  120->128 %.1f us\n", B, a, (double)B * 256 * 256 * 9 * 128 / a / 1e6, c,
                (double)B * 64 * 64 * 9 * 128 / c / 1e6, d);
+    }
+    // whole tower, 8 plain + 2 SE blocks x 128 filters: distinct weights per layer vs one shared (L2-hot) set
+    {
+        const int C = 128, NL = 21;
+        const size_t per = (size_t)9 * 16 * C * 2;  // float4 per layer
+        bo_f32x4 *tw; float *tp; bo_tower_layer *tl;
+        CK(hipMalloc(&tw, per * NL * 16)); CK(hipMemset(tw, 0, per * NL * 16));
+        CK(hipMalloc(&tp, 64 * 1024 * 4)); CK(hipMemset(tp, 0, 64 * 1024 * 4));
+        CK(hipMalloc(&tl, NL * sizeof(bo_tower_layer)));
+        for (int variant = 0; variant < 3; variant++) {
+            std::vector<bo_tower_layer> L(NL);
+            for (int l = 0; l < NL; l++) {
+                const bool se = variant != 2 && l >= 17 && (l % 2 == 0);
+                L[l] = {(int)((variant == 1 ? 0 : l) * per), 16, l * 128, l == 0 ? 0 : (l % 2 ? 1 : (se ? 3 : 2)), 4096, 8192, 8, l == NL - 1};
+            }
+            CK(hipMemcpy(tl, L.data(), NL * sizeof(bo_tower_layer), hipMemcpyHostToDevice));
+            for (int B : {256, 512}) {
+                hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+                for (int i = 0; i < 3; i++) hipLaunchKernelGGL((bo_k_tower<128>), dim3(256), dim3(256), 0, 0, x, tw, tp, tl, NL, y, B);
+                (void)hipEventRecord(e0, 0);
+                for (int i = 0; i < 20; i++) hipLaunchKernelGGL((bo_k_tower<128>), dim3(256), dim3(256), 0, 0, x, tw, tp, tl, NL, y, B);
+                (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+                float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+                printf("tower variant %d (%s) B=%d: %.1f us = %.2f us/layer/256 boards\n", variant,
+                       variant == 0 ? "distinct weights" : variant == 1 ? "shared weights" : "distinct, no SE", B, ms * 1000 / 20,
+                       ms * 1000 / 20 / NL / (B / 256));
+            }
+        }
     }
     CK(hipDeviceSynchronize());
     return 0;
