@@ -10,6 +10,7 @@
 #include "bo_nn_fused.h"
 #include "bo_conv.h"
 #include "bo_tower.h"
+#include "bo_tower_wg.h"
 #include "bo_rt.h"
 #include "bo_hostrng.h"
 
@@ -663,7 +664,7 @@ extern "C" int bo_nn_conv3x3(const float *x_dev, const float *wpacked_dev, const
 // ---- the whole residual tower as one persistent kernel (bo_tower.h) ------------------------------------------------
 #if !defined(BO_WAVE_EMU)
 struct bo_tower_s {
-    int channels = 0, n_layers = 0, n_cu = 0, device = 0;
+    int channels = 0, n_layers = 0, n_cu = 0, device = 0, algo = 0;
     bo_f32x4 *wts = nullptr;
     float *params = nullptr;
     bo_tower_layer *layers = nullptr;
@@ -673,24 +674,27 @@ struct bo_tower_s { int unused; };
 #endif
 
 extern "C" int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layers, const float *weights, int64_t n_weights,
-                                  const float *params, int64_t n_params, int channels, int device, bo_tower **out) {
+                                  const float *params, int64_t n_params, int channels, int algo, int device, bo_tower **out) {
 #if defined(BO_WAVE_EMU)
-    (void)layers; (void)n_layers; (void)weights; (void)n_weights; (void)params; (void)n_params; (void)channels; (void)device; (void)out;
+    (void)algo; (void)layers; (void)n_layers; (void)weights; (void)n_weights; (void)params; (void)n_params; (void)channels; (void)device; (void)out;
     return fail(BO_E_CONFIG, "bo_nn_tower is a gfx950-only kernel");
 #else
     static_assert(sizeof(bo_tower_layer_desc) == sizeof(bo_tower_layer), "descriptor layouts must agree");
     if (!layers || !weights || !params || !out || n_layers < 1 || n_layers > 4096) return fail(BO_E_ARG, "bad arguments");
     if (channels != 64 && channels != 128) return fail(BO_E_CONFIG, "bo_nn_tower: channels must be 64 or 128 (two padded boards must fit in 160 KB of LDS)");
     if (n_weights % 4) return fail(BO_E_ARG, "n_weights must be a multiple of 4");
+    if (algo != BO_TOWER_DIRECT && algo != BO_TOWER_WINOGRAD) return fail(BO_E_ARG, "algo must be BO_TOWER_DIRECT or BO_TOWER_WINOGRAD");
     const int C = channels;
     for (int l = 0; l < n_layers; l++) {  // every offset the kernel will form stays inside the two buffers
         const bo_tower_layer_desc &L = layers[l];
-        const int want_t4 = L.kind == 0 ? 16 : C / 8;
+        // K steps per layer: direct = groups of 8 input channels, Winograd = groups of 4; the input conv is padded to 128
+        const int cin = L.kind == 0 ? 128 : C, want_t4 = algo == BO_TOWER_DIRECT ? cin / 8 : cin / 4;
+        const int64_t w4 = algo == BO_TOWER_DIRECT ? (int64_t)9 * want_t4 * C * 2 : (int64_t)want_t4 * (C / 16) * 4 * 64;
         if (L.kind < 0 || L.kind > 3 || (l == 0) != (L.kind == 0)) return fail(BO_E_ARG, "layer " + std::to_string(l) + ": bad kind");
         if (L.kind == 1 && (l + 1 >= n_layers || layers[l + 1].kind < 2)) return fail(BO_E_ARG, "a first conv must be followed by a second conv");
         if (L.kind >= 2 && layers[l - 1].kind != 1) return fail(BO_E_ARG, "a second conv must follow a first conv");
         if (L.t4 != want_t4) return fail(BO_E_ARG, "layer " + std::to_string(l) + ": t4 must be " + std::to_string(want_t4));
-        if (L.w_off4 < 0 || ((int64_t)L.w_off4 + (int64_t)9 * L.t4 * C * 2) * 4 > n_weights) return fail(BO_E_ARG, "weights offset out of range");
+        if (L.w_off4 < 0 || ((int64_t)L.w_off4 + w4) * 4 > n_weights) return fail(BO_E_ARG, "weights offset out of range");
         if (L.bias_off < 0 || (int64_t)L.bias_off + C > n_params) return fail(BO_E_ARG, "bias offset out of range");
         if (L.kind == 3) {
             if (L.hidden < 1 || L.hidden > 16) return fail(BO_E_CONFIG, "SE hidden width must be 1..16");
@@ -705,7 +709,7 @@ extern "C" int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layer
     hipDeviceProp_t prop;
     RT((int)hipGetDeviceProperties(&prop, device));
     bo_tower_s *t = new bo_tower_s();
-    t->channels = C; t->n_layers = n_layers; t->n_cu = prop.multiProcessorCount; t->device = device;
+    t->channels = C; t->n_layers = n_layers; t->n_cu = prop.multiProcessorCount; t->device = device; t->algo = algo;
     int rc = (int)hipMalloc((void **)&t->wts, (size_t)n_weights * 4);
     if (!rc) rc = (int)hipMalloc((void **)&t->params, (size_t)n_params * 4);
     if (!rc) rc = (int)hipMalloc((void **)&t->layers, (size_t)n_layers * sizeof(bo_tower_layer));
@@ -731,7 +735,11 @@ extern "C" int bo_nn_tower_forward(bo_tower *t, const float *x_dev, float *y_dev
     const int slots = t->n_cu * (t->channels == 64 ? 2 : 1);  // 64 filters: two 2-wave workgroups share a CU
     const unsigned grid = (unsigned)(batch < slots ? batch : slots);
     hipStream_t st = (hipStream_t)stream;
-    if (t->channels == 128)
+    if (t->algo == BO_TOWER_WINOGRAD && t->channels == 128)
+        hipLaunchKernelGGL((bo_k_tower_wg<128>), dim3(grid), dim3(512), 0, st, x_dev, t->wts, t->params, t->layers, t->n_layers, y_dev, batch);
+    else if (t->algo == BO_TOWER_WINOGRAD)
+        hipLaunchKernelGGL((bo_k_tower_wg<64>), dim3(grid), dim3(256), 0, st, x_dev, t->wts, t->params, t->layers, t->n_layers, y_dev, batch);
+    else if (t->channels == 128)
         hipLaunchKernelGGL((bo_k_tower<128>), dim3(grid), dim3(256), 0, st, x_dev, t->wts, t->params, t->layers, t->n_layers, y_dev, batch);
     else
         hipLaunchKernelGGL((bo_k_tower<64>), dim3(grid), dim3(128), 0, st, x_dev, t->wts, t->params, t->layers, t->n_layers, y_dev, batch);

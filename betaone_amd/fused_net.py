@@ -12,6 +12,7 @@ elementwise launches PyTorch issues (bias, ReLU, residual add, SE pooling / FCs 
 
   conv="tower":  input conv + all residual blocks are ONE persistent kernel that keeps each board's activations in
                  LDS (csrc/bo_tower.h); 64 or 128 filters.
+  conv="tower_wg": the same with Winograd F(2x2,3x3) convolutions (csrc/bo_tower_wg.h), 2.25x fewer MFMA cycles.
 
 NCHW float32 only; other dtypes/layouts use PolicyValueNet.for_inference().
 """
@@ -36,6 +37,18 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     of four consecutive 32x32x2 MFMA K-steps as one 16-byte load per lane (csrc/bo_conv.h)."""
     co, ci = w.shape[0], w.shape[1]
     return w.reshape(co, ci // 8, 4, 2, 9).permute(4, 1, 0, 3, 2).contiguous()
+
+
+_WG_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+
+
+def pack_conv_weight_winograd(w: torch.Tensor) -> torch.Tensor:
+    """[c_out, c_in, 3, 3] -> U = G g G^T laid out [c_in/4][c_out/16][4][64][4] (include/betaone_engine.h,
+    BO_TOWER_WINOGRAD): element (step, ob, pq, lane, e) = U[4*pq + e][16*ob + (lane & 15)][4*step + (lane >> 4)]."""
+    co, ci = w.shape[0], w.shape[1]
+    u = torch.einsum("ai,ocij,bj->aboc", _WG_G, w.double(), _WG_G).reshape(16, co, ci)  # [pos][oc][ic]
+    u = u.reshape(4, 4, co // 16, 16, ci // 4, 4)  # [pq][e][ob][o16][step][k]
+    return u.permute(4, 2, 0, 5, 3, 1).contiguous().float()  # [step][ob][pq][k][o16][e]
 
 
 def conv3x3_mfma(lib, x, wpacked, bias, c_out, mode=0, residual=None, out=None):
@@ -103,13 +116,13 @@ class FusedPolicyValueNet(nn.Module):
                 self.packed.append((p1, p2))
             self.zero_bias = nn.Parameter(torch.zeros(self.c, device=dev), requires_grad=False)
             self.layout = "nchw+mfma"
-        elif conv == "tower":
-            self._build_tower(dev)
-            self.layout = "nchw+tower"
+        elif conv in ("tower", "tower_wg"):
+            self._build_tower(dev, winograd=conv == "tower_wg")
+            self.layout = "nchw+" + conv
         elif conv != "miopen":
-            raise ValueError("conv must be 'miopen', 'mfma' or 'tower'")
+            raise ValueError("conv must be 'miopen', 'mfma', 'tower' or 'tower_wg'")
 
-    def _build_tower(self, dev):
+    def _build_tower(self, dev, winograd=False):
         """Flatten the trunk into the three host arrays of bo_nn_tower_create (include/betaone_engine.h)."""
         c = self.w_in.shape[0]
         if c not in (64, 128) or self.w_in.shape[1] != 120:
@@ -120,7 +133,7 @@ class FusedPolicyValueNet(nn.Module):
         def add_w(w):
             nonlocal n_w
             off = n_w // 4
-            flat = pack_conv_weight(w.detach().float().cpu()).reshape(-1).numpy()
+            flat = (pack_conv_weight_winograd if winograd else pack_conv_weight)(w.detach().float().cpu()).reshape(-1).numpy()
             wts.append(flat)
             n_w += flat.size
             return off
@@ -135,22 +148,23 @@ class FusedPolicyValueNet(nn.Module):
 
         w0 = torch.zeros((c, 128, 3, 3))
         w0[:, :120] = self.w_in.detach().float().cpu()
-        layers.append([add_w(w0), 16, add_p(self.b_in), 0, 0, 0, 0, 0])
+        ksteps = (lambda cin: cin // 4) if winograd else (lambda cin: cin // 8)
+        layers.append([add_w(w0), ksteps(128), add_p(self.b_in), 0, 0, 0, 0, 0])
         for w1, b1, w2, b2, se in self.blocks:
-            layers.append([add_w(w1), c // 8, add_p(b1), 1, 0, 0, 0, 0])
+            layers.append([add_w(w1), ksteps(c), add_p(b1), 1, 0, 0, 0, 0])
             if se is not None:
                 if se[0].shape[0] > 16:
                     raise E.EngineError("conv='tower' supports SE hidden widths up to 16")
-                layers.append([add_w(w2), c // 8, add_p(b2), 3, add_p(se[0]), add_p(se[1]), se[0].shape[0], 0])
+                layers.append([add_w(w2), ksteps(c), add_p(b2), 3, add_p(se[0]), add_p(se[1]), se[0].shape[0], 0])
             else:
-                layers.append([add_w(w2), c // 8, add_p(b2), 2, 0, 0, 0, 0])
+                layers.append([add_w(w2), ksteps(c), add_p(b2), 2, 0, 0, 0, 0])
         layers[-1][7] = 1
         wts = np.ascontiguousarray(np.concatenate(wts), dtype=np.float32)
         params = np.ascontiguousarray(np.concatenate(params), dtype=np.float32)
         table = np.ascontiguousarray(np.array(layers, dtype=np.int32))
         handle = C.c_void_p()
         rc = self.lib.bo_nn_tower_create(table.ctypes.data, len(layers), wts.ctypes.data, wts.size, params.ctypes.data, params.size, c,
-                                         dev.index if dev.index is not None else torch.cuda.current_device(), C.byref(handle))
+                                         1 if winograd else 0, dev.index if dev.index is not None else torch.cuda.current_device(), C.byref(handle))
         if rc:
             raise E.EngineError(self.lib.bo_last_error().decode())
         self.c, self._tower, self._tower_dev = c, handle, dev
@@ -204,7 +218,7 @@ class FusedPolicyValueNet(nn.Module):
 
     @torch.no_grad()
     def forward(self, x):
-        if self.conv in ("mfma", "tower"):
+        if self.conv in ("mfma", "tower", "tower_wg"):
             x = self._tower_mfma(x) if self.conv == "mfma" else self._tower_forward(x)
             h = self._epi(F.conv2d(x, self.w_head, None), self.b_head)
             p = h[:, :self.n_policy_ch].flatten(1)

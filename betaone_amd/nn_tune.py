@@ -46,7 +46,7 @@ def best_inference_copy(model, batch: int, device, dtype: torch.dtype = torch.fl
         from . import engine as E
         from .fused_net import FusedPolicyValueNet
 
-        for conv in ("miopen", "mfma", "tower"):
+        for conv in ("miopen", "mfma", "tower", "tower_wg"):
             try:
                 fused = FusedPolicyValueNet(model.to(device), conv=conv).to(device)
             except E.EngineError:

@@ -218,19 +218,25 @@ int bo_nn_conv3x3(const float *x_dev, const float *wpacked_dev, const float *bia
                   float *y_dev, int batch, int c_in, int c_out, int mode, void *stream);
 
 /* The whole residual tower (input conv + N residual blocks, /root/reference/network.py:48-118,167-190, BatchNorm
- * folded) as ONE persistent kernel that keeps each board's activations in LDS (csrc/bo_tower.h).  channels in {64, 128}.
- * Layer l: kind 0 = input conv 120 -> C with ReLU (first layer only; weights zero-padded to 128 input channels, t4 = 16),
+ * folded) as ONE persistent kernel that keeps each board's activations in LDS.  channels in {64, 128}.
+ * Layer l: kind 0 = input conv 120 -> C with ReLU (first layer only; weights zero-padded to 128 input channels),
  * 1 = first conv of a block with ReLU, 2 = second conv + skip + ReLU, 3 = second conv + SE gate + skip + ReLU
- * (W1 [hidden][C], W2 [C][hidden], no biases, hidden <= 16); t4 = C/8 for kinds 1-3; `last` = 1 on the final layer only.
- * weights: float32, per layer [tap 9][t4][C][2][4] as for bo_nn_conv3x3, at float4 offset w_off4; params: float32 biases
- * and SE matrices at float offsets.  bo_nn_tower_create validates every offset, copies the three HOST arrays to
- * `device`; bo_nn_tower_forward(x_dev [batch,120,8,8] -> y_dev [batch,C,8,8], NCHW float32) is asynchronous on `stream`. */
+ * (W1 [hidden][C], W2 [C][hidden], no biases, hidden <= 16); `last` = 1 on the final layer only.
+ * algo BO_TOWER_DIRECT (csrc/bo_tower.h): implicit GEMM; t4 = c_in/8; weights per layer [tap 9][t4][C][2][4] as for
+ *   bo_nn_conv3x3.
+ * algo BO_TOWER_WINOGRAD (csrc/bo_tower_wg.h): F(2x2,3x3); t4 = c_in/4 K-steps; weights per layer
+ *   [t4][C/16][4][64][4] with element (step, ob, pq, lane, e) = (G g G^T)[4*pq + e] of filter
+ *   g = W[16*ob + (lane & 15)][4*step + (lane >> 4)], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], position = 4*row + col.
+ * weights: float32 at float4 offset w_off4; params: float32 biases and SE matrices at float offsets.
+ * bo_nn_tower_create validates every offset and copies the three HOST arrays to `device`;
+ * bo_nn_tower_forward(x_dev [batch,120,8,8] -> y_dev [batch,C,8,8], NCHW float32) is asynchronous on `stream`. */
+enum { BO_TOWER_DIRECT = 0, BO_TOWER_WINOGRAD = 1 };
 typedef struct bo_tower_layer_desc {
     int32_t w_off4, t4, bias_off, kind, se_w1_off, se_w2_off, hidden, last;
 } bo_tower_layer_desc;
 typedef struct bo_tower_s bo_tower;
 int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layers, const float *weights, int64_t n_weights,
-                       const float *params, int64_t n_params, int channels, int device, bo_tower **out);
+                       const float *params, int64_t n_params, int channels, int algo, int device, bo_tower **out);
 int bo_nn_tower_forward(bo_tower *tower, const float *x_dev, float *y_dev, int batch, void *stream);
 void bo_nn_tower_destroy(bo_tower *tower);
 

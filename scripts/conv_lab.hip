@@ -5,6 +5,7 @@
 #include <vector>
 #include "../betaone_amd/csrc/bo_conv.h"
 #include "../betaone_amd/csrc/bo_tower.h"
+#include "../betaone_amd/csrc/bo_tower_wg.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
@@ -39,6 +40,33 @@ __global__ void __launch_bounds__(256) k_mfma_peak(float *out, int iters, float 
 }
 
 template <int NACC>
+__global__ void __launch_bounds__(256) k_mfma16_peak(float *out, int iters, float a, float b) {
+    bo_f32x4 acc[NACC];
+    for (int i = 0; i < NACC; i++) acc[i] = bo_f32x4{0, 0, 0, 0};
+    float av = a + threadIdx.x, bw = b;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw + i, acc[i], 0, 0, 0);
+    }
+    float s = 0;
+    for (int i = 0; i < NACC; i++) for (int r = 0; r < 4; r++) s += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int NACC>
+static void peak16(float *out) {
+    const int iters = 1024 * 20 / NACC;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k_mfma16_peak<NACC>, dim3(256), dim3(256), 0, 0, out, iters, 1.0f, 2.0f);
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < 10; i++) hipLaunchKernelGGL(k_mfma16_peak<NACC>, dim3(256), dim3(256), 0, 0, out, iters, 1.0f, 2.0f);
+    (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double us = ms * 1000 / 10, n_mfma = (double)iters * NACC;
+    printf("pure MFMA 16x16x4 f32, %d accumulators: %.1f us for %.0f MFMAs/wave = %.1f ns/MFMA -> %.1f TFLOP/s\n", NACC, us, n_mfma,
+           us * 1000 / n_mfma, n_mfma * 2048 * 4 * 256 / us / 1e6);
+}
+
+template <int NACC>
 static void peak(float *out, int grid) {
     const int iters = 1152 / (8 * NACC) * 20;  // 20 conv layers' worth of MFMAs per wave
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -59,6 +87,7 @@ int main() {
     CK(hipMalloc(&bias, C * 4)); CK(hipMalloc(&w, (size_t)9 * C * C * 4));
     CK(hipMemset(x, 0, (size_t)BMAX * C * 64 * 4)); CK(hipMemset(res, 0, (size_t)BMAX * C * 64 * 4)); CK(hipMemset(bias, 0, C * 4));
     CK(hipMemset(w, 0, (size_t)9 * C * C * 4));
+    peak16<4>(y); peak16<8>(y); peak16<32>(y);
     peak<1>(y, 256); peak<2>(y, 256); peak<4>(y, 256); peak<2>(y, 32); peak<2>(y, 512);
     for (int B : {256, 512, 768, 1024, 2048}) {
         float t0 = run<128, 128, 0>(B, x, w, bias, res, y, 2, 50);
@@ -100,6 +129,35 @@ int main() {
                 printf("tower variant %d (%s) B=%d: %.1f us = %.2f us/layer/256 boards\n", variant,
                        variant == 0 ? "distinct weights" : variant == 1 ? "shared weights" : "distinct, no SE", B, ms * 1000 / 20,
                        ms * 1000 / 20 / NL / (B / 256));
+            }
+        }
+    }
+    // Winograd tower: 16*128*128 floats per layer = 65536 float4
+    {
+        const int NL = 21; const size_t per = 65536;
+        bo_f32x4 *tw; float *tp; bo_tower_layer *tl;
+        CK(hipMalloc(&tw, per * NL * 16)); CK(hipMemset(tw, 0, per * NL * 16));
+        CK(hipMalloc(&tp, 64 * 1024 * 4)); CK(hipMemset(tp, 0, 64 * 1024 * 4));
+        CK(hipMalloc(&tl, NL * sizeof(bo_tower_layer)));
+        for (int variant = 0; variant < 4; variant++) {
+            std::vector<bo_tower_layer> L(NL);
+            for (int l = 0; l < NL; l++) L[l] = {(int)((variant == 1 ? 0 : l) * per), 32, l * 128, l == 0 ? 0 : (l % 2 ? 1 : 2), 0, 0, 0, l == NL - 1};
+            CK(hipMemcpy(tl, L.data(), NL * sizeof(bo_tower_layer), hipMemcpyHostToDevice));
+            for (int B : {256, 512}) {
+                hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+                auto go = [&]() {
+                    if (variant == 2) hipLaunchKernelGGL((bo_k_tower_wg<128, 1>), dim3(256), dim3(512), 0, 0, x, tw, tp, tl, NL, y, B);
+                    else if (variant == 3) hipLaunchKernelGGL((bo_k_tower_wg<128, 2>), dim3(256), dim3(512), 0, 0, x, tw, tp, tl, NL, y, B);
+                    else hipLaunchKernelGGL((bo_k_tower_wg<128, 0>), dim3(256), dim3(512), 0, 0, x, tw, tp, tl, NL, y, B);
+                };
+                for (int i = 0; i < 3; i++) go();
+                (void)hipEventRecord(e0, 0);
+                for (int i = 0; i < 20; i++) go();
+                (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+                float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+                const char *names[4] = {"distinct weights", "shared weights", "no weight loads", "no LDS patch reads"};
+                printf("winograd tower (%s, no SE) B=%d: %.1f us = %.2f us/layer/256 boards\n", names[variant], B,
+                       ms * 1000 / 20, ms * 1000 / 20 / NL / (B / 256));
             }
         }
     }

@@ -40,19 +40,20 @@ from betaone_amd.fused_net import FusedPolicyValueNet, conv3x3_mfma, pack_conv_w
 from betaone_amd import engine as E
 import torch.nn.functional as F
 lib = E.load_hip_library()
-for conv in ("miopen", "mfma", "tower"):
+for conv in ("miopen", "mfma", "tower", "tower_wg"):
     net = FusedPolicyValueNet(base, conv=conv).cuda()
     for B in (256, 512, 1024, 2048):
         x = torch.randn(B, 120, 8, 8, device="cuda")
         ms = bench(net, x)
         print(f"fused conv={conv} B={B}: {ms:.3f} ms  {B/ms*1e3:.0f} pos/s  {gflop*B/ms:.1f} TFLOP/s", flush=True)
-tw = FusedPolicyValueNet(base, conv="tower").cuda()
-class TowerOnly(torch.nn.Module):
-    def forward(self, x): return tw._tower_forward(x)
-for B in (128, 256, 512):
-    x = torch.randn(B, 120, 8, 8, device="cuda")
-    ms = bench(TowerOnly(), x, 100)
-    print(f"tower kernel alone B={B}: {ms*1e3:.1f} us = {ms*1e3/21:.1f} us/layer", flush=True)
+for kind in ("tower", "tower_wg"):
+    tw = FusedPolicyValueNet(base, conv=kind).cuda()
+    class TowerOnly(torch.nn.Module):
+        def forward(self, x): return tw._tower_forward(x)
+    for B in (128, 256, 512):
+        x = torch.randn(B, 120, 8, 8, device="cuda")
+        ms = bench(TowerOnly(), x, 100)
+        print(f"{kind} kernel alone B={B}: {ms*1e3:.1f} us = {ms*1e3/21:.1f} us/layer", flush=True)
 for B in (256, 1024):
     x = torch.randn(B, 128, 8, 8, device="cuda"); w = torch.randn(128, 128, 3, 3, device="cuda") * 0.03
     bias = torch.zeros(128, device="cuda"); wp = pack_conv_weight(w); y = torch.empty_like(x)
