@@ -51,7 +51,7 @@ bo_k_conv3x3(const float *__restrict__ x, const bo_f32x4 *__restrict__ wp, const
     constexpr int PITCH = 100;        // padded 10x10 board
     constexpr int NT = COUT * 2;      // threads: one wave per 32 output channels
     __shared__ bo_f32x4 X[T4 * 2 * PITCH];  // [t4][k][padded pos] x 4 channels e
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     const int k = lane >> 5, j = lane & 31;
     const int oc = wave * 32 + j;                       // A operand row of this lane

@@ -41,7 +41,7 @@ bo_k_tower(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, const 
     __shared__ bo_f32x4 P[GP * 2 * PITCH];
     __shared__ bo_f32x4 Q[GQ * 2 * PITCH];
     __shared__ float pooled[C];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = lane >> 5, j = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), k = lane >> 5, j = lane & 31;
     const int cell = ((j >> 3) + 1) * 10 + (j & 7) + 1;  // padded cell of square j; square j+32 is cell+40
     const int oc_a = wave * 32 + j;                      // A operand row of this lane
 

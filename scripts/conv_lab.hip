@@ -155,7 +155,7 @@ int main() {
                 for (int i = 0; i < 20; i++) go();
                 (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
                 float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
-                const char *names[4] = {"distinct weights", "shared weights", "no weight loads", "no LDS patch reads"};
+                const char *names[4] = {"distinct weights", "shared weights", "no weight loads", "no input transform"};
                 printf("winograd tower (%s, no SE) B=%d: %.1f us = %.2f us/layer/256 boards\n", names[variant], B,
                        ms * 1000 / 20, ms * 1000 / 20 / NL / (B / 256));
             }
