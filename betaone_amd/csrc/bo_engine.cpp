@@ -665,6 +665,7 @@ extern "C" int bo_nn_conv3x3(const float *x_dev, const float *wpacked_dev, const
 #if !defined(BO_WAVE_EMU)
 struct bo_tower_s {
     int channels = 0, n_layers = 0, n_cu = 0, device = 0, algo = 0;
+    int head_channels = 0, head_split = 0, head_w_off = 0, head_b_off = 0;
     bo_f32x4 *wts = nullptr;
     float *params = nullptr;
     bo_tower_layer *layers = nullptr;
@@ -674,9 +675,10 @@ struct bo_tower_s { int unused; };
 #endif
 
 extern "C" int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layers, const float *weights, int64_t n_weights,
-                                  const float *params, int64_t n_params, int channels, int algo, int device, bo_tower **out) {
+                                  const float *params, int64_t n_params, int channels, int algo, const bo_tower_head_desc *head, int device,
+                                  bo_tower **out) {
 #if defined(BO_WAVE_EMU)
-    (void)algo; (void)layers; (void)n_layers; (void)weights; (void)n_weights; (void)params; (void)n_params; (void)channels; (void)device; (void)out;
+    (void)head; (void)algo; (void)layers; (void)n_layers; (void)weights; (void)n_weights; (void)params; (void)n_params; (void)channels; (void)device; (void)out;
     return fail(BO_E_CONFIG, "bo_nn_tower is a gfx950-only kernel");
 #else
     static_assert(sizeof(bo_tower_layer_desc) == sizeof(bo_tower_layer), "descriptor layouts must agree");
@@ -705,11 +707,19 @@ extern "C" int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layer
         if ((L.last != 0) != (l == n_layers - 1)) return fail(BO_E_ARG, "exactly the final layer stores the output");
     }
     if (layers[n_layers - 1].kind < 2) return fail(BO_E_ARG, "the tower must end with a second conv");
+    if (head) {
+        if (algo != BO_TOWER_WINOGRAD) return fail(BO_E_CONFIG, "fused head convolutions need BO_TOWER_WINOGRAD");
+        if (head->channels < 1 || head->channels > 256 || head->split < 0 || head->split > head->channels) return fail(BO_E_ARG, "bad head channels/split");
+        if (head->w_off < 0 || (head->w_off & 3) || (int64_t)head->w_off + (int64_t)((head->channels + 15) / 16) * 16 * C > n_params || head->b_off < 0 ||
+            (int64_t)head->b_off + head->channels > n_params)
+            return fail(BO_E_ARG, "head offsets out of range");
+    }
     RT(rt_set_device(device));
     hipDeviceProp_t prop;
     RT((int)hipGetDeviceProperties(&prop, device));
     bo_tower_s *t = new bo_tower_s();
     t->channels = C; t->n_layers = n_layers; t->n_cu = prop.multiProcessorCount; t->device = device; t->algo = algo;
+    if (head) { t->head_channels = head->channels; t->head_split = head->split; t->head_w_off = head->w_off; t->head_b_off = head->b_off; }
     int rc = (int)hipMalloc((void **)&t->wts, (size_t)n_weights * 4);
     if (!rc) rc = (int)hipMalloc((void **)&t->params, (size_t)n_params * 4);
     if (!rc) rc = (int)hipMalloc((void **)&t->layers, (size_t)n_layers * sizeof(bo_tower_layer));
@@ -726,19 +736,28 @@ extern "C" int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layer
 #endif
 }
 
-extern "C" int bo_nn_tower_forward(bo_tower *t, const float *x_dev, float *y_dev, int batch, void *stream) {
+extern "C" int bo_nn_tower_forward(bo_tower *t, const float *x_dev, float *y_dev, float *head_a_dev, float *head_b_dev, int batch,
+                                   void *stream) {
 #if defined(BO_WAVE_EMU)
-    (void)t; (void)x_dev; (void)y_dev; (void)batch; (void)stream;
+    (void)t; (void)x_dev; (void)y_dev; (void)head_a_dev; (void)head_b_dev; (void)batch; (void)stream;
     return fail(BO_E_CONFIG, "bo_nn_tower is a gfx950-only kernel");
 #else
-    if (!t || !x_dev || !y_dev || batch < 1) return fail(BO_E_ARG, "bad arguments");
+    if (!t || !x_dev || batch < 1) return fail(BO_E_ARG, "bad arguments");
+    bo_tower_head hd;
+    if (t->head_channels > 0) {
+        if ((t->head_split > 0 && !head_a_dev) || (t->head_split < t->head_channels && !head_b_dev)) return fail(BO_E_ARG, "head output buffers missing");
+        hd.channels = t->head_channels; hd.split = t->head_split; hd.w_off = t->head_w_off; hd.b_off = t->head_b_off;
+        hd.out_a = head_a_dev; hd.out_b = head_b_dev;
+    } else if (!y_dev) {
+        return fail(BO_E_ARG, "y_dev is required for a tower without fused heads");
+    }
     const int slots = t->n_cu * (t->channels == 64 ? 2 : 1);  // 64 filters: two 2-wave workgroups share a CU
     const unsigned grid = (unsigned)(batch < slots ? batch : slots);
     hipStream_t st = (hipStream_t)stream;
     if (t->algo == BO_TOWER_WINOGRAD && t->channels == 128)
-        hipLaunchKernelGGL((bo_k_tower_wg<128>), dim3(grid), dim3(512), 0, st, x_dev, t->wts, t->params, t->layers, t->n_layers, y_dev, batch);
+        hipLaunchKernelGGL((bo_k_tower_wg<128>), dim3(grid), dim3(512), 0, st, x_dev, t->wts, t->params, t->layers, t->n_layers, y_dev, batch, hd);
     else if (t->algo == BO_TOWER_WINOGRAD)
-        hipLaunchKernelGGL((bo_k_tower_wg<64>), dim3(grid), dim3(256), 0, st, x_dev, t->wts, t->params, t->layers, t->n_layers, y_dev, batch);
+        hipLaunchKernelGGL((bo_k_tower_wg<64>), dim3(grid), dim3(256), 0, st, x_dev, t->wts, t->params, t->layers, t->n_layers, y_dev, batch, hd);
     else if (t->channels == 128)
         hipLaunchKernelGGL((bo_k_tower<128>), dim3(grid), dim3(256), 0, st, x_dev, t->wts, t->params, t->layers, t->n_layers, y_dev, batch);
     else
@@ -754,4 +773,16 @@ extern "C" void bo_nn_tower_destroy(bo_tower *t) {
     (void)hipFree(t->wts); (void)hipFree(t->params); (void)hipFree(t->layers);
 #endif
     delete t;
+}
+
+extern "C" int bo_nn_value_tail(const float *h_dev, const float *w_dev, const float *bias_dev, float *out_dev, int batch, int hidden, void *stream) {
+#if defined(BO_WAVE_EMU)
+    (void)h_dev; (void)w_dev; (void)bias_dev; (void)out_dev; (void)batch; (void)hidden; (void)stream;
+    return fail(BO_E_CONFIG, "bo_nn_value_tail is a gfx950-only kernel");
+#else
+    if (!h_dev || !w_dev || !bias_dev || !out_dev || batch < 1 || hidden < 1) return fail(BO_E_ARG, "bad arguments");
+    hipLaunchKernelGGL(bo_k_value_tail, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h_dev, w_dev, bias_dev, out_dev, batch, hidden);
+    RT((int)hipGetLastError());
+    return BO_OK;
+#endif
 }

@@ -71,4 +71,16 @@ bo_k_se_residual(float *__restrict__ x, const float *__restrict__ bias, const fl
         xb[i] = v > 0.0f ? v : 0.0f;
     }
 }
+
+// value tail: out[b] = tanh(w . h[b] + bias) (value_fc2 + tanh, /root/reference/network.py:116-118,197); one wave per board
+extern "C" __global__ void __launch_bounds__(256)
+bo_k_value_tail(const float *__restrict__ h, const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ out, int B, int H) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    float a = 0.0f;
+    for (int i = lane; i < H; i += 64) a += h[(size_t)b * H + i] * w[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
+    if (lane == 0) out[b] = tanhf(a + bias[0]);
+}
 #endif

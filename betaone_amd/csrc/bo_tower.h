@@ -33,6 +33,13 @@ struct bo_tower_layer {
     int last;       // 1: also store the result to y (NCHW)
 };
 
+// the two 1x1 head convolutions fused behind the tower (bo_tower_wg.h): channels [0, split) go to out_a [B][split][64],
+// channels [split, channels) to out_b [B][channels - split][64]; weights [channels][C] and bias in params
+struct bo_tower_head {
+    int channels = 0, split = 0, w_off = 0, b_off = 0;
+    float *out_a = nullptr, *out_b = nullptr;
+};
+
 template <int C>
 __global__ void __launch_bounds__(C * 2)
 bo_k_tower(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, const float *__restrict__ params,

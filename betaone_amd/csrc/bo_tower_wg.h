@@ -34,7 +34,7 @@
 template <int C, int LAB = 0>
 __global__ void __launch_bounds__(C * 4)
 bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, const float *__restrict__ params,
-              const bo_tower_layer *__restrict__ layers, int n_layers, float *__restrict__ y, int B) {
+              const bo_tower_layer *__restrict__ layers, int n_layers, float *__restrict__ y, int B, bo_tower_head head = bo_tower_head{}) {
     constexpr int IMG = 100, NT = C * 4, CP = 128, CIN0 = 120, OB = C / 16;
     __shared__ __attribute__((aligned(16))) float P[CP * IMG];  // staged input planes / mid activation of a block
     __shared__ __attribute__((aligned(16))) float Q[C * IMG];   // block input
@@ -222,7 +222,7 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
                         skip[r][e] = fmaxf(t, 0.0f);
                     }
                     c[0] = skip[r][0]; c[1] = skip[r][1]; c[10] = skip[r][2]; c[11] = skip[r][3];
-                    if (L.last) {
+                    if (L.last && y) {
                         float *g2 = yb + oc * 64 + 16 * ty + 2 * tx;
                         *reinterpret_cast<float2 *>(g2) = float2{skip[r][0], skip[r][1]};
                         *reinterpret_cast<float2 *>(g2 + 8) = float2{skip[r][2], skip[r][3]};
@@ -230,6 +230,37 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
                 }
             }
             __syncthreads();
+        }
+        // ---- the two 1x1 head convolutions + ReLU (network.py:101-113,191-195) on the tower output still in Q:
+        // D[oc][square] = sum_ic Wh[oc][ic] * Q[ic][square], one 16x16 job per (16 head channels, 16 squares) ----
+        if (head.channels > 0) {
+            // head weights, packed on the host: Whp[mb][g][lane][e] = Wh[16*mb + (lane&15)][4*(4*g + e) + (lane>>4)] (0 beyond the
+            // last channel): the A fragments of four K-steps per global_load_dwordx4, all issued before the first MFMA
+            const bo_f32x4 *whp = reinterpret_cast<const bo_f32x4 *>(params + head.w_off);
+            const float *bh = params + head.b_off;
+            const int jobs = ((head.channels + 15) >> 4) * 4;
+            for (int job = wave; job < jobs; job += NT / 64) {
+                const int mb = job >> 2, nb = job & 3, sq = 16 * nb + n, cell = ((sq >> 3) + 1) * 10 + (sq & 7) + 1;
+                const int oc_d = 16 * mb + 4 * kq;
+                bo_f32x4 aw[C / 16];
+#pragma unroll
+                for (int g = 0; g < C / 16; g++) aw[g] = whp[(mb * (C / 16) + g) * 64 + lane];
+                bo_f32x4 hacc = {0, 0, 0, 0};
+#pragma unroll
+                for (int g = 0; g < C / 16; g++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        hacc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[g][e], Q[(4 * (4 * g + e) + kq) * IMG + cell], hacc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int oc = oc_d + r;
+                    if (oc < head.channels) {
+                        const float t = fmaxf(hacc[r] + bh[oc], 0.0f);
+                        if (oc < head.split) head.out_a[((size_t)b * head.split + oc) * 64 + sq] = t;
+                        else head.out_b[((size_t)b * (head.channels - head.split) + (oc - head.split)) * 64 + sq] = t;
+                    }
+                }
+            }
         }
     }
 }

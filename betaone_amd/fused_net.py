@@ -159,12 +159,22 @@ class FusedPolicyValueNet(nn.Module):
             else:
                 layers.append([add_w(w2), ksteps(c), add_p(b2), 2, 0, 0, 0, 0])
         layers[-1][7] = 1
+        head = None
+        if winograd:  # the two 1x1 head convolutions run behind the tower on the LDS-resident output
+            self._head_ch, self._head_split = self.w_head.shape[0], self.n_policy_ch
+            mb = (self._head_ch + 15) // 16
+            wh = torch.zeros((mb * 16, c))
+            wh[:self._head_ch] = self.w_head.detach().float().cpu().reshape(self._head_ch, c)
+            whp = wh.reshape(mb, 16, c // 16, 4, 4).permute(0, 2, 4, 1, 3).contiguous()  # [mb][g][k][o16][e], ic = 16g + 4e + k
+            if n_p % 4:
+                add_p(torch.zeros(4 - n_p % 4))
+            head = np.array([self._head_ch, self._head_split, add_p(whp), add_p(self.b_head)], dtype=np.int32)
         wts = np.ascontiguousarray(np.concatenate(wts), dtype=np.float32)
         params = np.ascontiguousarray(np.concatenate(params), dtype=np.float32)
         table = np.ascontiguousarray(np.array(layers, dtype=np.int32))
         handle = C.c_void_p()
         rc = self.lib.bo_nn_tower_create(table.ctypes.data, len(layers), wts.ctypes.data, wts.size, params.ctypes.data, params.size, c,
-                                         1 if winograd else 0, dev.index if dev.index is not None else torch.cuda.current_device(), C.byref(handle))
+                                         1 if winograd else 0, head.ctypes.data if head is not None else None, dev.index if dev.index is not None else torch.cuda.current_device(), C.byref(handle))
         if rc:
             raise E.EngineError(self.lib.bo_last_error().decode())
         self.c, self._tower, self._tower_dev = c, handle, dev
@@ -178,15 +188,36 @@ class FusedPolicyValueNet(nn.Module):
         except Exception:  # interpreter shutdown
             pass
 
-    def _tower_forward(self, x):
+    def _tower_forward(self, x, heads=False):
+        """Tower output [B, C, 8, 8]; with heads=True (conv='tower_wg') the ReLU'd policy / value planes, flattened."""
         if x.device != self._tower_dev or x.dtype != torch.float32 or x.shape[1:] != (120, 8, 8):
             raise E.EngineError("tower: x must be float32 [B, 120, 8, 8] on the tower's device")
         x = x.contiguous()
-        y = torch.empty((x.shape[0], self.c, 8, 8), dtype=torch.float32, device=x.device)
-        rc = self.lib.bo_nn_tower_forward(self._tower, x.data_ptr(), y.data_ptr(), x.shape[0], torch.cuda.current_stream(x.device).cuda_stream)
+        B = x.shape[0]
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        if heads:
+            pa = torch.empty((B, self._head_split * 64), dtype=torch.float32, device=x.device)
+            pb = torch.empty((B, (self._head_ch - self._head_split) * 64), dtype=torch.float32, device=x.device)
+            rc = self.lib.bo_nn_tower_forward(self._tower, x.data_ptr(), None, pa.data_ptr(), pb.data_ptr(), B, stream)
+            out = (pa, pb)
+        else:
+            y = torch.empty((B, self.c, 8, 8), dtype=torch.float32, device=x.device)
+            wg = self.conv == "tower_wg"
+            dummy = torch.empty((2, B, self._head_ch * 64), dtype=torch.float32, device=x.device) if wg else None
+            rc = self.lib.bo_nn_tower_forward(self._tower, x.data_ptr(), y.data_ptr(), dummy[0].data_ptr() if wg else None,
+                                              dummy[1].data_ptr() if wg else None, B, stream)
+            out = y
         if rc:
             raise E.EngineError(self.lib.bo_last_error().decode())
-        return y
+        return out
+
+    def _value_tail(self, h):
+        out = torch.empty((h.shape[0], 1), dtype=torch.float32, device=h.device)
+        rc = self.lib.bo_nn_value_tail(h.data_ptr(), self.value_fc2.weight.data_ptr(), self.value_fc2.bias.data_ptr(), out.data_ptr(), h.shape[0],
+                                       h.shape[1], torch.cuda.current_stream(h.device).cuda_stream)
+        if rc:
+            raise E.EngineError(self.lib.bo_last_error().decode())
+        return out
 
     def _epi(self, x, bias, res=None):
         B, C = x.shape[0], x.shape[1]
@@ -218,7 +249,11 @@ class FusedPolicyValueNet(nn.Module):
 
     @torch.no_grad()
     def forward(self, x):
-        if self.conv in ("mfma", "tower", "tower_wg"):
+        if self.conv == "tower_wg":  # tower + head convolutions in one kernel, then 2 GEMMs and the value tail
+            p, v = self._tower_forward(x, heads=True)
+            h = torch._addmm_activation(self.value_fc1.bias, v, self.value_fc1.weight.t())  # relu(fc1)
+            return self.policy_fc(p), self._value_tail(h)
+        if self.conv in ("mfma", "tower"):
             x = self._tower_mfma(x) if self.conv == "mfma" else self._tower_forward(x)
             h = self._epi(F.conv2d(x, self.w_head, None), self.b_head)
             p = h[:, :self.n_policy_ch].flatten(1)

@@ -14,15 +14,24 @@ import torch
 
 
 def _time_forward(net, x, reps: int = 8) -> float:
+    """Seconds per forward: best of three timed rounds after at least 50 ms of warm-up (the first launches after the
+    host-side weight packing of a candidate run at idle clocks and would misrank it)."""
     with torch.no_grad():
-        for _ in range(3):
-            net(x)
-        torch.cuda.synchronize(x.device)
         t0 = time.perf_counter()
-        for _ in range(reps):
+        n = 0
+        while n < 3 or time.perf_counter() - t0 < 0.05:
             net(x)
-        torch.cuda.synchronize(x.device)
-    return (time.perf_counter() - t0) / reps
+            torch.cuda.synchronize(x.device)
+            n += 1
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                net(x)
+            torch.cuda.synchronize(x.device)
+            t = (time.perf_counter() - t0) / reps
+            best = t if best is None or t < best else best
+    return best
 
 
 def best_inference_copy(model, batch: int, device, dtype: torch.dtype = torch.float32, verbose: bool = False):
