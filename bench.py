@@ -136,6 +136,38 @@ def select_roofline(args, device):
             "levels_per_launch": levels, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(t * 1e3, 4)}
 
 
+def nn_roofline(net, batch, device):
+    """MFMA roofline of the evaluate stage's tower kernel (csrc/bo_tower_wg.h / bo_tower.h), timed with events on the
+    stream it is launched on.  `achieved` counts the fp32 MFMA flops the kernel executes (Winograd F(2x2,3x3): 16
+    multiplies per 2x2 output tile and input channel, input conv padded to 128 channels); `algorithmic` is the direct
+    3x3 convolution's flop count for the same layers (what MIOpen / the reference's net would be charged)."""
+    conv = getattr(net, "conv", None)
+    if conv not in ("tower", "tower_wg"):
+        return None
+    C, n_conv = net.c, 1 + 2 * len(net.blocks)
+    x = torch.rand((batch, 120, 8, 8), device=device)
+    with torch.no_grad():
+        for _ in range(5):
+            net._tower_forward(x, heads=conv == "tower_wg")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 50
+        e0.record()
+        for _ in range(reps):
+            net._tower_forward(x, heads=conv == "tower_wg")
+        e1.record()
+        e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    per_mac = 16 * 16 if conv == "tower_wg" else 9 * 64       # multiplies per (c_in, c_out) pair and board
+    executed = 2.0 * per_mac * C * (128 + (n_conv - 1) * C) * batch
+    algorithmic = 2.0 * 9 * 64 * C * (120 + (n_conv - 1) * C) * batch
+    peak = 157.3  # TFLOP/s dense fp32 MFMA: 256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz (MI355X_MICROARCH.md)
+    return {"bound": "mfma", "kernel": "bo_k_tower_wg" if conv == "tower_wg" else "bo_k_tower", "achieved": round(executed / us / 1e6, 1), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(executed / us / 1e6 / peak, 4), "traffic": None, "avg_launch_us": round(us, 1),
+            "boards_per_launch": batch, "conv_layers": n_conv,
+            "algorithmic_direct_conv_tflops": round(algorithmic / us / 1e6, 1),
+            "note": "fp32 v_mfma_f32_16x16x4_f32; one workgroup per board, activations LDS-resident for the whole tower"}
+
+
 def step_roofline(ro, n_steps_timed):
     """The in-loop tree step kernel: algorithmic bytes from the engine's own counters."""
     st = ro.eng.status()
@@ -279,6 +311,10 @@ def main():
     torch.cuda.empty_cache()
     if rank == 0 and not args.no_roofline:
         out["roofline"] = select_roofline(args, device)
+        if not args.fast and args.net_dtype == "fp32":
+            rn = nn_roofline(net, G, device)
+            if rn:
+                out["roofline_nn"] = rn
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # "on rank 0 at N=1 only"
         out["cpu_baseline"] = cpu_baseline(args)
     if dist is not None:
