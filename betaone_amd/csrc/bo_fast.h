@@ -183,7 +183,7 @@ BO_KERNEL void bo_k_fast_step(Eng e, FastEng f, const float *policy, const float
                 bo_sync();
                 bool chk;
                 const int n = bo_movegen(P, sh.moves, &chk);
-                t = terminal_eval(e, g, leaf, P, sh.moves, n, chk, sh.moves2);
+                t = terminal_eval(e, g, leaf, P, sh.moves, n, chk, sh.moves2, sh.chain);
                 slot = -1;
                 if (lane == 0) { e.term[no + leaf] = (signed char)t; e.eval_slot[no + leaf] = -1; }
                 if (t == 0 && n_rows < L) {  // becomes NN row n_rows

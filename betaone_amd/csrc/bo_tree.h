@@ -95,25 +95,43 @@ BO_DEV float bo_expf(float x) {
 #endif
 }
 struct bo_f4 { float x, y, z, w; };
-// max and sum(exp(x - max)) over one 4672-float policy row: 16-byte loads, 1168 float4 over 64 lanes
-BO_DEV void row_max_sum(const float *row, float *mx_out, float *sum_out) {
+// max and sum(exp(x - max)) over one 4672-float policy row: 1168 float4 over 64 lanes.  All 19 loads of a lane are
+// issued before the first use (one memory round trip for the 18.7 KB row; as two dependent-looking loops the row
+// cost ~40 serial misses = 25 k cycles of a 87 k-cycle game-step) and both passes run from registers.
+#if defined(BO_WAVE_EMU)
+#define BO_UNROLL
+#else
+#define BO_UNROLL _Pragma("unroll")
+#endif
+constexpr int BO_ROW_N4 = BO_NUM_ACTIONS / 4, BO_ROW_IT = (BO_ROW_N4 + 63) / 64;
+// v[] = this lane's float4s of the row (-inf beyond the end); returns max and sum(exp(x - max)) over the row
+BO_DEV void row_load_max_sum(const float *row, bo_f4 (&v)[BO_ROW_IT], float *mx_out, float *sum_out) {
     const bo_f4 *r4 = reinterpret_cast<const bo_f4 *>(row);
     const int lane = bo_lane();
-    float mx = -__builtin_inff();
-    for (int k = lane; k < BO_NUM_ACTIONS / 4; k += 64) {
-        const bo_f4 v = r4[k];
-        const float a = v.x > v.y ? v.x : v.y, b = v.z > v.w ? v.z : v.w;
+    const float ninf = -__builtin_inff();
+    BO_UNROLL
+    for (int i = 0; i < BO_ROW_IT; i++) {
+        const int k = lane + 64 * i;
+        v[i] = k < BO_ROW_N4 ? r4[k] : bo_f4{ninf, ninf, ninf, ninf};
+    }
+    float mx = ninf;
+    BO_UNROLL
+    for (int i = 0; i < BO_ROW_IT; i++) {
+        const float a = v[i].x > v[i].y ? v[i].x : v[i].y, b = v[i].z > v[i].w ? v[i].z : v[i].w;
         const float c = a > b ? a : b;
         mx = c > mx ? c : mx;
     }
     mx = bo_wave_max_f(mx);
     float sum = 0.0f;
-    for (int k = lane; k < BO_NUM_ACTIONS / 4; k += 64) {
-        const bo_f4 v = r4[k];
-        sum += (bo_expf(v.x - mx) + bo_expf(v.y - mx)) + (bo_expf(v.z - mx) + bo_expf(v.w - mx));
-    }
+    BO_UNROLL
+    for (int i = 0; i < BO_ROW_IT; i++)
+        if (lane + 64 * i < BO_ROW_N4) sum += (bo_expf(v[i].x - mx) + bo_expf(v[i].y - mx)) + (bo_expf(v[i].z - mx) + bo_expf(v[i].w - mx));
     *mx_out = mx;
     *sum_out = bo_wave_sum_f(sum);
+}
+BO_DEV void row_max_sum(const float *row, float *mx_out, float *sum_out) {
+    bo_f4 v[BO_ROW_IT];
+    row_load_max_sum(row, v, mx_out, sum_out);
 }
 
 BO_DEV int bo_uniform(int v) {
@@ -126,33 +144,61 @@ BO_DEV int bo_uniform(int v) {
 
 // ---- chain walk: the positions python-chess revisits when it pops back to the last irreversible
 // move (Board.is_repetition / can_claim_threefold_repetition).  Calls f(const DPos&) per entry.
-template <class F> BO_DEV int chain_walk(const Eng &e, int g, int leaf, F f) {
+#define BO_CHAIN_CAP 192  // a reversible chain is shorter than the halfmove clock (< 150 where this is called)
+struct ChainBuf {
+    unsigned long long hash[BO_CHAIN_CAP];
+    int ref[BO_CHAIN_CAP];  // node index (>= 0) or -1 - ply of the game history
+};
+BO_DEV DPos chain_entry(const Eng &e, int g, int ref) {
+    return ref >= 0 ? e.npos[NOFF(e, g) + ref] : e.gpos[(size_t)g * e.c.PLY_CAP + (-1 - ref)];
+}
+// Collects (transposition hash, reference) of every chain entry into LDS and returns their number.  The in-tree part
+// follows parent links (a few levels); the game-history part -- up to ~100 plies in drawn-out endgames, the tail
+// of the step kernel when it was walked one dependent 80-byte load at a time -- is found and read by all lanes at
+// once: ballot for the last irreversible ply, then one hash per lane.
+BO_DEV int chain_collect(const Eng &e, int g, int leaf, ChainBuf &cb) {
     const size_t no = NOFF(e, g);
+    const int lane = bo_lane();
     int cnt = 0, x = leaf;
+    bool stop = false;
     while (x > 0) {
-        if (e.npos[no + x].flags & F_IRREV) return cnt;
+        if (e.npos[no + x].flags & F_IRREV) { stop = true; break; }
         x = e.parent[no + x];
-        f(e.npos[no + x]);
+        if (lane == 0 && cnt < BO_CHAIN_CAP) { cb.hash[cnt] = e.npos[no + x].khash; cb.ref[cnt] = x; }
         cnt++;
     }
-    const DPos *gp = e.gpos + (size_t)g * e.c.PLY_CAP;
-    int j = e.ply[g];
-    while (j > 0 && !(gp[j].flags & F_IRREV)) {
-        j--;
-        f(gp[j]);
-        cnt++;
+    if (!stop) {
+        const DPos *gp = e.gpos + (size_t)g * e.c.PLY_CAP;
+        const int ply = e.ply[g];
+        int J = 0;  // largest j in [1, ply] whose position was reached by an irreversible move, else 0
+        for (int base = ply; base > 0; base -= 64) {
+            const int j = base - lane;
+            const bool irr = j > 0 && (gp[j].flags & F_IRREV);
+            const unsigned long long m = bo_ballot(irr);
+            if (m) { J = base - __builtin_ctzll(m); break; }
+        }
+        const int nh = ply - J;  // entries ply-1 .. J
+        for (int i = lane; i < nh; i += 64) {
+            if (cnt + i < BO_CHAIN_CAP) { const int j = ply - 1 - i; cb.hash[cnt + i] = gp[j].khash; cb.ref[cnt + i] = -1 - j; }
+        }
+        cnt += nh;
     }
+    bo_sync();
     return cnt;
 }
 
 // Board.outcome(claim_draw=True) of node `leaf` whose legal moves are mv[0..n): 0 ongoing, 1 mate, 2 draw
-BO_DEV int terminal_eval(const Eng &e, int g, int leaf, const DPos &P, const bo_mv *mv, int n, bool in_check, bo_mv *scratch) {
+BO_DEV int terminal_eval(const Eng &e, int g, int leaf, const DPos &P, const bo_mv *mv, int n, bool in_check, bo_mv *scratch, ChainBuf &cb) {
     if (n == 0 && in_check) return 1;
     if (insufficient_material(P)) return 2;
     if (n == 0) return 2;
     if (P.halfmove >= 150) return 2;
-    int self = 1;
-    int npred = chain_walk(e, g, leaf, [&](const DPos &E) { if (E.khash == P.khash && key_equal(E, P)) self++; });
+    const int npred = chain_collect(e, g, leaf, cb);
+    const int nn = npred < BO_CHAIN_CAP ? npred : BO_CHAIN_CAP;
+    int same = 0;
+    for (int i = bo_lane(); i < nn; i += 64)
+        if (cb.hash[i] == P.khash && key_equal(chain_entry(e, g, cb.ref[i]), P)) same++;
+    const int self = 1 + bo_wave_sum(same);
     if (self >= 5) return 2;
     if (P.halfmove >= 100) return 2;
     if (P.halfmove >= 99) {  // can_claim_fifty_moves: some non-zeroing move reaches 100 without ending the game
@@ -176,7 +222,8 @@ BO_DEV int terminal_eval(const Eng &e, int g, int leaf, const DPos &P, const bo_
             DPos c = P;
             if (act) c = make_move(P, m);
             int cc = 0;
-            chain_walk(e, g, leaf, [&](const DPos &E) { if (act && E.khash == c.khash && key_equal(E, c)) cc++; });
+            for (int i = 0; i < nn; i++)
+                if (act && cb.hash[i] == c.khash && key_equal(chain_entry(e, g, cb.ref[i]), c)) cc++;
             if (bo_ballot(act && cc >= 2)) hit = true;
         }
         if (hit) return 2;
@@ -484,6 +531,7 @@ struct StepShared {
     int path[BO_PATH_CAP];
     float probs[BO_NUM_ACTIONS];
     int rank_of[2 * BO_CH_CAP];
+    ChainBuf chain;
 };
 
 // softmax row -> LDS (policy_kind LOGITS) or copy (PROBS)
@@ -491,10 +539,18 @@ BO_DEV void load_probs(const float *row, int kind, float *out) {
     const int lane = bo_lane();
     if (kind == POLICY_PROBS) {
         for (int i = lane; i < BO_NUM_ACTIONS; i += 64) out[i] = row[i];
-    } else {
+    } else {  // the row stays in registers between the reduction and the normalised write
         float mx, sum;
-        row_max_sum(row, &mx, &sum);
-        for (int i = lane; i < BO_NUM_ACTIONS; i += 64) out[i] = bo_expf(row[i] - mx) / sum;
+        bo_f4 v[BO_ROW_IT];
+        row_load_max_sum(row, v, &mx, &sum);
+        BO_UNROLL
+        for (int i = 0; i < BO_ROW_IT; i++) {
+            const int k = lane + 64 * i;
+            if (k < BO_ROW_N4) {
+                out[4 * k] = bo_expf(v[i].x - mx) / sum; out[4 * k + 1] = bo_expf(v[i].y - mx) / sum;
+                out[4 * k + 2] = bo_expf(v[i].z - mx) / sum; out[4 * k + 3] = bo_expf(v[i].w - mx) / sum;
+            }
+        }
     }
     bo_sync();
 }
@@ -639,7 +695,7 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
             const DPos P = e.npos[no + leaf];
             bool chk;
             const int n = bo_movegen(P, sh.moves, &chk);
-            t = terminal_eval(e, g, leaf, P, sh.moves, n, chk, sh.moves2);
+            t = terminal_eval(e, g, leaf, P, sh.moves, n, chk, sh.moves2, sh.chain);
             if (lane == 0) e.term[no + leaf] = (signed char)t;
             if (t == 0) {  // it will be evaluated now: keep its ordered legal moves for apply_leaf
                 for (int j = lane; j < n; j += 64) e.req_moves[(size_t)g * BO_MAX_MOVES + j] = sh.moves[j];
@@ -713,7 +769,7 @@ BO_DEV void root_prepare(const Eng &e, int g, StepShared &sh) {
     bo_sync();
     bool chk;
     const int n = bo_movegen(P, sh.moves, &chk);
-    const int t = terminal_eval(e, g, 0, P, sh.moves, n, chk, sh.moves2);
+    const int t = terminal_eval(e, g, 0, P, sh.moves, n, chk, sh.moves2, sh.chain);
     for (int j = lane; j < n; j += 64) {
         e.root_moves[(size_t)g * BO_MAX_MOVES + j] = sh.moves[j];
         e.req_moves[(size_t)g * BO_MAX_MOVES + j] = sh.moves[j];
