@@ -751,7 +751,7 @@ extern "C" int bo_nn_tower_forward(bo_tower *t, const float *x_dev, float *y_dev
     } else if (!y_dev) {
         return fail(BO_E_ARG, "y_dev is required for a tower without fused heads");
     }
-    const int slots = t->n_cu * (t->channels == 64 ? 2 : 1);  // 64 filters: two 2-wave workgroups share a CU
+    const int slots = t->n_cu * (t->channels == 64 && t->algo == BO_TOWER_DIRECT ? 2 : 1);  // direct, 64 filters: two 2-wave workgroups share a CU
     const unsigned grid = (unsigned)(batch < slots ? batch : slots);
     hipStream_t st = (hipStream_t)stream;
     if (t->algo == BO_TOWER_WINOGRAD && t->channels == 128)

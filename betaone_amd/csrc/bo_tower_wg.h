@@ -30,7 +30,8 @@
 #include <hip/hip_runtime.h>
 #include "bo_tower.h"
 
-// LAB (scripts/conv_lab.hip only): 0 = the kernel; 1 = no weight loads; 2 = no input transform
+// LAB (scripts/conv_lab.hip only): 0 = the kernel; 1 = no weight loads; 2 = no input transform; 4 = no epilogue (wrong
+// results); 5 = no chunk barriers (wrong results); 6 = 1 + 2 + 4 + 5
 template <int C, int LAB = 0>
 __global__ void __launch_bounds__(C * 4)
 bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, const float *__restrict__ params,
@@ -39,7 +40,7 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
     __shared__ __attribute__((aligned(16))) float P[CP * IMG];  // staged input planes / mid activation of a block
     __shared__ __attribute__((aligned(16))) float Q[C * IMG];   // block input
     __shared__ bo_f32x4 V[2][16 * 4 * 16];                      // transformed patches: [buffer][channel 16][pos quad][tile]
-    __shared__ float pooled[C];
+    __shared__ float pooled[C], hid[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kq = lane >> 4, n = lane & 15;
     const int ty = n >> 2, tx = n & 3;
     const int patch = 20 * ty + 2 * tx;       // top-left of the tile's 4x4 input patch in a padded 10x10 image
@@ -103,7 +104,7 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
         const bo_f32x4 *src = &V[buf][(4 * (sl_next < 0 ? 0 : sl_next) + kq) * 64 + n];
 #pragma unroll
         for (int pq = 0; pq < 4; pq++) {
-            if (LAB != 1) an[pq] = wb[pq * 64];
+            if (LAB != 1 && LAB != 6) an[pq] = wb[pq * 64];
             if (sl_next >= 0) vn[pq] = src[pq * 16];
 #pragma unroll
             for (int e = 0; e < 4; e++) acc[4 * pq + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[pq][e], v[pq][e], acc[4 * pq + e], 0, 0, 0);
@@ -137,21 +138,21 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
             for (int r = 0; r < 4; r++) bv[r] = params[L.bias_off + oc0 + r];
 #pragma unroll
             for (int pos = 0; pos < 16; pos++) acc[pos] = bo_f32x4{0, 0, 0, 0};
-            if (LAB != 2 && my_chunk(0)) transform(img, 0);
+            if (LAB != 2 && LAB != 6 && my_chunk(0)) transform(img, 0);
             __syncthreads();
             // One chunk = 4 K-steps = one turn of the weight-set rotation: step s multiplies with set s%4 while the weights
             // of step s+3 (possibly the first steps of the next layer) are loaded into set (s+3)%4.
             const int nk = L.t4, nchunks = nk >> 2;
             for (int c = 0; c < nchunks; c++) {
                 const int s = 4 * c, buf = c & 1, t4 = s + 4, t5 = s + 5, t6 = s + 6;
-                if (LAB != 2 && c + 1 < nchunks && my_chunk(c + 1)) transform(img, c + 1);
+                if (LAB != 2 && LAB != 6 && c + 1 < nchunks && my_chunk(c + 1)) transform(img, c + 1);
                 read_b(va, buf, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 kstep(a0, va, a3, vb, buf, 1, L.w_off4, s + 3);
                 kstep(a1, vb, a0, va, buf, 2, t4 < nk ? L.w_off4 : Ln.w_off4, t4 < nk ? t4 : t4 - nk);
                 kstep(a2, va, a1, vb, buf, 3, t5 < nk ? L.w_off4 : Ln.w_off4, t5 < nk ? t5 : t5 - nk);
                 kstep(a3, vb, a2, va, buf, -1, t6 < nk ? L.w_off4 : Ln.w_off4, t6 < nk ? t6 : t6 - nk);
-                if (c + 1 < nchunks) __syncthreads();  // V[buf] is free for chunk c+2, V[buf^1] is complete
+                if (LAB != 5 && LAB != 6 && c + 1 < nchunks) __syncthreads();  // V[buf] is free for chunk c+2, V[buf^1] is complete
             }
 
             // ---- output transform Y = A^T M A per row r: M[i][j] = acc[4i+j][r] ----
@@ -169,7 +170,9 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
                 o[r][2] = t1[0] + t1[1] + t1[2] + bv[r];
                 o[r][3] = t1[1] - t1[2] - t1[3] + bv[r];
             }
-            if (L.kind <= 1) {
+            if (LAB == 4 || LAB == 6) {
+                if (o[0][0] == 123.456f) Q[tid] = o[1][1] + o[2][2] + o[3][3];
+            } else if (L.kind <= 1) {
                 float *out = L.kind == 0 ? Q : P;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -184,6 +187,18 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
             } else {
                 float gate[4] = {1.0f, 1.0f, 1.0f, 1.0f};
                 if (L.kind == 3) {
+                    // SE gate (network.py:33-45).  Weights first, so their latency hides behind the pooling: wave h owns hidden
+                    // unit h (W1 row h at channels lane, lane+64), lane (lane&15) of wave w owns the gate of channel 16w + (lane&15)
+                    const float *w1 = params + L.se_w1_off, *w2 = params + L.se_w2_off;
+                    constexpr int NWAVE = NT / 64;
+                    float w1a[2] = {0.0f, 0.0f}, w1b[2] = {0.0f, 0.0f}, w2r[16];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int h = wave + u * NWAVE;
+                        if (h < L.hidden) { w1a[u] = w1[h * C + lane]; w1b[u] = C > 64 ? w1[h * C + 64 + lane] : 0.0f; }
+                    }
+#pragma unroll
+                    for (int h = 0; h < 16; h++) w2r[h] = h < L.hidden ? w2[(wave * 16 + n) * L.hidden + h] : 0.0f;
                     // channel means of conv + bias over the 64 squares = 16 tiles x 4 outputs (AdaptiveAvgPool2d(1))
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
@@ -193,20 +208,21 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
                         if (n == 0) pooled[oc0 + r] = s * (1.0f / 64.0f);
                     }
                     __syncthreads();
-                    // hidden = relu(W1 mean) (every wave, redundantly); gate = sigmoid(W2 hidden) for channel 16*wave + (lane&15)
-                    const float *w1 = params + L.se_w1_off, *w2 = params + L.se_w2_off;
-                    const int oc_g = wave * 16 + n;
-                    float a = 0.0f;
 #pragma unroll
-                    for (int h = 0; h < 16; h++) {
+                    for (int u = 0; u < 2; u++) {  // hidden = relu(W1 mean): one wave reduction per hidden unit
+                        const int h = wave + u * NWAVE;
                         if (h < L.hidden) {
-                            float p = 0.0f;
-                            for (int c = lane; c < C; c += 64) p += w1[h * C + c] * pooled[c];
+                            float p = w1a[u] * pooled[lane] + (C > 64 ? w1b[u] * pooled[64 + lane] : 0.0f);
 #pragma unroll
                             for (int m = 32; m >= 1; m >>= 1) p += __shfl_xor(p, m);
-                            a += w2[oc_g * L.hidden + h] * fmaxf(p, 0.0f);
+                            if (lane == 0) hid[h] = fmaxf(p, 0.0f);
                         }
                     }
+                    __syncthreads();
+                    float a = 0.0f;
+#pragma unroll
+                    for (int h = 0; h < 16; h++)
+                        if (h < L.hidden) a += w2r[h] * hid[h];
                     const float g = 1.0f / (1.0f + expf(-a));
 #pragma unroll
                     for (int r = 0; r < 4; r++) gate[r] = __shfl(g, 4 * kq + r);

@@ -139,7 +139,7 @@ int main() {
         CK(hipMalloc(&tw, per * NL * 16)); CK(hipMemset(tw, 0, per * NL * 16));
         CK(hipMalloc(&tp, 64 * 1024 * 4)); CK(hipMemset(tp, 0, 64 * 1024 * 4));
         CK(hipMalloc(&tl, NL * sizeof(bo_tower_layer)));
-        for (int variant = 0; variant < 4; variant++) {
+        for (int variant = 0; variant < 7; variant++) {
             std::vector<bo_tower_layer> L(NL);
             for (int l = 0; l < NL; l++) L[l] = {(int)((variant == 1 ? 0 : l) * per), 32, l * 128, l == 0 ? 0 : (l % 2 ? 1 : 2), 0, 0, 0, l == NL - 1};
             CK(hipMemcpy(tl, L.data(), NL * sizeof(bo_tower_layer), hipMemcpyHostToDevice));
@@ -148,6 +148,9 @@ int main() {
                 auto go = [&]() {
                     if (variant == 2) hipLaunchKernelGGL((bo_k_tower_wg<128, 1>), dim3(256), dim3(512), 0, 0, x, tw, tp, tl, NL, y, B);
                     else if (variant == 3) hipLaunchKernelGGL((bo_k_tower_wg<128, 2>), dim3(256), dim3(512), 0, 0, x, tw, tp, tl, NL, y, B);
+                    else if (variant == 4) hipLaunchKernelGGL((bo_k_tower_wg<128, 4>), dim3(256), dim3(512), 0, 0, x, tw, tp, tl, NL, y, B);
+                    else if (variant == 5) hipLaunchKernelGGL((bo_k_tower_wg<128, 5>), dim3(256), dim3(512), 0, 0, x, tw, tp, tl, NL, y, B);
+                    else if (variant == 6) hipLaunchKernelGGL((bo_k_tower_wg<128, 6>), dim3(256), dim3(512), 0, 0, x, tw, tp, tl, NL, y, B);
                     else hipLaunchKernelGGL((bo_k_tower_wg<128, 0>), dim3(256), dim3(512), 0, 0, x, tw, tp, tl, NL, y, B);
                 };
                 for (int i = 0; i < 3; i++) go();
@@ -155,7 +158,7 @@ int main() {
                 for (int i = 0; i < 20; i++) go();
                 (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
                 float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
-                const char *names[4] = {"distinct weights", "shared weights", "no weight loads", "no input transform"};
+                const char *names[7] = {"distinct weights", "shared weights", "no weight loads", "no input transform", "no epilogue", "no chunk barriers", "MFMA + B reads only"};
                 printf("winograd tower (%s, no SE) B=%d: %.1f us = %.2f us/layer/256 boards\n", names[variant], B,
                        ms * 1000 / 20, ms * 1000 / 20 / NL / (B / 256));
             }
