@@ -90,6 +90,8 @@ class CastIn(torch.nn.Module):
         self.net, self.dtype = net, dtype
 
     def forward(self, x):
+        if getattr(self.net, "wants_float32_input", False):  # the fp16 tower converts the planes itself
+            return self.net(x)
         return self.net(x.to(self.dtype))
 
 
@@ -286,11 +288,14 @@ def main():
         out = {
             "metric": "mcts_nodes_per_sec", "value": round(sims / dt, 1), "unit": "nodes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "fp16": "f16", "bf16": "bf16"}[args.net_dtype], "data": "synthetic",
             "config": {"workload": f"{G} concurrent self-play games per GPU x {args.sims} sims/move, MCTS_BATCH_SIZE {args.batch}, "
                                    f"net {args.net} ({'+'.join(map(str, NETS[args.net][:2]))} blocks x {NETS[args.net][2]} filters, "
                                    f"random init, {args.net_dtype}, BN folded), start position, per-game seeds = game id; "
-                                   f"BASELINE.json configs[2] per-GPU shard",
+                                   + ("BASELINE.json configs[4] per-GPU shard (f16 net, f32 tree)" if (args.net, args.net_dtype, G) == ("20x256", "fp16", 512)
+                                      else "BASELINE.json configs[1]" if (args.net, args.net_dtype, G, args.sims) == ("10x128", "fp32", 256, 400)
+                                      else "BASELINE.json configs[2] per-GPU shard" if (args.net, args.net_dtype, G, args.sims) == ("10x128", "fp32", 256, 800)
+                                      else "custom configuration"),
                        "games_per_gpu": G, "sims_per_move": args.sims, "net": args.net, "net_dtype": args.net_dtype,
                        "hipgraph": not args.no_graph, "net_layout": net_layout,
                        "search_mode": ("fast: virtual loss, %d leaves/step, full-width expansion (NOT the reference's semantics)" % args.leaves)

@@ -11,6 +11,7 @@
 #include "bo_conv.h"
 #include "bo_tower.h"
 #include "bo_tower_wg.h"
+#include "bo_tower_h.h"
 #include "bo_rt.h"
 #include "bo_hostrng.h"
 
@@ -683,15 +684,19 @@ extern "C" int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layer
 #else
     static_assert(sizeof(bo_tower_layer_desc) == sizeof(bo_tower_layer), "descriptor layouts must agree");
     if (!layers || !weights || !params || !out || n_layers < 1 || n_layers > 4096) return fail(BO_E_ARG, "bad arguments");
-    if (channels != 64 && channels != 128) return fail(BO_E_CONFIG, "bo_nn_tower: channels must be 64 or 128 (two padded boards must fit in 160 KB of LDS)");
+    if (algo == BO_TOWER_DIRECT_F16 ? (channels != 128 && channels != 256) : (channels != 64 && channels != 128))
+        return fail(BO_E_CONFIG, "bo_nn_tower: channels must be 64 or 128 (fp32: two padded images per board in LDS) or 128 / 256 (BO_TOWER_DIRECT_F16)");
     if (n_weights % 4) return fail(BO_E_ARG, "n_weights must be a multiple of 4");
-    if (algo != BO_TOWER_DIRECT && algo != BO_TOWER_WINOGRAD) return fail(BO_E_ARG, "algo must be BO_TOWER_DIRECT or BO_TOWER_WINOGRAD");
+    if (algo != BO_TOWER_DIRECT && algo != BO_TOWER_WINOGRAD && algo != BO_TOWER_DIRECT_F16) return fail(BO_E_ARG, "unknown algo");
+    if (algo == BO_TOWER_DIRECT_F16 && !head) return fail(BO_E_ARG, "BO_TOWER_DIRECT_F16 needs the fused head (it has no tower output buffer)");
     const int C = channels;
     for (int l = 0; l < n_layers; l++) {  // every offset the kernel will form stays inside the two buffers
         const bo_tower_layer_desc &L = layers[l];
         // K steps per layer: direct = groups of 8 input channels, Winograd = groups of 4; the input conv is padded to 128
-        const int cin = L.kind == 0 ? 128 : C, want_t4 = algo == BO_TOWER_DIRECT ? cin / 8 : cin / 4;
-        const int64_t w4 = algo == BO_TOWER_DIRECT ? (int64_t)9 * want_t4 * C * 2 : (int64_t)want_t4 * (C / 16) * 4 * 64;
+        const int cin = L.kind == 0 ? 128 : C;
+        const int want_t4 = algo == BO_TOWER_DIRECT ? cin / 8 : algo == BO_TOWER_WINOGRAD ? cin / 4 : 9 * cin / 16;
+        const int64_t w4 = algo == BO_TOWER_DIRECT ? (int64_t)9 * want_t4 * C * 2
+                           : algo == BO_TOWER_WINOGRAD ? (int64_t)want_t4 * (C / 16) * 4 * 64 : (int64_t)want_t4 * (C / 32) * 64;
         if (L.kind < 0 || L.kind > 3 || (l == 0) != (L.kind == 0)) return fail(BO_E_ARG, "layer " + std::to_string(l) + ": bad kind");
         if (L.kind == 1 && (l + 1 >= n_layers || layers[l + 1].kind < 2)) return fail(BO_E_ARG, "a first conv must be followed by a second conv");
         if (L.kind >= 2 && layers[l - 1].kind != 1) return fail(BO_E_ARG, "a second conv must follow a first conv");
@@ -708,11 +713,15 @@ extern "C" int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layer
     }
     if (layers[n_layers - 1].kind < 2) return fail(BO_E_ARG, "the tower must end with a second conv");
     if (head) {
-        if (algo != BO_TOWER_WINOGRAD) return fail(BO_E_CONFIG, "fused head convolutions need BO_TOWER_WINOGRAD");
+        if (algo == BO_TOWER_DIRECT) return fail(BO_E_CONFIG, "fused head convolutions need BO_TOWER_WINOGRAD or BO_TOWER_DIRECT_F16");
         if (head->channels < 1 || head->channels > 256 || head->split < 0 || head->split > head->channels) return fail(BO_E_ARG, "bad head channels/split");
-        if (head->w_off < 0 || (head->w_off & 3) || (int64_t)head->w_off + (int64_t)((head->channels + 15) / 16) * 16 * C > n_params || head->b_off < 0 ||
-            (int64_t)head->b_off + head->channels > n_params)
-            return fail(BO_E_ARG, "head offsets out of range");
+        if (head->b_off < 0 || (int64_t)head->b_off + head->channels > n_params) return fail(BO_E_ARG, "head bias offset out of range");
+        if (algo == BO_TOWER_WINOGRAD) {
+            if (head->w_off < 0 || (head->w_off & 3) || (int64_t)head->w_off + (int64_t)((head->channels + 15) / 16) * 16 * C > n_params)
+                return fail(BO_E_ARG, "head weight offset out of range");
+        } else if (head->w_off < 0 || ((int64_t)head->w_off + (int64_t)((head->channels + 31) / 32) * (C / 16) * 64) * 4 > n_weights) {
+            return fail(BO_E_ARG, "head weight offset out of range");
+        }
     }
     RT(rt_set_device(device));
     hipDeviceProp_t prop;
@@ -736,7 +745,7 @@ extern "C" int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layer
 #endif
 }
 
-extern "C" int bo_nn_tower_forward(bo_tower *t, const float *x_dev, float *y_dev, float *head_a_dev, float *head_b_dev, int batch,
+extern "C" int bo_nn_tower_forward(bo_tower *t, const float *x_dev, float *y_dev, void *head_a_dev, void *head_b_dev, int batch,
                                    void *stream) {
 #if defined(BO_WAVE_EMU)
     (void)t; (void)x_dev; (void)y_dev; (void)head_a_dev; (void)head_b_dev; (void)batch; (void)stream;
@@ -747,13 +756,25 @@ extern "C" int bo_nn_tower_forward(bo_tower *t, const float *x_dev, float *y_dev
     if (t->head_channels > 0) {
         if ((t->head_split > 0 && !head_a_dev) || (t->head_split < t->head_channels && !head_b_dev)) return fail(BO_E_ARG, "head output buffers missing");
         hd.channels = t->head_channels; hd.split = t->head_split; hd.w_off = t->head_w_off; hd.b_off = t->head_b_off;
-        hd.out_a = head_a_dev; hd.out_b = head_b_dev;
+        hd.out_a = (float *)head_a_dev; hd.out_b = (float *)head_b_dev;
     } else if (!y_dev) {
         return fail(BO_E_ARG, "y_dev is required for a tower without fused heads");
     }
     const int slots = t->n_cu * (t->channels == 64 && t->algo == BO_TOWER_DIRECT ? 2 : 1);  // direct, 64 filters: two 2-wave workgroups share a CU
     const unsigned grid = (unsigned)(batch < slots ? batch : slots);
     hipStream_t st = (hipStream_t)stream;
+    if (t->algo == BO_TOWER_DIRECT_F16) {  // two boards per workgroup
+        bo_tower_head_h hh;
+        hh.channels = t->head_channels; hh.split = t->head_split; hh.w_off8 = t->head_w_off; hh.b_off = t->head_b_off;
+        hh.out_a = (_Float16 *)head_a_dev; hh.out_b = (_Float16 *)head_b_dev;
+        const int pairs = (batch + 1) / 2;
+        const unsigned g2 = (unsigned)(pairs < t->n_cu ? pairs : t->n_cu);
+        const bo_h8 *w8 = reinterpret_cast<const bo_h8 *>(t->wts);
+        if (t->channels == 256) hipLaunchKernelGGL((bo_k_tower_h<256>), dim3(g2), dim3(512), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, batch, hh);
+        else hipLaunchKernelGGL((bo_k_tower_h<128>), dim3(g2), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, batch, hh);
+        RT((int)hipGetLastError());
+        return BO_OK;
+    }
     if (t->algo == BO_TOWER_WINOGRAD && t->channels == 128)
         hipLaunchKernelGGL((bo_k_tower_wg<128>), dim3(grid), dim3(512), 0, st, x_dev, t->wts, t->params, t->layers, t->n_layers, y_dev, batch, hd);
     else if (t->algo == BO_TOWER_WINOGRAD)

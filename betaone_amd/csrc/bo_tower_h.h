@@ -1,0 +1,189 @@
+// betaone_amd/csrc/bo_tower_h.h -- the residual tower for 256-filter nets with an fp16 evaluate stage (BASELINE.json
+// configs[4]: 20-block x 256 net, "fp16 net eval") as one persistent kernel on v_mfma_f32_32x32x16_f16 (gfx950).
+//
+// Same contract as bo_tower.h (/root/reference/network.py:48-118,167-195, BatchNorm folded): fp16 weights and
+// activations, fp32 accumulation, like the network in torch.float16.  What changes against the fp32 kernels:
+//   * fp16 MFMA is 16x the fp32 rate, so a 3x3 layer of one board costs 7.7 us of MFMA time while its 1.18 MB of
+//     weights need ~17 us to stream from L2 to a CU: a workgroup therefore keeps TWO boards (512 games per GPU =
+//     2 boards per CU) and every weight fragment feeds 4 MFMAs (2 boards x 2 position halves);
+//   * activations live in LDS channels-last, [board][padded 10x10 cell][C + 8] fp16 (528-byte cell pitch: the B
+//     operand of a lane, 8 consecutive channels of one cell = one ds_read_b128, is bank-conflict free).  ONE image
+//     per board: each wave holds its 32 output channels x all 128 positions in 64 accumulator registers, so after a
+//     barrier the layer's output overwrites its input in place; the skip connection stays in registers (packed fp16);
+//   * direct (not Winograd) convolution: M = 32 output channels per wave (8 waves), N = 128 positions, K = 9 taps x C
+//     in steps of 16 channels; A fragments [step][oc/32][lane][8 fp16] = one global_load_dwordx4, reloaded 8 steps
+//     ahead into the register set its own MFMAs just released (64 KB per CU in flight).
+#pragma once
+#if !defined(BO_WAVE_EMU)
+#include <hip/hip_runtime.h>
+#include "bo_tower.h"
+
+typedef _Float16 bo_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 bo_h4 __attribute__((ext_vector_type(4)));
+
+struct bo_tower_head_h {
+    int channels = 0, split = 0, w_off8 = 0, b_off = 0;  // head weights: [mt 2][step C/16][lane][8 fp16] at bo_h8 offset w_off8 in wts
+    _Float16 *out_a = nullptr, *out_b = nullptr;
+};
+
+template <int C>
+__global__ void __launch_bounds__(C * 2)
+bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const float *__restrict__ params,
+             const bo_tower_layer *__restrict__ layers, int n_layers, int B, bo_tower_head_h head) {
+    constexpr int NT = C * 2, NW = C / 32, PH = C + 8, CELLS = 100, IMGH = CELLS * PH, CIN0 = 120;
+    __shared__ __attribute__((aligned(16))) _Float16 X[2 * IMGH];
+    __shared__ float pooled[2][C], hid[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kg = lane >> 5, n = lane & 31;
+    const int cell0 = ((n >> 3) + 1) * 10 + (n & 7) + 1;  // padded cell of position n; position n + 32 is cell0 + 40
+
+    for (int i = tid; i < 2 * IMGH / 8; i += NT) reinterpret_cast<bo_h8 *>(X)[i] = bo_h8{0, 0, 0, 0, 0, 0, 0, 0};
+
+    bo_f32x16 acc[4];          // [board*2 + half]: rows = output channels 32*wave + (r&3) + 8*(r>>2) + 4*kg, col = position n
+    bo_h8 a[8];                // A fragments of 8 consecutive K-steps
+    bo_h8 bq[2][4];            // B operands of two consecutive K-steps
+    bo_h4 skip[4][4];          // block input at this lane's (positions, channels), packed like the LDS writes
+    const _Float16 *xl = X + (size_t)cell0 * PH + 8 * kg;  // + board*IMGH + half*40*PH + tap/channel offset
+    auto load_a = [&](int j, int w_off8, int step) { a[j] = wts[(size_t)w_off8 + ((size_t)step * NW + wave) * 64 + lane]; };
+    auto read_b = [&](bo_h8(&b)[4], int off) {  // off: (tap offset in cells) * PH + 16 * channel group
+        b[0] = *reinterpret_cast<const bo_h8 *>(xl + off);
+        b[1] = *reinterpret_cast<const bo_h8 *>(xl + off + 40 * PH);
+        b[2] = *reinterpret_cast<const bo_h8 *>(xl + off + IMGH);
+        b[3] = *reinterpret_cast<const bo_h8 *>(xl + off + IMGH + 40 * PH);
+    };
+#define BO_H_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+
+#pragma unroll
+    for (int j = 0; j < 8; j++) load_a(j, layers[0].w_off4, j);
+    const int npairs = (B + 1) >> 1;
+    for (int pb = blockIdx.x; pb < npairs; pb += gridDim.x) {
+        const int b0 = 2 * pb;
+        // ---- stage the 120 input planes of both boards (fp32 NCHW) as fp16 channels-last; channels >= 120 stay zero ----
+        __syncthreads();
+        for (int i = tid; i < 2 * 128 * 16; i += NT) {  // channels 120..127 of the padded input conv are zeroed
+            const int bb = i >> 11, rem = i & 2047, ic = rem >> 4, q = rem & 15;
+            bo_f32x4 t = {0, 0, 0, 0};
+            if (ic < CIN0 && b0 + bb < B) t = reinterpret_cast<const bo_f32x4 *>(x + (size_t)(b0 + bb) * CIN0 * 64)[rem];
+            _Float16 *dst = X + (size_t)bb * IMGH + (size_t)(((q >> 1) + 1) * 10 + (q & 1) * 4 + 1) * PH + ic;
+            dst[0] = (_Float16)t[0]; dst[PH] = (_Float16)t[1]; dst[2 * PH] = (_Float16)t[2]; dst[3 * PH] = (_Float16)t[3];
+        }
+        __syncthreads();
+        for (int l = 0; l < n_layers; l++) {
+            const bo_tower_layer L = layers[l];
+            const bo_tower_layer Ln = layers[l + 1 < n_layers ? l + 1 : 0];
+            const int ncg = L.t4 / 9;  // channel groups of 16 per tap (L.t4 = K-steps of the layer, a multiple of 8)
+            float bv[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) bv[r] = params[L.bias_off + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg];
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+            read_b(bq[0], (-11) * PH);  // step 0: tap 0 = (-1, -1), channel group 0
+            for (int s0 = 0; s0 < L.t4; s0 += 8) {
+                const int tap = s0 / ncg, cg0 = s0 - tap * ncg;
+                const int off0 = ((tap / 3 - 1) * 10 + (tap % 3 - 1)) * PH + 16 * cg0;
+                // offset of the step after this group (first step of the next tap, or a harmless re-read at the layer's end)
+                const int s8 = s0 + 8, tapn = s8 < L.t4 ? s8 / ncg : tap, cgn = s8 < L.t4 ? s8 - tapn * ncg : cg0;
+                const int offn = ((tapn / 3 - 1) * 10 + (tapn % 3 - 1)) * PH + 16 * cgn;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const bo_h8(&bc)[4] = bq[j & 1];
+                    read_b(bq[(j + 1) & 1], j < 7 ? off0 + 16 * (j + 1) : offn);
+#pragma unroll
+                    for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j], bc[t], acc[t], 0, 0, 0);
+                    const int sn = s0 + j + 8;  // this set's next owner: 8 steps ahead, maybe in the next layer
+                    load_a(j, sn < L.t4 ? L.w_off4 : Ln.w_off4, sn < L.t4 ? sn : sn - L.t4);
+                    BO_H_SGB(0x008, 1); BO_H_SGB(0x100, 1); BO_H_SGB(0x008, 1); BO_H_SGB(0x100, 1);
+                    BO_H_SGB(0x008, 1); BO_H_SGB(0x100, 1); BO_H_SGB(0x008, 1); BO_H_SGB(0x100, 1); BO_H_SGB(0x020, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();  // every wave has read the layer input: the output may overwrite it
+
+            // ---- epilogue: rows (r&3) + 8*(r>>2) + 4*kg of tile t are 4 consecutive channels per r>>2 ----
+            float gate[2][16];
+            if (L.kind == 3) {
+                const float *w1 = params + L.se_w1_off, *w2 = params + L.se_w2_off;
+                float w2r[16];
+#pragma unroll
+                for (int h = 0; h < 16; h++) w2r[h] = h < L.hidden ? w2[(wave * 32 + n) * L.hidden + h] : 0.0f;
+#pragma unroll
+                for (int bb = 0; bb < 2; bb++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        float s = acc[2 * bb][r] + acc[2 * bb + 1][r];
+#pragma unroll
+                        for (int m = 16; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+                        if (n == 0) pooled[bb][wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg] = s * (1.0f / 64.0f) + bv[r];
+                    }
+                __syncthreads();
+                for (int u = wave; u < 2 * L.hidden; u += NW) {  // one wave reduction per (board, hidden unit)
+                    const int bb = u / L.hidden, h = u - bb * L.hidden;
+                    float p = 0.0f;
+                    for (int c = lane; c < C; c += 64) p += w1[h * C + c] * pooled[bb][c];
+#pragma unroll
+                    for (int m = 32; m >= 1; m >>= 1) p += __shfl_xor(p, m);
+                    if (lane == 0) hid[bb][h] = fmaxf(p, 0.0f);
+                }
+                __syncthreads();
+                float g = 0.0f;  // lane (n, kg): gate of channel 32*wave + n of board kg
+#pragma unroll
+                for (int h = 0; h < 16; h++)
+                    if (h < L.hidden) g += w2r[h] * hid[kg][h];
+                g = 1.0f / (1.0f + expf(-g));
+#pragma unroll
+                for (int bb = 0; bb < 2; bb++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) gate[bb][r] = __shfl(g, (r & 3) + 8 * (r >> 2) + 4 * kg + 32 * bb);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                _Float16 *cellp = X + (size_t)(t >> 1) * IMGH + (size_t)(cell0 + 40 * (t & 1)) * PH + wave * 32 + 4 * kg;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    bo_h4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int r = 4 * q + e;
+                        float v = acc[t][r] + bv[r];
+                        if (L.kind == 3) v = v * gate[t >> 1][r];
+                        if (L.kind >= 2) v += (float)skip[t][q][e];
+                        o[e] = (_Float16)fmaxf(v, 0.0f);
+                    }
+                    if (L.kind != 1) skip[t][q] = o;
+                    *reinterpret_cast<bo_h4 *>(cellp + 8 * q) = o;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- the two 1x1 head convolutions + ReLU on the tower output in X: one 32x32 job per (32 head channels, board, half) ----
+        if (head.channels > 0) {
+            const int mts = (head.channels + 31) >> 5;
+            for (int job = wave; job < mts * 4; job += NW) {
+                const int mt = job >> 2, t = job & 3, bb = t >> 1;
+                bo_f32x16 hacc;
+#pragma unroll
+                for (int r = 0; r < 16; r++) hacc[r] = 0.0f;
+                const _Float16 *xb = xl + (size_t)bb * IMGH + (t & 1) * 40 * PH;
+#pragma unroll 4
+                for (int st = 0; st < C / 16; st++) {
+                    const bo_h8 aw = wts[(size_t)head.w_off8 + ((size_t)mt * (C / 16) + st) * 64 + lane];
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, *reinterpret_cast<const bo_h8 *>(xb + 16 * st), hacc, 0, 0, 0);
+                }
+                if (b0 + bb < B) {
+                    const int sq = 32 * (t & 1) + n;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int oc = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                        if (oc < head.channels) {
+                            const _Float16 v = (_Float16)fmaxf(hacc[r] + params[head.b_off + oc], 0.0f);
+                            if (oc < head.split) head.out_a[((size_t)(b0 + bb) * head.split + oc) * 64 + sq] = v;
+                            else head.out_b[((size_t)(b0 + bb) * (head.channels - head.split) + (oc - head.split)) * 64 + sq] = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+#endif

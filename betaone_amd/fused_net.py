@@ -13,6 +13,8 @@ elementwise launches PyTorch issues (bias, ReLU, residual add, SE pooling / FCs 
   conv="tower":  input conv + all residual blocks are ONE persistent kernel that keeps each board's activations in
                  LDS (csrc/bo_tower.h); 64 or 128 filters.
   conv="tower_wg": the same with Winograd F(2x2,3x3) convolutions (csrc/bo_tower_wg.h), 2.25x fewer MFMA cycles.
+  conv="tower_f16": fp16 weights/activations, fp32 accumulation (csrc/bo_tower_h.h), 128 or 256 filters, two boards
+                 per workgroup; the evaluate stage of BASELINE.json configs[4].  Takes the engine's float32 planes.
 
 NCHW float32 only; other dtypes/layouts use PolicyValueNet.for_inference().
 """
@@ -49,6 +51,14 @@ def pack_conv_weight_winograd(w: torch.Tensor) -> torch.Tensor:
     u = torch.einsum("ai,ocij,bj->aboc", _WG_G, w.double(), _WG_G).reshape(16, co, ci)  # [pos][oc][ic]
     u = u.reshape(4, 4, co // 16, 16, ci // 4, 4)  # [pq][e][ob][o16][step][k]
     return u.permute(4, 2, 0, 5, 3, 1).contiguous().float()  # [step][ob][pq][k][o16][e]
+
+
+def pack_conv_weight_f16(w: torch.Tensor) -> torch.Tensor:
+    """[c_out, c_in, 3, 3] -> fp16 [9*c_in/16][c_out/32][64][8] (include/betaone_engine.h, BO_TOWER_DIRECT_F16):
+    element (step, mt, lane, i) = W[32*mt + (lane & 31)][16*(step % (c_in/16)) + 8*(lane >> 5) + i][tap = step / (c_in/16)]."""
+    co, ci = w.shape[0], w.shape[1]
+    u = w.reshape(co // 32, 32, ci // 16, 2, 8, 9)  # [mt][o][cg][kg][i][tap]
+    return u.permute(5, 2, 0, 3, 1, 4).contiguous().half()  # [tap][cg][mt][kg][o][i]
 
 
 def conv3x3_mfma(lib, x, wpacked, bias, c_out, mode=0, residual=None, out=None):
@@ -119,8 +129,87 @@ class FusedPolicyValueNet(nn.Module):
         elif conv in ("tower", "tower_wg"):
             self._build_tower(dev, winograd=conv == "tower_wg")
             self.layout = "nchw+" + conv
+        elif conv == "tower_f16":
+            self._build_tower_f16(dev)
+            self.layout = "nchw+tower_f16"
         elif conv != "miopen":
-            raise ValueError("conv must be 'miopen', 'mfma', 'tower' or 'tower_wg'")
+            raise ValueError("conv must be 'miopen', 'mfma', 'tower', 'tower_wg' or 'tower_f16'")
+
+    def _build_tower_f16(self, dev):
+        """fp16 tower (bo_nn_tower_create, BO_TOWER_DIRECT_F16) + half copies of the three head Linear layers."""
+        c = self.w_in.shape[0]
+        if c not in (128, 256) or self.w_in.shape[1] != 120:
+            raise E.EngineError("conv='tower_f16' supports 120 input planes and 128 or 256 filters")
+        wts, params, layers = [], [], []
+        n_h = n_p = 0  # halves in wts, floats in params
+
+        def add_w(t16):
+            nonlocal n_h
+            off = n_h // 8
+            flat = t16.reshape(-1).numpy()
+            wts.append(flat)
+            n_h += flat.size
+            return off
+
+        def add_p(t):
+            nonlocal n_p
+            off = n_p
+            flat = t.detach().float().cpu().contiguous().reshape(-1).numpy()
+            params.append(flat)
+            n_p += flat.size
+            return off
+
+        w0 = torch.zeros((c, 128, 3, 3))
+        w0[:, :120] = self.w_in.detach().float().cpu()
+        layers.append([add_w(pack_conv_weight_f16(w0)), 9 * 128 // 16, add_p(self.b_in), 0, 0, 0, 0, 0])
+        for w1, b1, w2, b2, se in self.blocks:
+            layers.append([add_w(pack_conv_weight_f16(w1.detach().float().cpu())), 9 * c // 16, add_p(b1), 1, 0, 0, 0, 0])
+            p2 = add_w(pack_conv_weight_f16(w2.detach().float().cpu()))
+            if se is not None:
+                if se[0].shape[0] > 16:
+                    raise E.EngineError("conv='tower_f16' supports SE hidden widths up to 16")
+                layers.append([p2, 9 * c // 16, add_p(b2), 3, add_p(se[0]), add_p(se[1]), se[0].shape[0], 0])
+            else:
+                layers.append([p2, 9 * c // 16, add_p(b2), 2, 0, 0, 0, 0])
+        layers[-1][7] = 1
+        self._head_ch, self._head_split = self.w_head.shape[0], self.n_policy_ch
+        mt = (self._head_ch + 31) // 32
+        wh = torch.zeros((mt * 32, c))
+        wh[:self._head_ch] = self.w_head.detach().float().cpu().reshape(self._head_ch, c)
+        whp = wh.reshape(mt, 32, c // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().half()  # [mt][st][kg][o][i]
+        head = np.array([self._head_ch, self._head_split, add_w(whp), add_p(self.b_head)], dtype=np.int32)
+        wts = np.ascontiguousarray(np.concatenate(wts), dtype=np.float16)
+        if wts.size % 2:
+            wts = np.concatenate([wts, np.zeros(1, np.float16)])
+        params = np.ascontiguousarray(np.concatenate(params), dtype=np.float32)
+        table = np.ascontiguousarray(np.array(layers, dtype=np.int32))
+        handle = C.c_void_p()
+        rc = self.lib.bo_nn_tower_create(table.ctypes.data, len(layers), wts.ctypes.data, wts.size // 2, params.ctypes.data, params.size, c,
+                                         2, head.ctypes.data, dev.index if dev.index is not None else torch.cuda.current_device(), C.byref(handle))
+        if rc:
+            raise E.EngineError(self.lib.bo_last_error().decode())
+        self.c, self._tower, self._tower_dev = c, handle, dev
+        import copy
+
+        self.policy_fc_h = copy.deepcopy(self.policy_fc).half()
+        self.value_fc1_h = copy.deepcopy(self.value_fc1).half()
+        self.value_fc2_h = copy.deepcopy(self.value_fc2).half()
+        self.wants_float32_input = True
+
+    def _tower_f16_forward(self, x):
+        if x.dtype != torch.float32:
+            x = x.float()
+        if x.device != self._tower_dev or x.shape[1:] != (120, 8, 8):
+            raise E.EngineError("tower_f16: x must be [B, 120, 8, 8] on the tower's device")
+        x = x.contiguous()
+        B = x.shape[0]
+        pa = torch.empty((B, self._head_split * 64), dtype=torch.float16, device=x.device)
+        pb = torch.empty((B, (self._head_ch - self._head_split) * 64), dtype=torch.float16, device=x.device)
+        rc = self.lib.bo_nn_tower_forward(self._tower, x.data_ptr(), None, pa.data_ptr(), pb.data_ptr(), B,
+                                          torch.cuda.current_stream(x.device).cuda_stream)
+        if rc:
+            raise E.EngineError(self.lib.bo_last_error().decode())
+        return pa, pb
 
     def _build_tower(self, dev, winograd=False):
         """Flatten the trunk into the three host arrays of bo_nn_tower_create (include/betaone_engine.h)."""
@@ -249,6 +338,9 @@ class FusedPolicyValueNet(nn.Module):
 
     @torch.no_grad()
     def forward(self, x):
+        if self.conv == "tower_f16":
+            p, v = self._tower_f16_forward(x)
+            return self.policy_fc_h(p), torch.tanh(self.value_fc2_h(F.relu(self.value_fc1_h(v))))
         if self.conv == "tower_wg":  # tower + head convolutions in one kernel, then 2 GEMMs and the value tail
             p, v = self._tower_forward(x, heads=True)
             h = torch._addmm_activation(self.value_fc1.bias, v, self.value_fc1.weight.t())  # relu(fc1)

@@ -67,4 +67,17 @@ def best_inference_copy(model, batch: int, device, dtype: torch.dtype = torch.fl
                 print(f"[nn_tune] batch={batch} nchw fused epilogues, conv={conv}: {t * 1e3:.3f} ms")
             if t < best_t:
                 best, best_t = fused, t
+    if dtype == torch.float16:  # fp16 tower, two boards per workgroup (csrc/bo_tower_h.h); it takes the float32 planes itself
+        from . import engine as E
+        from .fused_net import FusedPolicyValueNet
+
+        try:
+            fused = FusedPolicyValueNet(model.to(device), conv="tower_f16").to(device)
+            t = _time_forward(fused, x)
+            if verbose:
+                print(f"[nn_tune] batch={batch} fp16 tower: {t * 1e3:.3f} ms")
+            if t < best_t:
+                best = fused
+        except E.EngineError:
+            pass
     return best

@@ -227,6 +227,12 @@ int bo_nn_conv3x3(const float *x_dev, const float *wpacked_dev, const float *bia
  * algo BO_TOWER_WINOGRAD (csrc/bo_tower_wg.h): F(2x2,3x3); t4 = c_in/4 K-steps; weights per layer
  *   [t4][C/16][4][64][4] with element (step, ob, pq, lane, e) = (G g G^T)[4*pq + e] of filter
  *   g = W[16*ob + (lane & 15)][4*step + (lane >> 4)], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], position = 4*row + col.
+ * algo BO_TOWER_DIRECT_F16 (csrc/bo_tower_h.h): fp16 weights and activations, fp32 accumulation, two boards per
+ *   workgroup; channels in {128, 256}; t4 = 9*c_in/16 K-steps; `weights` holds fp16 data (n_weights still counts
+ *   4-byte units): per layer [t4][C/32][64][8] with element (step, mt, lane, i) = W[32*mt + (lane & 31)]
+ *   [16*(step % (c_in/16)) + 8*(lane >> 5) + i][tap = step / (c_in/16)] at 16-byte offset w_off4.  Needs `head`: its
+ *   weights [ceil(channels/32)][C/16][64][8] fp16 with element (mt, st, lane, i) = Wh[32*mt + (lane & 31)][16*st +
+ *   8*(lane >> 5) + i] at 16-byte offset w_off in `weights`; head outputs are fp16; y_dev is unused.
  * weights: float32 at float4 offset w_off4; params: float32 biases and SE matrices at float offsets.
  * head (optional, BO_TOWER_WINOGRAD only): the policy and value 1x1 convolutions + ReLU (network.py:101-113,191-195)
  *   fused behind the tower: bias [channels] and weights in params, the weights packed [ceil(channels/16)][C/16][64][4]
@@ -236,7 +242,7 @@ int bo_nn_conv3x3(const float *x_dev, const float *wpacked_dev, const float *bia
  * bo_nn_tower_create validates every offset and copies the three HOST arrays to `device`;
  * bo_nn_tower_forward(x_dev [batch,120,8,8] -> y_dev [batch,C,8,8], NCHW float32) is asynchronous on `stream`.
  * bo_nn_value_tail: out[b] = tanh(w . h[b] + bias[0]) (value_fc2 + tanh, network.py:116-118,197). */
-enum { BO_TOWER_DIRECT = 0, BO_TOWER_WINOGRAD = 1 };
+enum { BO_TOWER_DIRECT = 0, BO_TOWER_WINOGRAD = 1, BO_TOWER_DIRECT_F16 = 2 };
 typedef struct bo_tower_layer_desc {
     int32_t w_off4, t4, bias_off, kind, se_w1_off, se_w2_off, hidden, last;
 } bo_tower_layer_desc;
@@ -247,7 +253,7 @@ typedef struct bo_tower_s bo_tower;
 int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layers, const float *weights, int64_t n_weights,
                        const float *params, int64_t n_params, int channels, int algo, const bo_tower_head_desc *head, int device,
                        bo_tower **out);
-int bo_nn_tower_forward(bo_tower *tower, const float *x_dev, float *y_dev, float *head_a_dev, float *head_b_dev, int batch, void *stream);
+int bo_nn_tower_forward(bo_tower *tower, const float *x_dev, float *y_dev, void *head_a_dev, void *head_b_dev, int batch, void *stream);
 int bo_nn_value_tail(const float *h_dev, const float *w_dev, const float *bias_dev, float *out_dev, int batch, int hidden, void *stream);
 void bo_nn_tower_destroy(bo_tower *tower);
 

@@ -65,3 +65,19 @@ for B in (256, 1024):
     for nm, m in (("mfma", One()), ("miopen", Lib())):
         ms = bench(m, x, 100)
         print(f"single conv 128->128 {nm} B={B}: {ms*1e3:.1f} us  {B*128*128*9*64*2/ms/1e9:.1f} TFLOP/s", flush=True)
+
+# fp16 tower (csrc/bo_tower_h.h) vs MIOpen fp16 on the 20x256 net of BASELINE configs[4]
+config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 15, 5, 256
+big = network.PolicyValueNet().cuda().eval()
+f16 = FusedPolicyValueNet(big, conv="tower_f16").cuda()
+for cl in (True, False):
+    hn = big.for_inference(dtype=torch.float16, channels_last=cl)
+    for B in (256, 512, 1024):
+        x = torch.randn(B, 120, 8, 8, device="cuda", dtype=torch.float16)
+        if cl: x = x.contiguous(memory_format=torch.channels_last)
+        ms = bench(hn, x)
+        print(f"20x256 fp16 MIOpen channels_last={cl} B={B}: {ms:.3f} ms  {B/ms*1e3:.0f} pos/s", flush=True)
+for B in (256, 512, 1024):
+    x = torch.randn(B, 120, 8, 8, device="cuda")
+    ms = bench(f16, x)
+    print(f"20x256 fp16 tower B={B}: {ms:.3f} ms  {B/ms*1e3:.0f} pos/s  {41*2*9*256*256*64*B/ms/1e9:.0f} TFLOP/s", flush=True)

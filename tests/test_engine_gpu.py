@@ -229,6 +229,40 @@ def test_fused_epilogue_net_matches_plain_net(backend, size, conv):
         config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = saved
 
 
+@pytest.mark.parametrize("size", [(2, 1, 128), (3, 2, 256)])
+def test_fp16_tower_matches_half_precision_net(backend, size):
+    """csrc/bo_tower_h.h (fp16 weights/activations, fp32 accumulation, two boards per workgroup) against the same net in
+    float32 and against PyTorch's own float16 evaluation: its error vs the float32 net must be of the size of torch-fp16's
+    own error (fp16 has 11 significand bits: outputs agree to ~1e-2 at these magnitudes, not 1e-4)."""
+    import torch
+    from betaone_amd import dropin
+    dropin.install()
+    import config, network
+    from betaone_amd.fused_net import FusedPolicyValueNet
+    from fake_model import hash_init_
+
+    saved = (config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS)
+    config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = size
+    try:
+        net = hash_init_(network.PolicyValueNet().eval()).to("cuda:0")
+        fused = FusedPolicyValueNet(net, conv="tower_f16").to("cuda:0")
+        half = net.for_inference(dtype=torch.float16, channels_last=False)
+        z = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "g1_net.npz"))
+        base = torch.from_numpy(z["inputs"]).to("cuda:0")
+        for nb in (1, 2, 7, 300):  # odd counts: the last workgroup holds one board; 300 > 2 x 128 pairs loop
+            x = (base.repeat(nb // 3 + 1, 1, 1, 1)[:nb] * torch.linspace(0.5, 1.0, nb, device="cuda:0")[:, None, None, None]).contiguous()
+            with torch.no_grad():
+                l0, v0 = net(x)
+                l1, v1 = fused(x)
+                l2, v2 = half(x.half())
+            e_ours = max((l0 - l1.float()).abs().max().item(), (v0 - v1.float()).abs().max().item())
+            e_torch = max((l0 - l2.float()).abs().max().item(), (v0 - v2.float()).abs().max().item())
+            scale = max(1.0, l0.abs().max().item())
+            assert e_ours <= max(3.0 * e_torch, 4e-3 * scale), (size, nb, e_ours, e_torch, scale)
+    finally:
+        config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = saved
+
+
 def test_full_size_config_parity_with_real_net(backend):
     """BASELINE.json configs[1] (256 concurrent games, 400 sims/move, 10-block x 128 net) on the GPU for a few plies.
     The (planes -> torch.softmax probabilities, value) pairs the engine consumed are recorded for three slots and
