@@ -705,6 +705,7 @@ extern "C" int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layer
         if (L.bias_off < 0 || (int64_t)L.bias_off + C > n_params) return fail(BO_E_ARG, "bias offset out of range");
         if (L.kind == 3) {
             if (L.hidden < 1 || L.hidden > 16) return fail(BO_E_CONFIG, "SE hidden width must be 1..16");
+            if (algo == BO_TOWER_DIRECT_F16 && L.hidden > C / 16) return fail(BO_E_CONFIG, "BO_TOWER_DIRECT_F16: SE hidden width must be <= channels/16");
             if (L.se_w1_off < 0 || (int64_t)L.se_w1_off + (int64_t)L.hidden * C > n_params || L.se_w2_off < 0 ||
                 (int64_t)L.se_w2_off + (int64_t)L.hidden * C > n_params)
                 return fail(BO_E_ARG, "SE weight offset out of range");

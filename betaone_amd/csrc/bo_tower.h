@@ -33,6 +33,27 @@ struct bo_tower_layer {
     int last;       // 1: also store the result to y (NCHW)
 };
 
+// Cross-lane sums on the VALU (DPP), not through LDS (ds_bpermute): after bo_row_sum every lane holds the sum of its
+// 16-lane row; bo_half_sum: lanes 16..31 / 48..63 hold the sum of lanes 0..31 / 32..63; bo_wave_sum63: lane 63 holds all 64.
+#define BO_DPP(v, ctrl, rmask) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, false))
+__device__ inline float bo_row_sum(float v) {
+    v += BO_DPP(v, 0xB1, 0xF);   // quad_perm [1,0,3,2]
+    v += BO_DPP(v, 0x4E, 0xF);   // quad_perm [2,3,0,1]
+    v += BO_DPP(v, 0x141, 0xF);  // row_half_mirror
+    v += BO_DPP(v, 0x140, 0xF);  // row_mirror
+    return v;
+}
+__device__ inline float bo_half_sum(float v) {
+    v = bo_row_sum(v);
+    v += BO_DPP(v, 0x142, 0xA);  // row_bcast15 into rows 1 and 3
+    return v;
+}
+__device__ inline float bo_wave_sum63(float v) {
+    v = bo_half_sum(v);
+    v += BO_DPP(v, 0x143, 0xC);  // row_bcast31 into rows 2 and 3
+    return v;
+}
+
 // the two 1x1 head convolutions fused behind the tower (bo_tower_wg.h): channels [0, split) go to out_a [B][split][64],
 // channels [split, channels) to out_b [B][channels - split][64]; weights [channels][C] and bias in params
 struct bo_tower_head {

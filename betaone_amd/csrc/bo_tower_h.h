@@ -26,13 +26,17 @@ struct bo_tower_head_h {
     _Float16 *out_a = nullptr, *out_b = nullptr;
 };
 
-template <int C>
+// LAB (scripts/conv_lab.hip only): 0 = the kernel; 1 = no weight loads; 2 = no B operand reads; 4 = no epilogue;
+// 5 = 1 + 2 + 4; 6 = 5 without barriers
+template <int C, int LAB = 0>
 __global__ void __launch_bounds__(C * 2)
 bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const float *__restrict__ params,
              const bo_tower_layer *__restrict__ layers, int n_layers, int B, bo_tower_head_h head) {
     constexpr int NT = C * 2, NW = C / 32, PH = C + 8, CELLS = 100, IMGH = CELLS * PH, CIN0 = 120;
     __shared__ __attribute__((aligned(16))) _Float16 X[2 * IMGH];
-    __shared__ float pooled[2][C], hid[2][16];
+    __shared__ __attribute__((aligned(16))) float pooled[2][C];
+    __shared__ float hid[2][16];
+    static_assert(C == 128 || C == 256, "one float4 of a W1 row per lane");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kg = lane >> 5, n = lane & 31;
     const int cell0 = ((n >> 3) + 1) * 10 + (n & 7) + 1;  // padded cell of position n; position n + 32 is cell0 + 40
 
@@ -43,8 +47,9 @@ bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
     bo_h8 bq[2][4];            // B operands of two consecutive K-steps
     bo_h4 skip[4][4];          // block input at this lane's (positions, channels), packed like the LDS writes
     const _Float16 *xl = X + (size_t)cell0 * PH + 8 * kg;  // + board*IMGH + half*40*PH + tap/channel offset
-    auto load_a = [&](int j, int w_off8, int step) { a[j] = wts[(size_t)w_off8 + ((size_t)step * NW + wave) * 64 + lane]; };
+    auto load_a = [&](int j, int w_off8, int step) { if (LAB != 1 && LAB < 5) a[j] = wts[(size_t)w_off8 + ((size_t)step * NW + wave) * 64 + lane]; };
     auto read_b = [&](bo_h8(&b)[4], int off) {  // off: (tap offset in cells) * PH + 16 * channel group
+        if (LAB == 2 || LAB >= 5) return;
         b[0] = *reinterpret_cast<const bo_h8 *>(xl + off);
         b[1] = *reinterpret_cast<const bo_h8 *>(xl + off + 40 * PH);
         b[2] = *reinterpret_cast<const bo_h8 *>(xl + off + IMGH);
@@ -98,35 +103,41 @@ bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            __syncthreads();  // every wave has read the layer input: the output may overwrite it
+            if (LAB != 6) __syncthreads();  // every wave has read the layer input: the output may overwrite it
 
             // ---- epilogue: rows (r&3) + 8*(r>>2) + 4*kg of tile t are 4 consecutive channels per r>>2 ----
             float gate[2][16];
             if (L.kind == 3) {
+                // SE gate (network.py:33-45) for both boards.  Wave w owns hidden units 2w, 2w+1 (H <= 2 * #waves); lane (n, kg)
+                // owns the gate of channel 32*wave + n of board kg.  Weights are requested first, reductions run on the VALU (DPP).
                 const float *w1 = params + L.se_w1_off, *w2 = params + L.se_w2_off;
                 float w2r[16];
+                const bool have4 = lane < C / 4;  // a W1 row is C/4 float4: one per lane (C = 256) or per lane of the first half (128)
+                bo_f32x4 w1r[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+                    w1r[u] = (have4 && 2 * wave + u < L.hidden) ? reinterpret_cast<const bo_f32x4 *>(w1 + (size_t)(2 * wave + u) * C)[lane] : bo_f32x4{0, 0, 0, 0};
 #pragma unroll
                 for (int h = 0; h < 16; h++) w2r[h] = h < L.hidden ? w2[(wave * 32 + n) * L.hidden + h] : 0.0f;
 #pragma unroll
                 for (int bb = 0; bb < 2; bb++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
-                        float s = acc[2 * bb][r] + acc[2 * bb + 1][r];
-#pragma unroll
-                        for (int m = 16; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-                        if (n == 0) pooled[bb][wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg] = s * (1.0f / 64.0f) + bv[r];
+                        const float s = bo_half_sum(acc[2 * bb][r] + acc[2 * bb + 1][r]);
+                        if (n == 16) pooled[bb][wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg] = s * (1.0f / 64.0f) + bv[r];
                     }
                 __syncthreads();
-                for (int u = wave; u < 2 * L.hidden; u += NW) {  // one wave reduction per (board, hidden unit)
-                    const int bb = u / L.hidden, h = u - bb * L.hidden;
-                    float p = 0.0f;
-                    for (int c = lane; c < C; c += 64) p += w1[h * C + c] * pooled[bb][c];
 #pragma unroll
-                    for (int m = 32; m >= 1; m >>= 1) p += __shfl_xor(p, m);
-                    if (lane == 0) hid[bb][h] = fmaxf(p, 0.0f);
-                }
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int bb = 0; bb < 2; bb++) {
+                        const bo_f32x4 m = have4 ? reinterpret_cast<const bo_f32x4 *>(pooled[bb])[lane] : bo_f32x4{0, 0, 0, 0};
+                        float p = (w1r[u][0] * m[0] + w1r[u][1] * m[1]) + (w1r[u][2] * m[2] + w1r[u][3] * m[3]);
+                        p = bo_wave_sum63(p);
+                        if (lane == 63 && 2 * wave + u < L.hidden) hid[bb][2 * wave + u] = fmaxf(p, 0.0f);
+                    }
                 __syncthreads();
-                float g = 0.0f;  // lane (n, kg): gate of channel 32*wave + n of board kg
+                float g = 0.0f;
 #pragma unroll
                 for (int h = 0; h < 16; h++)
                     if (h < L.hidden) g += w2r[h] * hid[kg][h];
@@ -136,6 +147,9 @@ bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
 #pragma unroll
                     for (int r = 0; r < 16; r++) gate[bb][r] = __shfl(g, (r & 3) + 8 * (r >> 2) + 4 * kg + 32 * bb);
             }
+            if (LAB >= 4) {
+                if (acc[0][0] == 123.456f) X[tid] = (_Float16)(acc[1][1] + acc[2][2] + acc[3][3]);
+            } else
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 _Float16 *cellp = X + (size_t)(t >> 1) * IMGH + (size_t)(cell0 + 40 * (t & 1)) * PH + wave * 32 + 4 * kg;
@@ -154,7 +168,7 @@ bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
                     *reinterpret_cast<bo_h4 *>(cellp + 8 * q) = o;
                 }
             }
-            __syncthreads();
+            if (LAB != 6) __syncthreads();
         }
         // ---- the two 1x1 head convolutions + ReLU on the tower output in X: one 32x32 job per (32 head channels, board, half) ----
         if (head.channels > 0) {

@@ -202,9 +202,7 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
                     // channel means of conv + bias over the 64 squares = 16 tiles x 4 outputs (AdaptiveAvgPool2d(1))
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        float s = (o[r][0] + o[r][1]) + (o[r][2] + o[r][3]);
-#pragma unroll
-                        for (int m = 8; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+                        const float s = bo_row_sum((o[r][0] + o[r][1]) + (o[r][2] + o[r][3]));  // over the 16 tiles (DPP)
                         if (n == 0) pooled[oc0 + r] = s * (1.0f / 64.0f);
                     }
                     __syncthreads();
@@ -212,10 +210,8 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
                     for (int u = 0; u < 2; u++) {  // hidden = relu(W1 mean): one wave reduction per hidden unit
                         const int h = wave + u * NWAVE;
                         if (h < L.hidden) {
-                            float p = w1a[u] * pooled[lane] + (C > 64 ? w1b[u] * pooled[64 + lane] : 0.0f);
-#pragma unroll
-                            for (int m = 32; m >= 1; m >>= 1) p += __shfl_xor(p, m);
-                            if (lane == 0) hid[h] = fmaxf(p, 0.0f);
+                            const float p = bo_wave_sum63(w1a[u] * pooled[lane] + (C > 64 ? w1b[u] * pooled[64 + lane] : 0.0f));
+                            if (lane == 63) hid[h] = fmaxf(p, 0.0f);
                         }
                     }
                     __syncthreads();

@@ -11,7 +11,7 @@ from betaone_amd.fused_net import FusedPolicyValueNet
 
 conv = sys.argv[1] if len(sys.argv) > 1 else "tower_wg"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 8, 2, 128
+config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = (15, 5, 256) if conv == "tower_f16" else (8, 2, 128)
 torch.manual_seed(0)
 net = FusedPolicyValueNet(network.PolicyValueNet().cuda().eval(), conv=conv).cuda()
 x = torch.randn(B, 120, 8, 8, device="cuda")
