@@ -35,3 +35,43 @@ def test_product_loader_has_no_fallback(monkeypatch, tmp_path):
     monkeypatch.setattr(E, "_hip_lib", None)
     with pytest.raises(E.EngineError):
         E.load_hip_library()
+
+
+def test_tower_descriptors_are_validated_before_any_device_call():
+    """bo_nn_tower_create / bo_nn_conv3x3 / bo_nn_tower_forward reject malformed arguments on the host (no GPU here:
+    a descriptor that passed would go on to hipMalloc and fail differently)."""
+    import numpy as np
+
+    lib = E.bind(C.CDLL(build.build()))
+    lib.bo_last_error.restype = C.c_char_p
+    c, per_direct, per_wg = 128, 9 * 16 * 128 * 2 * 4, 32 * 8 * 4 * 64 * 4  # floats per 128->128 layer
+    w = np.zeros(3 * per_wg, np.float32)
+    p = np.zeros(4096, np.float32)
+    out = C.c_void_p()
+
+    def create(rows, algo, channels=c, head=None, n_w=None):
+        t = np.ascontiguousarray(np.array(rows, dtype=np.int32))
+        return lib.bo_nn_tower_create(t.ctypes.data, len(rows), w.ctypes.data, w.size if n_w is None else n_w, p.ctypes.data, p.size, channels, algo,
+                                      head.ctypes.data if head is not None else None, 0, C.byref(out))
+
+    good_direct = [[0, 16, 0, 0, 0, 0, 0, 0], [per_direct // 4, 16, 128, 1, 0, 0, 0, 0], [2 * per_direct // 4, 16, 256, 2, 0, 0, 0, 1]]
+    bad = [
+        (lambda: create(good_direct, 0, channels=96), E.BO_E_CONFIG if hasattr(E, "BO_E_CONFIG") else -3),          # unsupported filter count
+        (lambda: create(good_direct, 7), -1),                                                                        # unknown algo
+        (lambda: create([[0, 15, 0, 0, 0, 0, 0, 0]] + good_direct[1:], 0), -1),                                       # wrong K-step count
+        (lambda: create([good_direct[1]] + good_direct[1:], 0), -1),                                                  # first layer must be the input conv
+        (lambda: create(good_direct[:2], 0), -1),                                                                     # a first conv without its second conv
+        (lambda: create(good_direct, 0, n_w=per_direct), -1),                                                         # weights offset beyond the buffer
+        (lambda: create(good_direct[:2] + [[2 * per_direct // 4, 16, 4000, 2, 0, 0, 0, 1]], 0), -1),                  # bias offset beyond params
+        (lambda: create(good_direct[:2] + [[2 * per_direct // 4, 16, 256, 3, 0, 0, 17, 1]], 0), -3),                  # SE hidden width > 16
+        (lambda: create(good_direct[:2] + [[2 * per_direct // 4, 16, 256, 2, 0, 0, 0, 0]], 0), -1),                   # nobody stores the output
+        (lambda: create(good_direct, 0, head=np.array([34, 2, 0, 0], np.int32)), -3),                                 # fused head needs Winograd / fp16
+        (lambda: create(good_direct, 2, channels=256), -1),                                                           # fp16 tower without head
+    ]
+    for i, (call, code) in enumerate(bad):
+        rc = call()
+        assert rc == code and lib.bo_last_error(), (i, rc, code, lib.bo_last_error())
+    assert lib.bo_nn_conv3x3(1, 1, 1, None, 1, 4, 24, 24, 0, None) == -3      # no instantiation for 24 filters
+    assert lib.bo_nn_conv3x3(1, 1, 1, None, 1, 4, 128, 128, 2, None) == -1    # residual epilogue without a residual
+    assert lib.bo_nn_tower_forward(None, 1, 1, None, None, 4, None) == -1
+    assert lib.bo_nn_value_tail(None, 1, 1, 1, 4, 8, None) == -1
