@@ -156,3 +156,70 @@ bo_k_conv3x3(const float *__restrict__ x, const bo_f32x4 *__restrict__ wp, const
     }
 }
 #endif
+
+#if !defined(BO_WAVE_EMU)
+// ---- small-batch form (BASELINE.json configs[3]: uci.py analyses ONE position, 20-block x 256 net) ---------------------
+// bo_k_conv3x3 gives a board one workgroup, so a batch of 1 would use 1 of 256 CUs.  Here one board's layer is cut into
+// (C_out/16) x 4 workgroups: 16 output channels x 16 positions (two board rows) each, and the four waves of a workgroup
+// split K (a quarter of the input channels each, all 9 taps) and reduce through LDS: 64 workgroups for a 256-filter layer,
+// 144 v_mfma_f32_16x16x4_f32 per wave = 2 us of MFMA time.  Each wave stages only what it needs (its channels, the two
+// rows + halo: 4 x 10 cells) -- no workgroup-wide data, one barrier before the reduction.
+// Weights: Ws[oc/16][tap][c_in/16][lane = 16*(ic&3) + (oc&15)][e] = W[oc][16*g + 4*e + (ic&3)][tap].
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256)
+bo_k_conv3x3_small(const float *__restrict__ x, const bo_f32x4 *__restrict__ ws, const float *__restrict__ bias,
+                   const float *__restrict__ res, float *__restrict__ y, int c_in_x, int mode) {
+    constexpr int CQ = CIN / 4, G = CQ / 16, SLAB = 40;  // channels per wave, weight groups per wave, cells per channel
+    __shared__ float Xs[4][CQ * SLAB];
+    __shared__ bo_f32x4 red[4][64];
+    const int ot = blockIdx.x, pt = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kq = lane >> 4, n = lane & 15;
+    const bo_f32x4 *wl = ws + ((size_t)ot * 9 * (CIN / 16) + wave * G) * 64 + lane;  // + (tap*(CIN/16) + g)*64
+    // everything this wave will read is requested up front: its 9*G weight fragments (registers) and its slab (one global
+    // round trip for the layer instead of one per tap / per staging iteration)
+    bo_f32x4 a[9][G];
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+        for (int g = 0; g < G; g++) a[tap][g] = wl[(tap * (CIN / 16) + g) * 64];
+    {   // this wave's slab: channels wave*CQ .. +CQ, board rows 2pt-1 .. 2pt+2, columns -1 .. 8
+        constexpr int NST = CQ * SLAB / 64;
+        const float *xb = x + ((size_t)b * c_in_x + wave * CQ) * 64;
+        float st[NST];
+#pragma unroll
+        for (int u = 0; u < NST; u++) {
+            const int i = lane + 64 * u, c = i / SLAB, cell = i - c * SLAB, r = cell / 10, col = cell - r * 10 - 1, row = 2 * pt - 1 + r;
+            const bool in = row >= 0 && row < 8 && col >= 0 && col < 8 && wave * CQ + c < c_in_x;
+            st[u] = in ? xb[c * 64 + row * 8 + col] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < NST; u++) Xs[wave][lane + 64 * u] = st[u];
+    }
+    __syncthreads();
+    const float *xl = &Xs[wave][kq * SLAB + (n >> 3) * 10 + (n & 7)];  // + ch4*4*SLAB + (tap/3)*10 + tap%3
+    bo_f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {
+        const int off = (tap / 3) * 10 + tap % 3;
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tap][g][e], xl[(4 * g + e) * 4 * SLAB + off], acc, 0, 0, 0);
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+        const bo_f32x4 s0 = red[0][lane], s1 = red[1][lane], s2 = red[2][lane], s3 = red[3][lane];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int oc = 16 * ot + 4 * kq + r;
+            const size_t o = ((size_t)b * COUT + oc) * 64 + 16 * pt + n;
+            float v = ((s0[r] + s1[r]) + (s2[r] + s3[r])) + bias[oc];
+            if (mode == BO_CONV_BIAS_RES_RELU) v += res[o];
+            if (mode != BO_CONV_RAW_BIAS) v = v > 0.0f ? v : 0.0f;
+            y[o] = v;
+        }
+    }
+}
+#endif

@@ -808,3 +808,28 @@ extern "C" int bo_nn_value_tail(const float *h_dev, const float *w_dev, const fl
     return BO_OK;
 #endif
 }
+
+// small-batch form of bo_nn_conv3x3 (bo_conv.h: bo_k_conv3x3_small): (c_out/16) x 4 workgroups per board
+extern "C" int bo_nn_conv3x3_small(const float *x_dev, const float *wpacked_dev, const float *bias_dev, const float *residual_dev, float *y_dev,
+                                   int batch, int c_in, int c_in_x, int c_out, int mode, void *stream) {
+#if defined(BO_WAVE_EMU)
+    (void)x_dev; (void)wpacked_dev; (void)bias_dev; (void)residual_dev; (void)y_dev; (void)batch; (void)c_in; (void)c_in_x; (void)c_out; (void)mode; (void)stream;
+    return fail(BO_E_CONFIG, "bo_nn_conv3x3_small is a gfx950-only kernel");
+#else
+    if (!x_dev || !wpacked_dev || !bias_dev || !y_dev || batch < 1 || batch > 65535) return fail(BO_E_ARG, "bad arguments");
+    if (mode < 0 || mode > 2 || (mode == 2 && !residual_dev)) return fail(BO_E_ARG, "bad epilogue mode");
+    if (c_in_x < 1 || c_in_x > c_in) return fail(BO_E_ARG, "c_in_x must be in 1..c_in");
+    const bo_f32x4 *wp = reinterpret_cast<const bo_f32x4 *>(wpacked_dev);
+    hipStream_t st = (hipStream_t)stream;
+#define BO_SMALL_CASE(CI, CO)                                                                                                             \
+    if (c_in == CI && c_out == CO) {                                                                                                      \
+        hipLaunchKernelGGL((bo_k_conv3x3_small<CI, CO>), dim3(CO / 16, 4, (unsigned)batch), dim3(256), 0, st, x_dev, wp, bias_dev, residual_dev, \
+                           y_dev, c_in_x, mode);                                                                                          \
+        RT((int)hipGetLastError());                                                                                                       \
+        return BO_OK;                                                                                                                     \
+    }
+    BO_SMALL_CASE(128, 64) BO_SMALL_CASE(64, 64) BO_SMALL_CASE(128, 128) BO_SMALL_CASE(128, 256) BO_SMALL_CASE(256, 256)
+#undef BO_SMALL_CASE
+    return fail(BO_E_CONFIG, "bo_nn_conv3x3_small: supported (c_in, c_out): (128 | C, C) for C in {64, 128, 256}");
+#endif
+}

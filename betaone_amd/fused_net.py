@@ -10,6 +10,8 @@ elementwise launches PyTorch issues (bias, ReLU, residual add, SE pooling / FCs 
   conv="mfma":   the 3x3 convolutions run in csrc/bo_conv.h (direct implicit GEMM on the fp32 matrix cores, bias /
                  ReLU / residual fused into its epilogue); SE blocks add csrc/bo_nn_fused.h's SE kernel.
 
+  conv="mfma_small": the small-batch form of "mfma" (bo_k_conv3x3_small: a board's layer is spread over (c_out/16) x 4
+                 workgroups) for uci.py's single-position searches (BASELINE.json configs[3]).
   conv="tower":  input conv + all residual blocks are ONE persistent kernel that keeps each board's activations in
                  LDS (csrc/bo_tower.h); 64 or 128 filters.
   conv="tower_wg": the same with Winograd F(2x2,3x3) convolutions (csrc/bo_tower_wg.h), 2.25x fewer MFMA cycles.
@@ -59,6 +61,25 @@ def pack_conv_weight_f16(w: torch.Tensor) -> torch.Tensor:
     co, ci = w.shape[0], w.shape[1]
     u = w.reshape(co // 32, 32, ci // 16, 2, 8, 9)  # [mt][o][cg][kg][i][tap]
     return u.permute(5, 2, 0, 3, 1, 4).contiguous().half()  # [tap][cg][mt][kg][o][i]
+
+
+def pack_conv_weight_small(w: torch.Tensor) -> torch.Tensor:
+    """[c_out, c_in, 3, 3] -> [c_out/16][tap 9][c_in/16][64][4] (bo_nn_conv3x3_small): element (ot, tap, g, lane, e) =
+    W[16*ot + (lane & 15)][16*g + 4*e + (lane >> 4)][tap]."""
+    co, ci = w.shape[0], w.shape[1]
+    u = w.reshape(co // 16, 16, ci // 16, 4, 4, 9)  # [ot][o][g][e][k][tap]
+    return u.permute(0, 5, 2, 4, 1, 3).contiguous()  # [ot][tap][g][k][o][e]
+
+
+def conv3x3_small(lib, x, wpacked, bias, c_in, c_out, mode=0, residual=None):
+    """y = epilogue(conv3x3(x)) through bo_nn_conv3x3_small; x NCHW float32 [B, c_in_x <= c_in, 8, 8], contiguous."""
+    B = x.shape[0]
+    y = torch.empty((B, c_out, 8, 8), dtype=torch.float32, device=x.device)
+    rc = lib.bo_nn_conv3x3_small(x.data_ptr(), wpacked.data_ptr(), bias.data_ptr(), residual.data_ptr() if residual is not None else None,
+                                 y.data_ptr(), B, c_in, x.shape[1], c_out, mode, torch.cuda.current_stream(x.device).cuda_stream)
+    if rc:
+        raise E.EngineError(lib.bo_last_error().decode())
+    return y
 
 
 def conv3x3_mfma(lib, x, wpacked, bias, c_out, mode=0, residual=None, out=None):
@@ -126,6 +147,23 @@ class FusedPolicyValueNet(nn.Module):
                 self.packed.append((p1, p2))
             self.zero_bias = nn.Parameter(torch.zeros(self.c, device=dev), requires_grad=False)
             self.layout = "nchw+mfma"
+        elif conv == "mfma_small":
+            c = self.w_in.shape[0]
+            if c not in (64, 128, 256) or self.w_in.shape[1] != 120:
+                raise E.EngineError("conv='mfma_small' supports 120 input planes and 64, 128 or 256 filters")
+            self.c = c
+            w0 = torch.zeros((c, 128, 3, 3), device=dev)
+            w0[:, :120] = self.w_in
+            self.p_in = nn.Parameter(pack_conv_weight_small(w0), requires_grad=False)
+            self.packed = []
+            for i, (w1, _, w2, _, _) in enumerate(self.blocks):
+                p1 = nn.Parameter(pack_conv_weight_small(w1), requires_grad=False)
+                p2 = nn.Parameter(pack_conv_weight_small(w2), requires_grad=False)
+                self.register_parameter(f"blk{i}_p1", p1)
+                self.register_parameter(f"blk{i}_p2", p2)
+                self.packed.append((p1, p2))
+            self.zero_bias = nn.Parameter(torch.zeros(c, device=dev), requires_grad=False)
+            self.layout = "nchw+mfma_small"
         elif conv in ("tower", "tower_wg"):
             self._build_tower(dev, winograd=conv == "tower_wg")
             self.layout = "nchw+" + conv
@@ -133,7 +171,7 @@ class FusedPolicyValueNet(nn.Module):
             self._build_tower_f16(dev)
             self.layout = "nchw+tower_f16"
         elif conv != "miopen":
-            raise ValueError("conv must be 'miopen', 'mfma', 'tower', 'tower_wg' or 'tower_f16'")
+            raise ValueError("conv must be 'miopen', 'mfma', 'mfma_small', 'tower', 'tower_wg' or 'tower_f16'")
 
     def _build_tower_f16(self, dev):
         """fp16 tower (bo_nn_tower_create, BO_TOWER_DIRECT_F16) + half copies of the three head Linear layers."""
@@ -336,6 +374,17 @@ class FusedPolicyValueNet(nn.Module):
                 x = conv3x3_mfma(L, y, p2, b2, C, 2, residual=x)
         return x
 
+    def _tower_small(self, x):
+        L, C = self.lib, self.c
+        x = conv3x3_small(L, x.contiguous(), self.p_in, self.b_in, 128, C, 1)
+        for (w1, b1, w2, b2, se), (p1, p2) in zip(self.blocks, self.packed):
+            y = conv3x3_small(L, x, p1, b1, C, C, 1)
+            if se is not None:
+                x = self._se(conv3x3_small(L, y, p2, self.zero_bias, C, C, 0), b2, se, x)
+            else:
+                x = conv3x3_small(L, y, p2, b2, C, C, 2, residual=x)
+        return x
+
     @torch.no_grad()
     def forward(self, x):
         if self.conv == "tower_f16":
@@ -345,8 +394,8 @@ class FusedPolicyValueNet(nn.Module):
             p, v = self._tower_forward(x, heads=True)
             h = torch._addmm_activation(self.value_fc1.bias, v, self.value_fc1.weight.t())  # relu(fc1)
             return self.policy_fc(p), self._value_tail(h)
-        if self.conv in ("mfma", "tower"):
-            x = self._tower_mfma(x) if self.conv == "mfma" else self._tower_forward(x)
+        if self.conv in ("mfma", "tower", "mfma_small"):
+            x = self._tower_mfma(x) if self.conv == "mfma" else self._tower_small(x) if self.conv == "mfma_small" else self._tower_forward(x)
             h = self._epi(F.conv2d(x, self.w_head, None), self.b_head)
             p = h[:, :self.n_policy_ch].flatten(1)
             v = h[:, self.n_policy_ch:].flatten(1)

@@ -217,6 +217,13 @@ int bo_nn_se_residual(float *x_dev, const float *bias_dev, const float *w1_dev, 
 int bo_nn_conv3x3(const float *x_dev, const float *wpacked_dev, const float *bias_dev, const float *residual_dev,
                   float *y_dev, int batch, int c_in, int c_out, int mode, void *stream);
 
+/* Small-batch form of bo_nn_conv3x3 (uci.py's single-position analysis): (c_out/16) x 4 workgroups per board, K split
+ * over the four waves of a workgroup.  wpacked_dev: [c_out/16][tap 9][c_in/16][64][4] with element (ot, tap, g, lane, e) =
+ * W[16*ot + (lane & 15)][16*g + 4*e + (lane >> 4)][tap]; c_in in {64, 128, 256} is the (zero-padded) channel count of
+ * the weights, c_in_x <= c_in the channel count of x (120 for the input conv with c_in = 128).  Same modes. */
+int bo_nn_conv3x3_small(const float *x_dev, const float *wpacked_dev, const float *bias_dev, const float *residual_dev, float *y_dev,
+                        int batch, int c_in, int c_in_x, int c_out, int mode, void *stream);
+
 /* The whole residual tower (input conv + N residual blocks, /root/reference/network.py:48-118,167-190, BatchNorm
  * folded) as ONE persistent kernel that keeps each board's activations in LDS.  channels in {64, 128}.
  * Layer l: kind 0 = input conv 120 -> C with ReLU (first layer only; weights zero-padded to 128 input channels),

@@ -190,7 +190,7 @@ def test_mfma_conv3x3_matches_float64_convolution(backend, shape):
         conv3x3_mfma(lib, torch.zeros((1, 24, 8, 8)).cuda(), wp, bias, co)
 
 
-@pytest.mark.parametrize("conv", ["miopen", "mfma", "tower", "tower_wg"])
+@pytest.mark.parametrize("conv", ["miopen", "mfma", "mfma_small", "tower", "tower_wg"])
 @pytest.mark.parametrize("size", [(3, 1, 64), (8, 2, 128), (2, 2, 256), (0, 3, 128), (4, 0, 64)])
 def test_fused_epilogue_net_matches_plain_net(backend, size, conv):
     """csrc/bo_nn_fused.h, csrc/bo_conv.h, csrc/bo_tower.h: conv (MIOpen, the fp32-MFMA direct kernel, or the whole
