@@ -41,8 +41,15 @@ struct bo_engine {
     int *d_go = nullptr, *d_action = nullptr;
     std::vector<int> h_i32;  // scratch [G]
     std::vector<HostRng> rng;          // one legacy MT19937 stream per game slot (bo_rng_seed)
-    std::vector<double> h_noise;       // [G][256]
-    std::vector<int> h_nl, h_term, h_go;
+    // The per-move host exchange goes through two device blocks and their pinned mirrors, one copy each:
+    //   res  = [res_n | res_best_idx | res_best_mv | res_total | res_idx[RES_CAP] | res_val[RES_CAP]]  (G rows each)
+    //   info = [phase | req_node | root_nlegal | root_term | ply]
+    int *d_res_blk = nullptr, *d_info_blk = nullptr;
+    int *h_res = nullptr, *h_info = nullptr;  // pinned
+    double *h_noise = nullptr;                // pinned [G][256]
+    int *h_go = nullptr;                      // pinned [G]
+    std::vector<int> h_nl, h_term;
+    bool nl_valid = false;  // h_nl holds the current roots' legal-move counts (set by bo_selfplay_begin)
     template <class T> int alloc(T **p, size_t n) {
         void *v = nullptr;
         int rc = rt_malloc(&v, n * sizeof(T));
@@ -188,11 +195,21 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
     int rc = 0;
     float *sq = nullptr; int *wl = nullptr;
     rc |= e->alloc(&sq, (size_t)c.S + 2); rc |= e->alloc(&wl, (size_t)c.B + 1);
-    int **iscal[] = {&d.phase, &d.sims_done, &d.n_nodes, &d.rows, &d.n_runs, &d.n_ul, &d.req_node, &d.req_nlegal, &d.status,
-                     &d.ply, &d.trk_n, &d.n_hist, &d.ctx_mode, &d.root_nlegal, &d.root_term, &d.root_nch, &d.stat_evals,
-                     &d.stat_flushes, &d.stat_term_sims, &d.stat_levels, &d.stat_children_scanned, &d.res_n,
-                     &d.res_best_idx, &d.res_best_mv, &d.res_total, &e->d_go, &e->d_action};
+    int **iscal[] = {&d.sims_done, &d.n_nodes, &d.rows, &d.n_runs, &d.n_ul, &d.req_nlegal, &d.status,
+                     &d.trk_n, &d.n_hist, &d.ctx_mode, &d.root_nch, &d.stat_evals,
+                     &d.stat_flushes, &d.stat_term_sims, &d.stat_levels, &d.stat_children_scanned, &e->d_go, &e->d_action};
     for (int **p : iscal) rc |= e->alloc(p, G);
+    const size_t res_ints = G * (4 + 2 * (size_t)BO_RES_CAP), info_ints = G * 5;
+    rc |= e->alloc(&e->d_res_blk, res_ints); rc |= e->alloc(&e->d_info_blk, info_ints);
+    if (!rc) {
+        d.res_n = e->d_res_blk; d.res_best_idx = e->d_res_blk + G; d.res_best_mv = e->d_res_blk + 2 * G; d.res_total = e->d_res_blk + 3 * G;
+        d.res_idx = e->d_res_blk + 4 * G; d.res_val = reinterpret_cast<float *>(e->d_res_blk + 4 * G + G * BO_RES_CAP);
+        d.phase = e->d_info_blk; d.req_node = e->d_info_blk + G; d.root_nlegal = e->d_info_blk + 2 * G; d.root_term = e->d_info_blk + 3 * G;
+        d.ply = e->d_info_blk + 4 * G;
+        rt_memset(e->d_res_blk, 0, res_ints * 4, nullptr); rt_memset(e->d_info_blk, 0, info_ints * 4, nullptr);
+    }
+    rc |= rt_host_alloc((void **)&e->h_res, res_ints * 4); rc |= rt_host_alloc((void **)&e->h_info, info_ints * 4);
+    rc |= rt_host_alloc((void **)&e->h_noise, G * BO_MAX_MOVES * sizeof(double)); rc |= rt_host_alloc((void **)&e->h_go, G * 4);
     rc |= e->alloc(&d.gpos, G * c.PLY_CAP); rc |= e->alloc(&d.trk, G * c.TRK_CAP); rc |= e->alloc(&d.trk_cnt, G * c.TRK_CAP);
     rc |= e->alloc(&d.hist, G * 7);
     rc |= e->alloc(&d.n_visits, N); rc |= e->alloc(&d.parent, N); rc |= e->alloc(&d.first_child, N); rc |= e->alloc(&d.n_children, N);
@@ -204,7 +221,6 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
     rc |= e->alloc(&d.req_moves, G * BO_MAX_MOVES); rc |= e->alloc(&d.root_moves, G * BO_MAX_MOVES);
     rc |= e->alloc(&d.root_child_rank, G * 2 * BO_CH_CAP); rc |= e->alloc(&d.noise, G * BO_MAX_MOVES);
     rc |= e->alloc(&d.played, G * c.PLY_CAP);
-    rc |= e->alloc(&d.res_idx, G * BO_RES_CAP); rc |= e->alloc(&d.res_val, G * BO_RES_CAP);
     rc |= e->alloc(&d.prof, G * 8);
     if (fast) {
         FastEng &f = e->f;
@@ -230,8 +246,8 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
     e->h_i32.resize(G);
     e->rng.resize(G);
     for (size_t g = 0; g < G; g++) hr_seed(&e->rng[g], (uint32_t)g);
-    e->h_noise.assign(G * BO_MAX_MOVES, 0.0);
-    e->h_nl.resize(G); e->h_term.resize(G); e->h_go.resize(G);
+    memset(e->h_noise, 0, G * BO_MAX_MOVES * sizeof(double));
+    e->h_nl.resize(G); e->h_term.resize(G);
     *out = e;
     return BO_OK;
 }
@@ -240,6 +256,7 @@ extern "C" void bo_engine_destroy(bo_engine *e) {
     if (!e) return;
     rt_set_device(e->device);
     for (void *p : e->allocs) rt_free(p);
+    rt_host_free(e->h_res); rt_host_free(e->h_info); rt_host_free(e->h_noise); rt_host_free(e->h_go);
     delete e;
 }
 
@@ -320,10 +337,11 @@ extern "C" int bo_games_reset(bo_engine *e, int n, const int32_t *slots, const c
 extern "C" int bo_root_info(bo_engine *e, int32_t *n_legal, int32_t *terminal, int32_t *ply, void *stream) {
     if (!e) return fail(BO_E_ARG, "null engine");
     const size_t G = (size_t)e->d.c.G;
-    if (n_legal) RT(rt_d2h(n_legal, e->d.root_nlegal, G * 4, stream));
-    if (terminal) RT(rt_d2h(terminal, e->d.root_term, G * 4, stream));
-    if (ply) RT(rt_d2h(ply, e->d.ply, G * 4, stream));
+    RT(rt_d2h(e->h_info + 2 * G, e->d_info_blk + 2 * G, 3 * G * 4, stream));  // [root_nlegal | root_term | ply] in one copy
     RT(rt_sync(stream));
+    if (n_legal) memcpy(n_legal, e->h_info + 2 * G, G * 4);
+    if (terminal) memcpy(terminal, e->h_info + 3 * G, G * 4);
+    if (ply) memcpy(ply, e->h_info + 4 * G, G * 4);
     return BO_OK;
 }
 
@@ -332,8 +350,19 @@ extern "C" int bo_search_begin(bo_engine *e, const int32_t *go, const double *no
     if (!e || !go || !nn_in_dev) return fail(BO_E_ARG, "null argument");
     const size_t G = (size_t)e->d.c.G;
     if (e->d.c.use_noise && !noise) return fail(BO_E_ARG, "noise required when dirichlet_alpha > 0");
-    RT(rt_h2d(e->d_go, go, G * 4, stream));
-    if (noise) RT(rt_h2d(e->d.noise, noise, G * BO_MAX_MOVES * sizeof(double), stream));
+    if (go != e->h_go) memcpy(e->h_go, go, G * 4);  // pinned staging: one DMA, no pageable bounce buffer
+    RT(rt_h2d(e->d_go, e->h_go, G * 4, stream));
+    if (noise) {
+        if (noise != e->h_noise) memcpy(e->h_noise, noise, G * BO_MAX_MOVES * sizeof(double));
+        size_t cols = 1;  // only the columns some root uses travel (the kernel reads noise[g][j < n_legal(g)])
+        for (size_t g = 0; g < G; g++)
+            if (e->h_go[g] && (size_t)e->h_nl[g] > cols) cols = (size_t)e->h_nl[g];
+        if (e->nl_valid && cols < BO_MAX_MOVES)
+            RT(rt_h2d_2d(e->d.noise, BO_MAX_MOVES * sizeof(double), e->h_noise, BO_MAX_MOVES * sizeof(double), cols * sizeof(double), G, stream));
+        else
+            RT(rt_h2d(e->d.noise, e->h_noise, G * BO_MAX_MOVES * sizeof(double), stream));
+    }
+    e->nl_valid = false;
     if (e->fast) RT(RT_LAUNCH(bo_k_fast_search_begin, e->d.c.G, stream, e->d, e->f, (const int *)e->d_go, nn_in_dev));
     else RT(RT_LAUNCH(bo_k_search_begin, e->d.c.G, stream, e->d, (const int *)e->d_go, nn_in_dev));
     return BO_OK;
@@ -351,9 +380,8 @@ extern "C" int bo_step(bo_engine *e, const float *policy_dev, const float *value
 extern "C" int bo_search_poll(bo_engine *e, int32_t *n_running, int32_t *n_requested, int32_t *requested_mask, void *stream) {
     if (!e) return fail(BO_E_ARG, "null engine");
     const size_t G = (size_t)e->d.c.G;
-    std::vector<int> ph(G), rq(G);
-    RT(rt_d2h(ph.data(), e->d.phase, G * 4, stream));
-    RT(rt_d2h(rq.data(), e->d.req_node, G * 4, stream));
+    RT(rt_d2h(e->h_info, e->d_info_blk, 2 * G * 4, stream));  // [phase | req_node] in one copy
+    const int *ph = e->h_info, *rq = e->h_info + G;
     RT(rt_sync(stream));
     int run = 0, req = 0;
     for (size_t g = 0; g < G; g++) {
@@ -373,13 +401,15 @@ extern "C" int bo_search_result(bo_engine *e, int32_t *res_n, int32_t *res_idx, 
     const size_t G = (size_t)e->d.c.G;
     if (e->fast) RT(RT_LAUNCH(bo_k_fast_result, e->d.c.G, stream, e->d));
     else RT(RT_LAUNCH(bo_k_result, e->d.c.G, stream, e->d));
-    if (res_n) RT(rt_d2h(res_n, e->d.res_n, G * 4, stream));
-    if (res_idx) RT(rt_d2h(res_idx, e->d.res_idx, G * BO_RES_CAP * 4, stream));
-    if (res_val) RT(rt_d2h(res_val, e->d.res_val, G * BO_RES_CAP * 4, stream));
-    if (best_idx) RT(rt_d2h(best_idx, e->d.res_best_idx, G * 4, stream));
-    if (best_move) RT(rt_d2h(best_move, e->d.res_best_mv, G * 4, stream));
-    if (total_visits) RT(rt_d2h(total_visits, e->d.res_total, G * 4, stream));
+    RT(rt_d2h(e->h_res, e->d_res_blk, G * (4 + 2 * (size_t)BO_RES_CAP) * 4, stream));  // the whole result block in one copy
     RT(rt_sync(stream));
+    const int *h = e->h_res;
+    if (res_n) memcpy(res_n, h, G * 4);
+    if (best_idx) memcpy(best_idx, h + G, G * 4);
+    if (best_move) memcpy(best_move, h + 2 * G, G * 4);
+    if (total_visits) memcpy(total_visits, h + 3 * G, G * 4);
+    if (res_idx) memcpy(res_idx, h + 4 * G, G * BO_RES_CAP * 4);
+    if (res_val) memcpy(res_val, h + 4 * G + G * BO_RES_CAP, G * BO_RES_CAP * 4);
     return BO_OK;
 }
 
@@ -391,6 +421,76 @@ extern "C" int bo_play(bo_engine *e, const int32_t *action, void *stream) {
 }
 
 // ---- native per-move host work (bit-compatible with numpy.random.RandomState; bo_hostrng.h) ----------------------
+// The per-game streams are independent, so the G Dirichlet draws / temperature samples of a ply are spread over a few
+// persistent worker threads (the GPU idles during this phase: 160 us single-threaded for 256 roots).
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+namespace {
+struct BoPool {
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv_go, cv_done;
+    const std::function<void(int)> *job = nullptr;
+    int n_items = 0, chunk = 1, generation = 0, pending = 0;
+    std::atomic<int> next{0};
+    bool stop = false;
+    explicit BoPool(int n) {
+        for (int i = 0; i < n; i++) workers.emplace_back([this] { loop(); });
+    }
+    ~BoPool() {
+        { std::lock_guard<std::mutex> l(m); stop = true; }
+        cv_go.notify_all();
+        for (auto &t : workers) t.join();
+    }
+    void drain() {
+        for (;;) {
+            const int b = next.fetch_add(chunk);
+            if (b >= n_items) return;
+            const int e = b + chunk < n_items ? b + chunk : n_items;
+            for (int i = b; i < e; i++) (*job)(i);
+        }
+    }
+    void loop() {
+        int seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> l(m);
+                cv_go.wait(l, [&] { return stop || generation != seen; });
+                if (stop) return;
+                seen = generation;
+            }
+            drain();
+            { std::lock_guard<std::mutex> l(m); pending--; }
+            cv_done.notify_one();
+        }
+    }
+    void run(int n, const std::function<void(int)> &f) {
+        if (workers.empty() || n < 64) { for (int i = 0; i < n; i++) f(i); return; }
+        {
+            std::lock_guard<std::mutex> l(m);
+            job = &f; n_items = n; chunk = 8; next = 0; pending = (int)workers.size(); generation++;
+        }
+        cv_go.notify_all();
+        drain();  // the calling thread works too
+        std::unique_lock<std::mutex> l(m);
+        cv_done.wait(l, [&] { return pending == 0; });
+    }
+};
+BoPool &host_pool() {
+    static BoPool pool([] {
+        const char *v = getenv("BO_HOST_THREADS");
+        int n = v ? atoi(v) : 4;
+        const int hw = (int)std::thread::hardware_concurrency();
+        if (hw > 0 && n > hw / 2) n = hw / 2;  // leave room for the other ranks of a node
+        return n < 1 ? 0 : n - 1;
+    }());
+    return pool;
+}
+}  // namespace
+
 extern "C" int bo_rng_seed(bo_engine *e, int slot, uint32_t seed) {
     if (!e || slot < 0 || slot >= e->d.c.G) return fail(BO_E_ARG, "bad slot");
     hr_seed(&e->rng[slot], seed);
@@ -417,14 +517,14 @@ extern "C" int bo_selfplay_sample(bo_engine *e, const int32_t *active, const int
     int rc = bo_search_result(e, res_n, res_idx, res_val, best_idx, nullptr, nullptr, stream);
     if (rc) return rc;
     const int G = e->d.c.G;
-    for (int g = 0; g < G; g++) {
-        if (!active[g]) { action_out[g] = -1; continue; }
+    host_pool().run(G, [&](int g) {
+        if (!active[g]) { action_out[g] = -1; return; }
         const int32_t *ri = res_idx + (size_t)g * BO_RES_CAP;
         const float *rv = res_val + (size_t)g * BO_RES_CAP;
         const int a = e->fast ? hr_select_action_general(&e->rng[g], res_n[g], ri, rv, move_number[g], threshold, t_initial, t_final)
                               : hr_select_action(&e->rng[g], res_n[g], ri, rv, move_number[g], threshold, t_initial, t_final);
         action_out[g] = a >= 0 ? a : -3;  // -3: not sparse enough, the caller samples with the dense NumPy mirror
-    }
+    });
     return BO_OK;
 }
 
@@ -435,15 +535,16 @@ extern "C" int bo_selfplay_begin(bo_engine *e, const int32_t *want, float *nn_in
     int rc = bo_root_info(e, e->h_nl.data(), e->h_term.data(), nullptr, stream);
     if (rc) return rc;
     const double alpha = e->cfg.dirichlet_alpha;
-    for (int g = 0; g < G; g++) {
+    host_pool().run(G, [&](int g) {
         const int go = want[g] && e->h_term[g] == 0;
         e->h_go[g] = go;
         if (go && alpha > 0) hr_dirichlet(&e->rng[g], alpha, e->h_nl[g], &e->h_noise[(size_t)g * BO_MAX_MOVES]);  // mcts.py:192
         if (n_legal_out) n_legal_out[g] = e->h_nl[g];
         if (terminal_out) terminal_out[g] = e->h_term[g];
         if (go_out) go_out[g] = go;
-    }
-    rc = bo_search_begin(e, e->h_go.data(), alpha > 0 ? e->h_noise.data() : nullptr, nn_in_dev, stream);
+    });
+    e->nl_valid = true;
+    rc = bo_search_begin(e, e->h_go, alpha > 0 ? e->h_noise : nullptr, nn_in_dev, stream);
     if (rc) return rc;
     return bo_step(e, nullptr, nullptr, BO_POLICY_NONE, nn_in_dev, stream);
 }

@@ -13,6 +13,12 @@ static inline int rt_h2d(void *d, const void *h, size_t n, void *) { memcpy(d, h
 static inline int rt_d2h(void *h, const void *d, size_t n, void *) { memcpy(h, d, n); return 0; }
 static inline int rt_memset(void *d, int v, size_t n, void *) { memset(d, v, n); return 0; }
 static inline int rt_sync(void *) { return 0; }
+static inline int rt_host_alloc(void **p, size_t n) { *p = calloc(n ? n : 1, 1); return *p ? 0 : -1; }
+static inline void rt_host_free(void *p) { free(p); }
+static inline int rt_h2d_2d(void *d, size_t dpitch, const void *h, size_t hpitch, size_t width, size_t height, void *) {
+    for (size_t r = 0; r < height; r++) memcpy((char *)d + r * dpitch, (const char *)h + r * hpitch, width);
+    return 0;
+}
 static inline const char *rt_errstr(int) { return "emulator error"; }
 #define RT_LAUNCH(kernel, grid, stream, ...) (bo_emu::launch((grid), [&]() { kernel(__VA_ARGS__); }), 0)
 #else
@@ -24,6 +30,12 @@ static inline int rt_h2d(void *d, const void *h, size_t n, void *s) { return (in
 static inline int rt_d2h(void *h, const void *d, size_t n, void *s) { return (int)hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, (hipStream_t)s); }
 static inline int rt_memset(void *d, int v, size_t n, void *s) { return (int)hipMemsetAsync(d, v, n, (hipStream_t)s); }
 static inline int rt_sync(void *s) { return (int)hipStreamSynchronize((hipStream_t)s); }
+// pinned host staging: async copies to/from it are one DMA without the runtime's pageable bounce buffer
+static inline int rt_host_alloc(void **p, size_t n) { return (int)hipHostMalloc(p, n ? n : 1, hipHostMallocDefault); }
+static inline void rt_host_free(void *p) { (void)hipHostFree(p); }
+static inline int rt_h2d_2d(void *d, size_t dpitch, const void *h, size_t hpitch, size_t width, size_t height, void *s) {
+    return (int)hipMemcpy2DAsync(d, dpitch, h, hpitch, width, height, hipMemcpyHostToDevice, (hipStream_t)s);
+}
 static inline const char *rt_errstr(int e) { return hipGetErrorString((hipError_t)e); }
 #define RT_LAUNCH(kernel, grid, stream, ...)                                                                   \
     ([&]() -> int {                                                                                            \
