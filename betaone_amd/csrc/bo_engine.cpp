@@ -50,6 +50,7 @@ struct bo_engine {
     int *h_go = nullptr;                      // pinned [G]
     std::vector<int> h_nl, h_term;
     bool nl_valid = false;  // h_nl holds the current roots' legal-move counts (set by bo_selfplay_begin)
+    std::vector<unsigned char> noise_pending;  // roots begun by bo_selfplay_turn(defer_noise) whose Dirichlet draw is still due
     template <class T> int alloc(T **p, size_t n) {
         void *v = nullptr;
         int rc = rt_malloc(&v, n * sizeof(T));
@@ -346,26 +347,40 @@ extern "C" int bo_root_info(bo_engine *e, int32_t *n_legal, int32_t *terminal, i
 }
 
 // ---- search --------------------------------------------------------------------------------------------
-extern "C" int bo_search_begin(bo_engine *e, const int32_t *go, const double *noise, float *nn_in_dev, void *stream) {
+static int upload_noise(bo_engine *e, const unsigned char *rows_used, void *stream) {
+    const size_t G = (size_t)e->d.c.G;
+    size_t cols = 1;  // only the columns some root uses travel (apply_root reads noise[g][j < n_legal(g)])
+    for (size_t g = 0; g < G; g++)
+        if (rows_used[g] && (size_t)e->h_nl[g] > cols) cols = (size_t)e->h_nl[g];
+    if (e->nl_valid && cols < BO_MAX_MOVES)
+        RT(rt_h2d_2d(e->d.noise, BO_MAX_MOVES * sizeof(double), e->h_noise, BO_MAX_MOVES * sizeof(double), cols * sizeof(double), G, stream));
+    else
+        RT(rt_h2d(e->d.noise, e->h_noise, G * BO_MAX_MOVES * sizeof(double), stream));
+    return BO_OK;
+}
+
+// noise_later: the caller uploads the noise before the first bo_step that applies a root evaluation (bo_selfplay_noise)
+static int search_begin_impl(bo_engine *e, const int32_t *go, const double *noise, bool noise_later, float *nn_in_dev, void *stream) {
     if (!e || !go || !nn_in_dev) return fail(BO_E_ARG, "null argument");
     const size_t G = (size_t)e->d.c.G;
-    if (e->d.c.use_noise && !noise) return fail(BO_E_ARG, "noise required when dirichlet_alpha > 0");
+    if (e->d.c.use_noise && !noise && !noise_later) return fail(BO_E_ARG, "noise required when dirichlet_alpha > 0");
     if (go != e->h_go) memcpy(e->h_go, go, G * 4);  // pinned staging: one DMA, no pageable bounce buffer
     RT(rt_h2d(e->d_go, e->h_go, G * 4, stream));
     if (noise) {
         if (noise != e->h_noise) memcpy(e->h_noise, noise, G * BO_MAX_MOVES * sizeof(double));
-        size_t cols = 1;  // only the columns some root uses travel (the kernel reads noise[g][j < n_legal(g)])
-        for (size_t g = 0; g < G; g++)
-            if (e->h_go[g] && (size_t)e->h_nl[g] > cols) cols = (size_t)e->h_nl[g];
-        if (e->nl_valid && cols < BO_MAX_MOVES)
-            RT(rt_h2d_2d(e->d.noise, BO_MAX_MOVES * sizeof(double), e->h_noise, BO_MAX_MOVES * sizeof(double), cols * sizeof(double), G, stream));
-        else
-            RT(rt_h2d(e->d.noise, e->h_noise, G * BO_MAX_MOVES * sizeof(double), stream));
+        std::vector<unsigned char> used(G);
+        for (size_t g = 0; g < G; g++) used[g] = e->h_go[g] != 0;
+        int rc = upload_noise(e, used.data(), stream);
+        if (rc) return rc;
     }
     e->nl_valid = false;
     if (e->fast) RT(RT_LAUNCH(bo_k_fast_search_begin, e->d.c.G, stream, e->d, e->f, (const int *)e->d_go, nn_in_dev));
     else RT(RT_LAUNCH(bo_k_search_begin, e->d.c.G, stream, e->d, (const int *)e->d_go, nn_in_dev));
     return BO_OK;
+}
+
+extern "C" int bo_search_begin(bo_engine *e, const int32_t *go, const double *noise, float *nn_in_dev, void *stream) {
+    return search_begin_impl(e, go, noise, false, nn_in_dev, stream);
 }
 
 extern "C" int bo_step(bo_engine *e, const float *policy_dev, const float *value_dev, int policy_kind, float *nn_in_dev,
@@ -528,25 +543,75 @@ extern "C" int bo_selfplay_sample(bo_engine *e, const int32_t *active, const int
     return BO_OK;
 }
 
-extern "C" int bo_selfplay_begin(bo_engine *e, const int32_t *want, float *nn_in_dev, int32_t *n_legal_out, int32_t *terminal_out,
-                                 int32_t *go_out, void *stream) {
+static int selfplay_begin_impl(bo_engine *e, const int32_t *want, float *nn_in_dev, int32_t *n_legal_out, int32_t *terminal_out,
+                               int32_t *go_out, bool defer_noise, void *stream) {
     if (!e || !want || !nn_in_dev) return fail(BO_E_ARG, "null argument");
     const int G = e->d.c.G;
     int rc = bo_root_info(e, e->h_nl.data(), e->h_term.data(), nullptr, stream);
     if (rc) return rc;
     const double alpha = e->cfg.dirichlet_alpha;
+    if ((int)e->noise_pending.size() != G) e->noise_pending.assign(G, 0);
     host_pool().run(G, [&](int g) {
         const int go = want[g] && e->h_term[g] == 0;
         e->h_go[g] = go;
-        if (go && alpha > 0) hr_dirichlet(&e->rng[g], alpha, e->h_nl[g], &e->h_noise[(size_t)g * BO_MAX_MOVES]);  // mcts.py:192
+        if (go && alpha > 0) {
+            if (defer_noise) e->noise_pending[g] = 1;
+            else hr_dirichlet(&e->rng[g], alpha, e->h_nl[g], &e->h_noise[(size_t)g * BO_MAX_MOVES]);  // mcts.py:192
+        }
         if (n_legal_out) n_legal_out[g] = e->h_nl[g];
         if (terminal_out) terminal_out[g] = e->h_term[g];
         if (go_out) go_out[g] = go;
     });
     e->nl_valid = true;
-    rc = bo_search_begin(e, e->h_go, alpha > 0 ? e->h_noise : nullptr, nn_in_dev, stream);
+    rc = search_begin_impl(e, e->h_go, (alpha > 0 && !defer_noise) ? e->h_noise : nullptr, defer_noise, nn_in_dev, stream);
     if (rc) return rc;
     return bo_step(e, nullptr, nullptr, BO_POLICY_NONE, nn_in_dev, stream);
+}
+
+extern "C" int bo_selfplay_begin(bo_engine *e, const int32_t *want, float *nn_in_dev, int32_t *n_legal_out, int32_t *terminal_out,
+                                 int32_t *go_out, void *stream) {
+    return selfplay_begin_impl(e, want, nn_in_dev, n_legal_out, terminal_out, go_out, false, stream);
+}
+
+// The Dirichlet draws bo_selfplay_turn(defer_noise = 1) left out, and their upload: call it after the root evaluation's
+// network forward has been enqueued (the host work then overlaps it) and before the bo_step that consumes that evaluation.
+extern "C" int bo_selfplay_noise(bo_engine *e, void *stream) {
+    if (!e) return fail(BO_E_ARG, "null engine");
+    const int G = e->d.c.G;
+    const double alpha = e->cfg.dirichlet_alpha;
+    if ((int)e->noise_pending.size() != G || alpha <= 0) return BO_OK;
+    bool any = false;
+    for (int g = 0; g < G; g++) any = any || e->noise_pending[g];
+    if (!any) return BO_OK;
+    host_pool().run(G, [&](int g) {
+        if (e->noise_pending[g]) hr_dirichlet(&e->rng[g], alpha, e->h_nl[g], &e->h_noise[(size_t)g * BO_MAX_MOVES]);
+    });
+    e->nl_valid = true;
+    int rc = upload_noise(e, e->noise_pending.data(), stream);
+    e->nl_valid = false;
+    std::fill(e->noise_pending.begin(), e->noise_pending.end(), 0);
+    return rc;
+}
+
+// One host round trip per ply: sample the moves of the finished searches, play them, and begin the next searches
+// (self_play.py:121-184 followed by the next iteration's mcts.py:185-203).  Per game the RNG stream order is unchanged:
+// the temperature sample, then the Dirichlet draw of the new root.
+extern "C" int bo_selfplay_turn(bo_engine *e, const int32_t *active, const int32_t *move_number, int32_t threshold, double t_initial,
+                                double t_final, int32_t *res_n, int32_t *res_idx, float *res_val, int32_t *best_idx, int32_t *action_out,
+                                const int32_t *want_next, float *nn_in_dev, int32_t *n_legal_out, int32_t *terminal_out, int32_t *go_out,
+                                int32_t defer_noise, int32_t *completed, void *stream) {
+    if (!e || !want_next || !nn_in_dev || !completed) return fail(BO_E_ARG, "null argument");
+    *completed = 0;
+    int rc = bo_selfplay_sample(e, active, move_number, threshold, t_initial, t_final, res_n, res_idx, res_val, best_idx, action_out, stream);
+    if (rc) return rc;
+    for (int g = 0; g < e->d.c.G; g++)
+        if (action_out[g] == -3) return BO_OK;  // a pi too dense for the native sampler: the caller samples it, then plays and begins
+    rc = bo_play(e, action_out, stream);
+    if (rc) return rc;
+    rc = selfplay_begin_impl(e, want_next, nn_in_dev, n_legal_out, terminal_out, go_out, defer_noise != 0, stream);
+    if (rc) return rc;
+    *completed = 1;
+    return BO_OK;
 }
 
 // ---- records ------------------------------------------------------------------------------------------------

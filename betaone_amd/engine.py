@@ -74,6 +74,9 @@ _SYMBOLS = {
     "bo_rng_state": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint32), _I32P, _I32P, _F64P]),
     "bo_selfplay_sample": (C.c_int, [C.c_void_p, _I32P, _I32P, C.c_int32, C.c_double, C.c_double, _I32P, _I32P, _F32P,
                                      _I32P, _I32P, C.c_void_p]),
+    "bo_selfplay_turn": (C.c_int, [C.c_void_p, _I32P, _I32P, C.c_int32, C.c_double, C.c_double, _I32P, _I32P, _F32P, _I32P, _I32P, _I32P,
+                                   C.c_void_p, _I32P, _I32P, _I32P, C.c_int32, _I32P, C.c_void_p]),
+    "bo_selfplay_noise": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bo_selfplay_begin": (C.c_int, [C.c_void_p, _I32P, C.c_void_p, _I32P, _I32P, _I32P, C.c_void_p]),
     "bo_records_encode": (C.c_int, [C.c_int, C.POINTER(BoPosition), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bo_debug_tree": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BoNode), C.c_int32, _I32P, C.c_void_p]),
@@ -268,6 +271,21 @@ class Engine:
                                                 _p(out["idx"]), _p(out["val"], _F32P), _p(out["best_idx"]),
                                                 _p(out["action"]), stream))
         return out
+
+    def selfplay_noise(self, stream: int = 0):
+        self._check(self.lib.bo_selfplay_noise(self.h, stream))
+
+    def selfplay_turn(self, active, move_number, temperature, out, want_next, nn_in_ptr: int, stream: int = 0, defer_noise: bool = False):
+        """selfplay_sample + play + selfplay_begin(want_next) in one call.  Returns (out, (n_legal, terminal, go) or None):
+        None when a game needs the dense NumPy sampler (action -3) -- nothing was played then."""
+        a, m, w = _i32(active), _i32(move_number), _i32(want_next)
+        th, ti, tf = temperature
+        nl, tm, go = (np.zeros(self.G, dtype=np.int32) for _ in range(3))
+        done = C.c_int32(0)
+        self._check(self.lib.bo_selfplay_turn(self.h, _p(a), _p(m), int(th), float(ti), float(tf), _p(out["n"]), _p(out["idx"]),
+                                              _p(out["val"], _F32P), _p(out["best_idx"]), _p(out["action"]), _p(w), nn_in_ptr, _p(nl), _p(tm),
+                                              _p(go), 1 if defer_noise else 0, C.byref(done), stream))
+        return out, ((nl, tm, go) if done.value else None)
 
     def selfplay_begin(self, want, nn_in_ptr: int, stream: int = 0):
         w = _i32(want)

@@ -109,6 +109,10 @@ class Rollout:
         assert policy_kind in ("logits", "probs")
         self.policy_kind = E.POLICY_LOGITS if policy_kind == "logits" else E.POLICY_PROBS
         G = self.G
+        self._fgraph = None
+        self._noise_pending = False
+        self._begun = None          # (n_legal, terminal, go) of searches already begun by the previous selfplay_turn
+        self._begun_want = None
         self._active = np.zeros(G, dtype=bool)
         self._plies = np.zeros(G, dtype=np.int64)
         self._start_full = np.ones(G, dtype=np.int64)
@@ -177,6 +181,8 @@ class Rollout:
             if moves is not None and moves[i]:
                 self.games[s].plies = len(moves[i].split())
             self._active[s] = True
+            if self._begun_want is not None:
+                self._begun_want[s] = False  # a search begun for the slot's previous occupant does not count
             self._plies[s] = self.games[s].plies
             self._start_full[s], self._start_black[s] = full, 0 if white else 1
             self._start_step[s] = self._step
@@ -254,8 +260,29 @@ class Rollout:
         self.n_plies += n_moves
         return n_moves
 
+    def _forward_only(self):
+        """The network forward alone (root evaluations of searches whose Dirichlet noise is still being drawn)."""
+        if not self.use_graph:
+            self._f_logits, self._f_value = self._forward()
+            return
+        if self._fgraph is None:
+            if self._graph is None:
+                self._capture()  # warms the allocator / MIOpen up as well
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                logits, value = self._forward()
+            self._fgraph, self._f_logits, self._f_value = g, logits, value
+        self._fgraph.replay()
+
     def _run_search_steps(self):
         burst = self.expected_evals
+        if self._noise_pending:  # root evaluation: forward | host draws the noise meanwhile | upload | apply
+            self._noise_pending = False
+            self.n_forward += 1
+            self._forward_only()
+            self.eng.selfplay_noise(self._stream())
+            self.eng.step(self._f_logits.data_ptr(), self._f_value.data_ptr(), self.policy_kind, self.nn_in.data_ptr(), self._stream())
+            burst -= 1
         while True:
             for _ in range(burst):
                 self._eval_and_step()
@@ -272,7 +299,15 @@ class Rollout:
         want = self._active & (self._plies < self.max_game_moves)
         limit_done = np.nonzero(self._active & ~want)[0]
         self.host_seconds += time.perf_counter() - t0
-        nl, term, go = eng.selfplay_begin(want.astype(np.int32), self.nn_in.data_ptr(), stream)
+        if self._begun is not None:  # the previous turn already began these searches (bo_selfplay_turn)
+            nl, term, go = self._begun
+            extra = want & ~self._begun_want
+            self._begun = None
+            if extra.any():  # games started in between
+                nl2, t2, go2 = eng.selfplay_begin(extra.astype(np.int32), self.nn_in.data_ptr(), stream)
+                nl, term, go = np.where(extra, nl2, nl), np.where(extra, t2, term), go | go2
+        else:
+            nl, term, go = eng.selfplay_begin(want.astype(np.int32), self.nn_in.data_ptr(), stream)
         done = [int(g) for g in limit_done] + [int(g) for g in np.nonzero(want & (term != 0))[0]]
         if done:
             new_slots, ids, seeds, fens = [], [], [], []
@@ -297,17 +332,24 @@ class Rollout:
         self.n_sims += int(np.count_nonzero(go)) * self.S
         t0 = time.perf_counter()
         move_number = self._start_full + (self._plies + self._start_black) // 2   # board.fullmove_number, self_play.py:104
+        want_next = self._active & ((self._plies + go) < self.max_game_moves)     # the next call's `want`
         self.host_seconds += time.perf_counter() - t0
-        out = eng.selfplay_sample(go, move_number, self.temperature, self._out, stream)
+        # one native call: sample the moves, play them, begin the next searches (root info, Dirichlet noise, root planes)
+        out, begun = eng.selfplay_turn(go, move_number, self.temperature, self._out, want_next.astype(np.int32), self.nn_in.data_ptr(), stream,
+                                       defer_noise=True)
         t0 = time.perf_counter()
         actions = out["action"]
-        for g in np.nonzero(actions == -3)[0]:  # rare: pi not sparse enough for the native sampler
-            rs = np.random.RandomState(0)
-            rs.set_state(eng.rng_get_state(int(g)))
-            n = int(out["n"][g])
-            th, ti, tf = self.temperature
-            actions[g] = sampling.select_action_sparse(out["idx"][g, :n], out["val"][g, :n], int(move_number[g]), rs, th, ti, tf)
-            eng.rng_set_state(int(g), rs.get_state())
+        if begun is None:  # rare: a pi not sparse enough for the native sampler -- nothing was played
+            for g in np.nonzero(actions == -3)[0]:
+                rs = np.random.RandomState(0)
+                rs.set_state(eng.rng_get_state(int(g)))
+                n = int(out["n"][g])
+                th, ti, tf = self.temperature
+                actions[g] = sampling.select_action_sparse(out["idx"][g, :n], out["val"][g, :n], int(move_number[g]), rs, th, ti, tf)
+                eng.rng_set_state(int(g), rs.get_state())
+            eng.play(actions, stream)
+        else:
+            self._begun, self._begun_want, self._noise_pending = begun, want_next.copy(), True
         k = max(1, int(out["n"].max()))
         self._hist[self._step] = (out["n"].copy(), out["idx"][:, :k].copy(), out["val"][:, :k].copy())
         self._step += 1
@@ -318,7 +360,6 @@ class Rollout:
         for st in [st for st in self._hist if st < lo]:
             del self._hist[st]
         self.host_seconds += time.perf_counter() - t0
-        eng.play(actions, stream)
         n_moves = int(np.count_nonzero(go))
         self.n_plies += n_moves
         return n_moves

@@ -154,6 +154,18 @@ int bo_selfplay_sample(bo_engine *e, const int32_t *active, const int32_t *move_
 int bo_selfplay_begin(bo_engine *e, const int32_t *want, float *nn_in_dev, int32_t *n_legal_out, int32_t *terminal_out,
                       int32_t *go_out, void *stream);
 
+/* bo_selfplay_sample + bo_play + bo_selfplay_begin(want_next) in one call (one host round trip per ply).  *completed = 0
+ * if some game's pi was too dense for the native sampler (action -3): nothing was played, the caller samples that game
+ * with the dense NumPy mirror, then calls bo_play and bo_selfplay_begin itself. */
+int bo_selfplay_turn(bo_engine *e, const int32_t *active, const int32_t *move_number, int32_t threshold, double t_initial,
+                     double t_final, int32_t *res_n, int32_t *res_idx, float *res_val, int32_t *best_idx, int32_t *action_out,
+                     const int32_t *want_next, float *nn_in_dev, int32_t *n_legal_out, int32_t *terminal_out, int32_t *go_out,
+                     int32_t defer_noise, int32_t *completed, void *stream);
+/* defer_noise = 1: the Dirichlet draws of the new roots (mcts.py:190-201) and their upload are left to bo_selfplay_noise,
+ * to be called after the root evaluations' network forward has been enqueued on `stream` (the host work overlaps it) and
+ * before the bo_step that consumes those evaluations.  Per game the RNG stream order is the same either way. */
+int bo_selfplay_noise(bo_engine *e, void *stream);
+
 /* ---- records ------------------------------------------------------------------------------------
  * The game in `slot` as plain data: its positions[0..n_plies] and moves[0..n_plies). */
 int bo_game_export(bo_engine *e, int slot, bo_position *positions, int32_t *moves, int32_t cap, int32_t *n_plies,
