@@ -392,8 +392,18 @@ class FusedPolicyValueNet(nn.Module):
             return self.policy_fc_h(p), torch.tanh(self.value_fc2_h(F.relu(self.value_fc1_h(v))))
         if self.conv == "tower_wg":  # tower + head convolutions in one kernel, then 2 GEMMs and the value tail
             p, v = self._tower_forward(x, heads=True)
-            h = torch._addmm_activation(self.value_fc1.bias, v, self.value_fc1.weight.t())  # relu(fc1)
-            return self.policy_fc(p), self._value_tail(h)
+            # the value head (2 small kernels) runs beside the policy GEMM: a fork/join of streams, also inside a captured graph
+            cur = torch.cuda.current_stream(x.device)
+            side = self.__dict__.get("_side")
+            if side is None or side.device != x.device:
+                side = self.__dict__["_side"] = torch.cuda.Stream(x.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                h = torch._addmm_activation(self.value_fc1.bias, v, self.value_fc1.weight.t())  # relu(fc1)
+                value = self._value_tail(h)
+            logits = self.policy_fc(p)
+            cur.wait_stream(side)
+            return logits, value
         if self.conv in ("mfma", "tower", "mfma_small"):
             x = self._tower_mfma(x) if self.conv == "mfma" else self._tower_small(x) if self.conv == "mfma_small" else self._tower_forward(x)
             h = self._epi(F.conv2d(x, self.w_head, None), self.b_head)

@@ -353,9 +353,7 @@ class Rollout:
         k = max(1, int(out["n"].max()))
         self._hist[self._step] = (out["n"].copy(), out["idx"][:, :k].copy(), out["val"][:, :k].copy())
         self._step += 1
-        self._plies += go
-        for g in np.nonzero(go)[0]:
-            self.games[g].plies += 1
+        self._plies += go  # GameState.plies of the native mode is brought up to date when the game is finished
         lo = int(self._start_step[self._active].min()) if self._active.any() else self._step
         for st in [st for st in self._hist if st < lo]:
             del self._hist[st]
@@ -366,6 +364,8 @@ class Rollout:
 
     def _finish(self, g: int, terminal: int) -> FinishedGame:
         gs = self.games[g]
+        if self.rng_mode == "native":
+            gs.plies = int(self._plies[g])
         positions, moves = self.eng.export_game(g, self._stream())
         outcome = 1.0 if terminal == 1 else 0.0
         pis = gs.pis
