@@ -222,7 +222,7 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
     rc |= e->alloc(&d.req_moves, G * BO_MAX_MOVES); rc |= e->alloc(&d.root_moves, G * BO_MAX_MOVES);
     rc |= e->alloc(&d.root_child_rank, G * 2 * BO_CH_CAP); rc |= e->alloc(&d.noise, G * BO_MAX_MOVES);
     rc |= e->alloc(&d.played, G * c.PLY_CAP);
-    rc |= e->alloc(&d.prof, G * 8);
+    rc |= e->alloc(&d.prof, G * 10);
     if (fast) {
         FastEng &f = e->f;
         const size_t L = (size_t)cfg->leaves_per_step;
@@ -702,12 +702,12 @@ extern "C" int bo_debug_profile(bo_engine *e, int enable, uint64_t *cycles_out, 
     if (!e) return fail(BO_E_ARG, "null engine");
     const size_t G = (size_t)e->d.c.G;
     if (cycles_out) {
-        RT(rt_d2h(cycles_out, e->d.prof, G * 8 * sizeof(uint64_t), stream));
+        RT(rt_d2h(cycles_out, e->d.prof, G * 10 * sizeof(uint64_t), stream));
         RT(rt_sync(stream));
     }
     if (enable >= 0) {
-        if (enable && !e->d.c.profile) RT(rt_memset(e->d.prof, 0, G * 8 * sizeof(uint64_t), stream));
-        e->d.c.profile = enable ? 1 : 0;
+        if (enable && !e->d.c.profile) RT(rt_memset(e->d.prof, 0, G * 10 * sizeof(uint64_t), stream));
+        e->d.c.profile = enable;  // 1: every game-step; N > 1: only game-steps longer than N cycles
     }
     return BO_OK;
 }

@@ -80,7 +80,8 @@ struct Eng {
     // search results
     int *res_n, *res_idx, *res_best_idx, *res_best_mv, *res_total;
     float *res_val;
-    unsigned long long *prof;         // [G][8] cycles: apply, select, first-visit (movegen+draw rules), terminal backups, encode, flush, total, steps
+    unsigned long long *prof;         // [G][10] cycles: apply, select, first-visit (movegen+draw rules), terminal backups, encode, flush, total; steps,
+                                      // loop iterations, first visits.  profile = N > 1 counts only game-steps longer than N cycles
 };
 
 #define NOFF(e, g) ((size_t)(g) * (size_t)(e).c.NCAP)
@@ -284,44 +285,66 @@ BO_DEV void encode_leaf(const Eng &e, int g, float *row, const DPos &P) {
 }
 
 // MCTSNode.select_child repeated down to a leaf (mcts.py:218-230, 72-118)
-BO_DEV int select_leaf(const Eng &e, int g, int *flags, int *path, int *depth_out) {
+// One PUCT descent (MCTSNode.select_child down to a leaf, mcts.py:72-118).  Per level ONE dependent memory round trip:
+// the children's (visits, prior, q) and, with them, each child's own (first_child, n_children), so the chosen child's
+// block is known without touching it; the parent-side visit count of the reference (mcts.py:89: the visits of the
+// node ABOVE the one being expanded, the root's own at the top) is carried down in registers; sqrt comes from the
+// table in the same round trip; the argmax over <= 16 children is four DPP exchanges (more children: two ds steps on top).
+BO_DEV int select_leaf(const Eng &e, int g, int *flags, int *path, int *depth_out, const float *lut) {
     const size_t no = NOFF(e, g);
     const int lane = bo_lane();
     int cur = 0, levels = 0, scanned = 0;
     if (lane == 0) path[0] = 0;
+    int nc = e.n_children[no], fc = e.first_child[no];
+    int pv = e.n_visits[no], pv_next = pv;  // level 0 and level 1 both see the root's visits
     for (;;) {
-        const int nc = e.n_children[no + cur];
         if (nc == 0) break;
-        const int fc = e.first_child[no + cur];
-        const int pv = cur == 0 ? e.n_visits[no] : e.n_visits[no + e.parent[no + cur]];  // mcts.py:89
-        const float sp = e.sqrt_lut[pv];
+        const float sp = lut[pv];
         float score = -__builtin_inff();
+        int n = 0, c_fc = 0, c_nc = 0;
         if (lane < nc) {
-            const int n = e.n_visits[no + fc + lane];
+            n = e.n_visits[no + fc + lane];
+            c_fc = e.first_child[no + fc + lane];
+            c_nc = e.n_children[no + fc + lane];
             const float p = e.prior[no + fc + lane];
             const float t1 = e.c.cpuct * p;
             const float t2 = t1 * sp;
+            const float q_child = e.q[no + fc + lane];  // requested with the rest (a load behind `n > 0` is a second round trip)
             float qv = 0.0f, u = t2;
             if (n > 0) {
-                qv = e.q[no + fc + lane];
+                qv = q_child;
                 u = t2 / (float)(1 + n);
             }
             score = qv + u;
             if (!(score == score)) score = -__builtin_inff();  // NaN never wins `score > best`
         }
         int bi = lane;
-        for (int m = 1; m < nc; m <<= 1) {  // lanes >= nc hold -inf: log2(next pow2 of nc) butterfly steps reach lane 0
-            float os = bo_shfl_xor_f(score, m);
-            int oi = bo_shfl_xor(bi, m);
-            if (os > score || (os == score && oi < bi)) { score = os; bi = oi; }
+#define BO_SEL_STEP(os_expr, oi_expr)                                                   \
+        {                                                                               \
+            const float os = (os_expr);                                                 \
+            const int oi = (oi_expr);                                                   \
+            if (os > score || (os == score && oi < bi)) { score = os; bi = oi; }        \
         }
-        score = bo_shfl_f(score, 0);
-        bi = bo_shfl(bi, 0);
+        BO_SEL_STEP(__builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, score), 0)), BO_ROW_XCHG(bi, 0))
+        BO_SEL_STEP(__builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, score), 1)), BO_ROW_XCHG(bi, 1))
+        BO_SEL_STEP(__builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, score), 2)), BO_ROW_XCHG(bi, 2))
+        BO_SEL_STEP(__builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, score), 3)), BO_ROW_XCHG(bi, 3))
+        if (nc > 16) {  // rows -> wave (lanes >= nc hold -inf)
+            BO_SEL_STEP(bo_shfl_xor_f(score, 16), bo_shfl_xor(bi, 16))
+            BO_SEL_STEP(bo_shfl_xor_f(score, 32), bo_shfl_xor(bi, 32))
+        }
+#undef BO_SEL_STEP
+        score = __builtin_bit_cast(float, bo_readlane(__builtin_bit_cast(int, score), 0));
+        bi = bo_readlane(bi, 0);
         if (!(score > -__builtin_inff())) { *flags |= ST_NAN_SCORE; bi = 0; }  // reference: random.choice
-        cur = bo_uniform(fc + bi);
+        cur = fc + bi;
         levels++;
         if (lane == 0) path[levels] = cur;
         scanned += nc;
+        pv = pv_next;
+        pv_next = bo_readlane(n, bi);
+        fc = bo_readlane(c_fc, bi);
+        nc = bo_readlane(c_nc, bi);
         if (levels >= BO_PATH_CAP - 1) { *flags |= ST_DEPTH_OVERFLOW; break; }
     }
     if (lane == 0) { e.stat_levels[g] += levels; e.stat_children_scanned[g] += scanned; }
@@ -365,7 +388,17 @@ BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, 
     const int cterm = (have && last && e.n_children[no + my_fc + j] == 0) ? (int)e.term[no + my_fc + j] : -1;
     float v_cur = v;
     int done = 0;
+    // sqrt(parent visits) of this lane's level for the NEXT re-evaluation: every level's count grows by one per simulation,
+    // so the table entry is requested one iteration ahead (it was a dependent global load inside every iteration)
+    int pv_next = nv[0] + 1;
+#pragma unroll
+    for (int k = 1; k < BO_BURST_LEVELS; k++)
+        if (grp == k) pv_next = nv[k - 1] + 1;
+    float sp_next = e.sqrt_lut[pv_next <= e.c.S + 1 ? pv_next : e.c.S + 1];
     for (;;) {
+        const float sp = sp_next;
+        pv_next++;
+        sp_next = e.sqrt_lut[pv_next <= e.c.S + 1 ? pv_next : e.c.S + 1];
         // ---- apply one terminal simulation (MCTSNode.update along the path, mcts.py:120-144) ----
         if (have && j == my_chosen) {
             const float val = ((d - (grp + 1)) & 1) ? -v_cur : v_cur;  // the leaf sees v, its parent -v, ...
@@ -385,11 +418,6 @@ BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, 
         done++;
         if (done >= sims_left) break;
         // ---- re-evaluate the descent from the registers (select_child at every level of the path) ----
-        int pv = nv[0];
-#pragma unroll
-        for (int k = 1; k < BO_BURST_LEVELS; k++)
-            if (grp == k) pv = nv[k - 1];
-        const float sp = e.sqrt_lut[pv];
         float score = -__builtin_inff();
         if (have) {
             const float t1 = e.c.cpuct * cp;
@@ -399,20 +427,27 @@ BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, 
             score = qv + u;
             if (!(score == score)) score = -__builtin_inff();
         }
-        int bi = j;
-        for (int m = 1; m < 16; m <<= 1) {
-            const float os = bo_shfl_xor_f(score, m);
-            const int oi = bo_shfl_xor(bi, m);
-            if (os > score || (os == score && oi < bi)) { score = os; bi = oi; }
+        int bi = j;  // argmax (first index on ties) over the 16 lanes of the level: four DPP exchanges
+#define BO_BURST_STEP(kind)                                                                          \
+        {                                                                                            \
+            const float os = __builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, score), kind)); \
+            const int oi = BO_ROW_XCHG(bi, kind);                                                    \
+            if (os > score || (os == score && oi < bi)) { score = os; bi = oi; }                     \
         }
+        BO_BURST_STEP(0) BO_BURST_STEP(1) BO_BURST_STEP(2) BO_BURST_STEP(3)
+#undef BO_BURST_STEP
         // upper levels must reproduce the path; the last level may move to another known terminal leaf
         const bool upper_ok = !(grp < d) || last || (bi == my_chosen && score > -__builtin_inff());
-        const int bterm = bo_shfl(cterm, (lane & 48) | (bi & 15));  // term of the child this group selected
+        int bterm = (j == (bi & 15)) ? cterm : -2;  // term of the child this group selected: row maximum of the one candidate
+        { int o = BO_ROW_XCHG(bterm, 0); bterm = o > bterm ? o : bterm; }
+        { int o = BO_ROW_XCHG(bterm, 1); bterm = o > bterm ? o : bterm; }
+        { int o = BO_ROW_XCHG(bterm, 2); bterm = o > bterm ? o : bterm; }
+        { int o = BO_ROW_XCHG(bterm, 3); bterm = o > bterm ? o : bterm; }
         const bool last_ok = !(have || (grp < d && j == 0)) || !last || (bterm > 0 && score > -__builtin_inff());
         if (bo_ballot(!(upper_ok && last_ok)) != 0) break;  // the next descent needs the general loop
         if (d > 0) {
             const int src = 16 * (d - 1);  // lane 0 of the last level's group holds its argmax
-            const int nb = bo_shfl(bi, src), nt = bo_shfl(bterm, src);
+            const int nb = bo_readlane(bi, src), nt = bo_readlane(bterm, src);
             if (last) my_chosen = nb;
             v_cur = nt == 1 ? 1.0f : 0.0f;
         }
@@ -668,12 +703,14 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
 
     const bool prof = e.c.profile != 0;
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int n_iter = 0, n_first = 0;
     unsigned long long tk = prof ? bo_clock() : 0ull;
     const unsigned long long t_start = tk;
 #define BO_PROF(slot)                                                    \
     if (prof) { const unsigned long long _n = bo_clock(); pc[slot] += _n - tk; tk = _n; }
+    if (req >= 0 && kind == POLICY_NONE) return;  // evaluation still outstanding
+    const float *lut = e.sqrt_lut;  // (an LDS copy costs a round trip per launch; the table entry is requested with the children)
     if (req >= 0) {
-        if (kind == POLICY_NONE) return;  // evaluation still outstanding
         if (req == 0) apply_root(e, g, policy + (size_t)g * BO_NUM_ACTIONS, kind, sh, &n_nodes, &flags);
         else apply_leaf(e, g, req, policy + (size_t)g * BO_NUM_ACTIONS, kind, value[g], sh, &n_ul, &flags);
         req = -1;
@@ -688,10 +725,12 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
             break;
         }
         int depth;
-        const int leaf = select_leaf(e, g, &flags, sh.path, &depth);
+        const int leaf = select_leaf(e, g, &flags, sh.path, &depth, lut);
+        n_iter++;
         BO_PROF(1)
         int t = e.term[no + leaf];
         if (t < 0) {  // first visit: legal moves + is_terminal()  (mcts.py:235, cached per node)
+            n_first++;
             const DPos P = e.npos[no + leaf];
             bool chk;
             const int n = bo_movegen(P, sh.moves, &chk);
@@ -737,10 +776,15 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
     }
 #undef BO_PROF
     if (prof && lane == 0) {
-        unsigned long long *pp = e.prof + (size_t)g * 8;
-        for (int i = 0; i < 6; i++) pp[i] += pc[i];
-        pp[6] += bo_clock() - t_start;
-        pp[7] += 1;
+        const unsigned long long total = bo_clock() - t_start;
+        if (e.c.profile == 1 || total > (unsigned long long)e.c.profile) {
+            unsigned long long *pp = e.prof + (size_t)g * 10;
+            for (int i = 0; i < 6; i++) pp[i] += pc[i];
+            pp[6] += total;
+            pp[7] += 1;
+            pp[8] += (unsigned long long)n_iter;
+            pp[9] += (unsigned long long)n_first;
+        }
     }
     if (lane == 0) {
         e.sims_done[g] = sims; e.rows[g] = rows; e.n_runs[g] = n_runs; e.n_ul[g] = n_ul; e.n_nodes[g] = n_nodes;

@@ -32,6 +32,24 @@ BO_DEV int bo_atomic_add(int *p, int v) { return atomicAdd(p, v); }
 BO_DEV int bo_atomic_or(int *p, int v) { return atomicOr(p, v); }
 BO_DEV uint64_t bo_bitrev64(uint64_t x) { return __builtin_bitreverse64(x); }
 BO_DEV unsigned long long bo_clock() { return (unsigned long long)clock64(); }
+// exchange within a 16-lane row on the VALU (DPP) instead of through the LDS crossbar (ds_bpermute):
+// kind 0: lane^1, 1: lane^2, 2: mirror within 8 lanes, 3: mirror within 16 lanes -- four steps combine a row
+#define BO_ROW_XCHG(v, kind) \
+    __builtin_amdgcn_update_dpp(0, (v), (kind) == 0 ? 0xB1 : (kind) == 1 ? 0x4E : (kind) == 2 ? 0x141 : 0x140, 0xF, 0xF, false)
+#endif
+#if !defined(BO_WAVE_EMU)
+// value of lane `src` where src is wave-uniform: v_readlane_b32 (an SGPR result), not a ds_bpermute round trip
+BO_DEV int bo_readlane(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
+#else
+static inline int bo_readlane(int v, int src) { return bo_shfl(v, src); }
+#endif
+#if defined(BO_WAVE_EMU)
+static inline int bo_row_xchg_emu(int v, int kind) {
+    const int l = bo_lane();
+    const int src = kind == 0 ? (l ^ 1) : kind == 1 ? (l ^ 2) : kind == 2 ? ((l & ~7) | (7 - (l & 7))) : ((l & ~15) | (15 - (l & 15)));
+    return bo_shfl(v, src);
+}
+#define BO_ROW_XCHG(v, kind) bo_row_xchg_emu((v), (kind))
 #endif
 
 // ---- derived primitives (identical in both builds) ---------------------------------------------

@@ -191,9 +191,11 @@ int bo_debug_tree(bo_engine *e, int slot, bo_node *out, int32_t cap, int32_t *n_
 int bo_engine_status(bo_engine *e, int32_t *status, int32_t *evals, int32_t *flushes, int32_t *term_sims,
                      int32_t *levels, int32_t *children_scanned, void *stream);
 
-/* Per-phase shader cycles of bo_step (s_memtime), accumulated per game while enabled: cycles_out [G][8] =
- * apply, select, first visit (move generation + draw rules), terminal backups, leaf encode, flush, total, steps.
- * enable: 1/0 switch (a 0->1 switch clears the counters), -1 = only read.  A captured hipGraph keeps the setting it
+/* Per-phase shader cycles of bo_step (s_memtime), accumulated per game while enabled: cycles_out [G][10] =
+ * apply, select, first visit (move generation + draw rules), terminal backups, leaf encode, flush, total, steps,
+ * simulation-loop iterations, first visits.
+ * enable: 1 = every game-step, N > 1 = only game-steps longer than N cycles, 0 = off (a 0->on switch clears the
+ * counters), -1 = only read.  A captured hipGraph keeps the setting it
  * was captured with.  Synchronises when cycles_out != NULL. */
 int bo_debug_profile(bo_engine *e, int enable, uint64_t *cycles_out, void *stream);
 

@@ -9,6 +9,7 @@ from betaone_amd.rollout import Rollout
 
 warm = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+thr = int(sys.argv[3]) if len(sys.argv) > 3 else 1   # > 1: only game-steps longer than that many cycles
 _, net = bench.make_net("10x128", torch.device("cuda:0"), "fp32", 256)
 ro = Rollout(net, 256, num_simulations=800, mcts_batch_size=96, device="cuda:0", use_graph=False, rng_mode="native")
 ro.start_games(list(range(256)), list(range(256)), list(range(256)))
@@ -18,11 +19,19 @@ def refill(_s):
     return nid[0], nid[0], None
 for _ in range(warm):
     ro.play_ply(refill=refill)
-ro.eng.profile(enable=1, read=False)
+ro.eng.profile(enable=thr, read=False)
 for _ in range(steps):
     ro.play_ply(refill=refill)
 p = ro.eng.profile(enable=0).astype(np.float64)
 names = ["apply", "select", "first-visit", "terminal-backup", "encode", "flush", "total", "steps"]
+if thr > 1:
+    n = p[:, 7].sum()
+    print(f"game-steps longer than {thr} cycles: {int(n)} of {256 * steps * 11} (~{n / (steps * 11):.2f} per launch)")
+    tot = p.sum(axis=0)
+    for i, nm in enumerate(names[:7]):
+        print(f"  {nm:16s} {tot[i] / max(n, 1):10.0f} cycles per slow step")
+    print(f"  loop iterations per slow step {tot[8] / max(n, 1):.1f}, first visits {tot[9] / max(n, 1):.1f}")
+    sys.exit(0)
 per_step = p[:, :7] / np.maximum(p[:, 7:8], 1)
 print("cycles per step per game (100 MHz s_memtime ticks? shader clock): mean over games / max over games")
 for i, n in enumerate(names[:7]):
