@@ -120,3 +120,43 @@ def test_native_rollout_equals_python_rollout_and_oracle():
         ref = O.self_play(uniform_eval, np.random.RandomState(seeds[gid]),
                           O.default_config(num_simulations=40, batch_size=16, max_game_moves=7), start_fen=fens[gid] or "")
         assert [E.move_to_uci(m) for m in a[gid].moves] == [O.move_to_uci(m) for m in ref["moves"]]
+
+
+def test_native_rollout_with_slot_recycling_equals_python_rollout():
+    """Finished games hand their slot to the next game id (refill) while the other slots' searches were already begun by
+    the previous bo_selfplay_turn: the games played must not depend on rng_mode."""
+    import torch
+    from betaone_amd.rollout import Rollout
+    from fake_model import FakeNet
+
+    class Net(torch.nn.Module):
+        def forward(self, x):
+            return FakeNet(scale=0.5, salt=7)(x)
+
+    start = ["k7/8/1K6/8/8/8/8/7R w - - 96 60", None, "6k1/5ppp/8/8/8/8/5PPP/3R2K1 w - - 0 30"]
+
+    def play(mode):
+        ro = Rollout(Net(), 3, num_simulations=24, mcts_batch_size=8, max_game_moves=5, device="cpu", use_graph=False,
+                     rng_mode=mode, lib=emu_lib())
+        mk = (lambda s: s) if mode == "native" else (lambda s: np.random.RandomState(s))
+        ro.start_games([0, 1, 2], [0, 1, 2], [mk(10), mk(11), mk(12)], start)
+        nxt, fins = [3], {}
+
+        def refill(_slot):
+            if nxt[0] >= 8:
+                return None
+            gid = nxt[0]
+            nxt[0] += 1
+            return gid, mk(10 + gid), start[gid % 3]
+
+        while any(g is not None for g in ro.games):
+            ro.play_ply(on_finished=lambda f: fins.__setitem__(f.game_id, f), refill=refill)
+        ro.close()
+        return fins
+
+    a, b = play("native"), play("python")
+    assert sorted(a) == sorted(b) == list(range(8))
+    for gid in a:
+        assert a[gid].moves == b[gid].moves and a[gid].terminal == b[gid].terminal, gid
+        for (i1, v1), (i2, v2) in zip(a[gid].pis, b[gid].pis):
+            assert i1.tolist() == i2.tolist() and v1.tolist() == v2.tolist()
