@@ -197,7 +197,15 @@ def cpu_baseline(args):
         g = O.self_play(eval_fn, np.random.RandomState(games), cfg, max_plies=6)
         sims += g["n_sims"]; plies += len(g["moves"]); evals += g["n_evals"]; games += 1
     dt = time.perf_counter() - t0
-    return {"value": round(sims / dt, 1), "unit": "nodes/s", "cores": threads, "kind": "port",
+    cpu_model = "unknown CPU"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(sims / dt, 1), "unit": "nodes/s", "cores": threads, "kind": "port", "cpu": cpu_model,
             "sample": f"{games} game prefixes x 6 plies ({plies} searches of {args.sims} sims, {evals} unique NN evals) "
                       f"in {dt:.1f} s; oracle/ C port single-threaded, net {args.net} fp32 under torch-CPU with {threads} threads; "
                       f"the port evaluates each unique leaf once (the Python reference evaluates up to 96 duplicate rows per batch)"}
