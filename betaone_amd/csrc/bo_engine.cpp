@@ -937,8 +937,8 @@ extern "C" int bo_nn_tower_forward(bo_tower *t, const float *x_dev, float *y_dev
         const int pairs = (batch + 1) / 2;
         const unsigned g2 = (unsigned)(pairs < t->n_cu ? pairs : t->n_cu);
         const bo_h8 *w8 = reinterpret_cast<const bo_h8 *>(t->wts);
-        if (t->channels == 256) hipLaunchKernelGGL((bo_k_tower_h<256>), dim3(g2), dim3(512), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, batch, hh);
-        else hipLaunchKernelGGL((bo_k_tower_h<128>), dim3(g2), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, batch, hh);
+        if (t->channels == 256) hipLaunchKernelGGL((bo_k_tower_h<256, 2>), dim3(g2), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, batch, hh);
+        else hipLaunchKernelGGL((bo_k_tower_h<128, 1>), dim3(g2), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, batch, hh);
         RT((int)hipGetLastError());
         return BO_OK;
     }

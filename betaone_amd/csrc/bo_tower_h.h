@@ -28,11 +28,13 @@ struct bo_tower_head_h {
 
 // LAB (scripts/conv_lab.hip only): 0 = the kernel; 1 = no weight loads; 2 = no B operand reads; 4 = no epilogue;
 // 5 = 1 + 2 + 4; 6 = 5 without barriers
-template <int C, int LAB = 0>
-__global__ void __launch_bounds__(C * 2)
+// MT = 32-channel output tiles per wave: C/(32*MT) waves per workgroup.  MT = 2 (256 filters: 4 waves, one per SIMD, 64
+// channels x 128 positions = 128 accumulator registers) reads every B operand for two MFMAs and halves the LDS traffic.
+template <int C, int MT, int LAB = 0>
+__global__ void __launch_bounds__(C * 2 / MT)
 bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const float *__restrict__ params,
              const bo_tower_layer *__restrict__ layers, int n_layers, int B, bo_tower_head_h head) {
-    constexpr int NT = C * 2, NW = C / 32, PH = C + 8, CELLS = 100, IMGH = CELLS * PH, CIN0 = 120;
+    constexpr int NW = C / (32 * MT), NT = NW * 64, PH = C + 8, CELLS = 100, IMGH = CELLS * PH, CIN0 = 120, HPW = (16 + NW - 1) / NW;
     __shared__ __attribute__((aligned(16))) _Float16 X[2 * IMGH];
     __shared__ __attribute__((aligned(16))) float pooled[2][C];
     __shared__ float hid[2][16];
@@ -42,12 +44,16 @@ bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
 
     for (int i = tid; i < 2 * IMGH / 8; i += NT) reinterpret_cast<bo_h8 *>(X)[i] = bo_h8{0, 0, 0, 0, 0, 0, 0, 0};
 
-    bo_f32x16 acc[4];          // [board*2 + half]: rows = output channels 32*wave + (r&3) + 8*(r>>2) + 4*kg, col = position n
-    bo_h8 a[8];                // A fragments of 8 consecutive K-steps
+    bo_f32x16 acc[MT][4];      // [tile][board*2 + half]: rows = channels 32*(MT*wave + tile) + (r&3) + 8*(r>>2) + 4*kg, col = position n
+    bo_h8 a[8][MT];            // A fragments of 8 consecutive K-steps
     bo_h8 bq[2][4];            // B operands of two consecutive K-steps
-    bo_h4 skip[4][4];          // block input at this lane's (positions, channels), packed like the LDS writes
+    bo_h4 skip[MT][4][4];      // block input at this lane's (positions, channels), packed like the LDS writes
     const _Float16 *xl = X + (size_t)cell0 * PH + 8 * kg;  // + board*IMGH + half*40*PH + tap/channel offset
-    auto load_a = [&](int j, int w_off8, int step) { if (LAB != 1 && LAB < 5) a[j] = wts[(size_t)w_off8 + ((size_t)step * NW + wave) * 64 + lane]; };
+    auto load_a = [&](int j, int w_off8, int step) {
+        if (LAB == 1 || LAB >= 5) return;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) a[j][mt] = wts[(size_t)w_off8 + ((size_t)step * (C / 32) + wave * MT + mt) * 64 + lane];
+    };
     auto read_b = [&](bo_h8(&b)[4], int off) {  // off: (tap offset in cells) * PH + 16 * channel group
         if (LAB == 2 || LAB >= 5) return;
         b[0] = *reinterpret_cast<const bo_h8 *>(xl + off);
@@ -76,13 +82,17 @@ bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
             const bo_tower_layer L = layers[l];
             const bo_tower_layer Ln = layers[l + 1 < n_layers ? l + 1 : 0];
             const int ncg = L.t4 / 9;  // channel groups of 16 per tap (L.t4 = K-steps of the layer, a multiple of 8)
-            float bv[16];
+            float bv[MT][16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) bv[r] = params[L.bias_off + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg];
+            for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+                for (int r = 0; r < 16; r++) bv[mt][r] = params[L.bias_off + (wave * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg];
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[mt][t][r] = 0.0f;
             read_b(bq[0], (-11) * PH);  // step 0: tap 0 = (-1, -1), channel group 0
             for (int s0 = 0; s0 < L.t4; s0 += 8) {
                 const int tap = s0 / ncg, cg0 = s0 - tap * ncg;
@@ -95,79 +105,93 @@ bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
                     const bo_h8(&bc)[4] = bq[j & 1];
                     read_b(bq[(j + 1) & 1], j < 7 ? off0 + 16 * (j + 1) : offn);
 #pragma unroll
-                    for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j], bc[t], acc[t], 0, 0, 0);
+                    for (int t = 0; t < 4; t++)
+#pragma unroll
+                        for (int mt = 0; mt < MT; mt++) acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j][mt], bc[t], acc[mt][t], 0, 0, 0);
                     const int sn = s0 + j + 8;  // this set's next owner: 8 steps ahead, maybe in the next layer
                     load_a(j, sn < L.t4 ? L.w_off4 : Ln.w_off4, sn < L.t4 ? sn : sn - L.t4);
-                    BO_H_SGB(0x008, 1); BO_H_SGB(0x100, 1); BO_H_SGB(0x008, 1); BO_H_SGB(0x100, 1);
-                    BO_H_SGB(0x008, 1); BO_H_SGB(0x100, 1); BO_H_SGB(0x008, 1); BO_H_SGB(0x100, 1); BO_H_SGB(0x020, 1);
+                    // every LDS read and weight load in the shadow of a different MFMA
+#pragma unroll
+                    for (int t = 0; t < 4; t++) { BO_H_SGB(0x008, MT); BO_H_SGB(0x100, 1); }
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) BO_H_SGB(0x020, 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (LAB != 6) __syncthreads();  // every wave has read the layer input: the output may overwrite it
 
-            // ---- epilogue: rows (r&3) + 8*(r>>2) + 4*kg of tile t are 4 consecutive channels per r>>2 ----
-            float gate[2][16];
+            // ---- epilogue: rows (r&3) + 8*(r>>2) + 4*kg of a tile are 4 consecutive channels per r>>2 ----
+            float gate[MT][2][16];
             if (L.kind == 3) {
-                // SE gate (network.py:33-45) for both boards.  Wave w owns hidden units 2w, 2w+1 (H <= 2 * #waves); lane (n, kg)
-                // owns the gate of channel 32*wave + n of board kg.  Weights are requested first, reductions run on the VALU (DPP).
+                // SE gate (network.py:33-45) for both boards.  Wave w owns hidden units w, w + NW, ...; lane (n, kg) owns the gates
+                // of channels 32*(MT*wave + tile) + n of board kg.  Weights are requested first, reductions run on the VALU (DPP).
                 const float *w1 = params + L.se_w1_off, *w2 = params + L.se_w2_off;
-                float w2r[16];
                 const bool have4 = lane < C / 4;  // a W1 row is C/4 float4: one per lane (C = 256) or per lane of the first half (128)
-                bo_f32x4 w1r[2];
+                float w2r[MT][16];
+                bo_f32x4 w1r[HPW];
 #pragma unroll
-                for (int u = 0; u < 2; u++)
-                    w1r[u] = (have4 && 2 * wave + u < L.hidden) ? reinterpret_cast<const bo_f32x4 *>(w1 + (size_t)(2 * wave + u) * C)[lane] : bo_f32x4{0, 0, 0, 0};
+                for (int u = 0; u < HPW; u++)
+                    w1r[u] = (have4 && wave + u * NW < L.hidden) ? reinterpret_cast<const bo_f32x4 *>(w1 + (size_t)(wave + u * NW) * C)[lane] : bo_f32x4{0, 0, 0, 0};
 #pragma unroll
-                for (int h = 0; h < 16; h++) w2r[h] = h < L.hidden ? w2[(wave * 32 + n) * L.hidden + h] : 0.0f;
+                for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-                for (int bb = 0; bb < 2; bb++)
+                    for (int h = 0; h < 16; h++) w2r[mt][h] = h < L.hidden ? w2[((wave * MT + mt) * 32 + n) * L.hidden + h] : 0.0f;
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const float s = bo_half_sum(acc[2 * bb][r] + acc[2 * bb + 1][r]);
-                        if (n == 16) pooled[bb][wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg] = s * (1.0f / 64.0f) + bv[r];
-                    }
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int bb = 0; bb < 2; bb++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const float s = bo_half_sum(acc[mt][2 * bb][r] + acc[mt][2 * bb + 1][r]);
+                            if (n == 16) pooled[bb][(wave * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg] = s * (1.0f / 64.0f) + bv[mt][r];
+                        }
                 __syncthreads();
 #pragma unroll
-                for (int u = 0; u < 2; u++)
+                for (int u = 0; u < HPW; u++)
 #pragma unroll
                     for (int bb = 0; bb < 2; bb++) {
                         const bo_f32x4 m = have4 ? reinterpret_cast<const bo_f32x4 *>(pooled[bb])[lane] : bo_f32x4{0, 0, 0, 0};
                         float p = (w1r[u][0] * m[0] + w1r[u][1] * m[1]) + (w1r[u][2] * m[2] + w1r[u][3] * m[3]);
                         p = bo_wave_sum63(p);
-                        if (lane == 63 && 2 * wave + u < L.hidden) hid[bb][2 * wave + u] = fmaxf(p, 0.0f);
+                        if (lane == 63 && wave + u * NW < L.hidden) hid[bb][wave + u * NW] = fmaxf(p, 0.0f);
                     }
                 __syncthreads();
-                float g = 0.0f;
 #pragma unroll
-                for (int h = 0; h < 16; h++)
-                    if (h < L.hidden) g += w2r[h] * hid[kg][h];
-                g = 1.0f / (1.0f + expf(-g));
+                for (int mt = 0; mt < MT; mt++) {
+                    float g = 0.0f;
 #pragma unroll
-                for (int bb = 0; bb < 2; bb++)
+                    for (int h = 0; h < 16; h++)
+                        if (h < L.hidden) g += w2r[mt][h] * hid[kg][h];
+                    g = 1.0f / (1.0f + expf(-g));
 #pragma unroll
-                    for (int r = 0; r < 16; r++) gate[bb][r] = __shfl(g, (r & 3) + 8 * (r >> 2) + 4 * kg + 32 * bb);
-            }
-            if (LAB >= 4) {
-                if (acc[0][0] == 123.456f) X[tid] = (_Float16)(acc[1][1] + acc[2][2] + acc[3][3]);
-            } else
+                    for (int bb = 0; bb < 2; bb++)
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                _Float16 *cellp = X + (size_t)(t >> 1) * IMGH + (size_t)(cell0 + 40 * (t & 1)) * PH + wave * 32 + 4 * kg;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    bo_h4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int r = 4 * q + e;
-                        float v = acc[t][r] + bv[r];
-                        if (L.kind == 3) v = v * gate[t >> 1][r];
-                        if (L.kind >= 2) v += (float)skip[t][q][e];
-                        o[e] = (_Float16)fmaxf(v, 0.0f);
-                    }
-                    if (L.kind != 1) skip[t][q] = o;
-                    *reinterpret_cast<bo_h4 *>(cellp + 8 * q) = o;
+                        for (int r = 0; r < 16; r++) gate[mt][bb][r] = __shfl(g, (r & 3) + 8 * (r >> 2) + 4 * kg + 32 * bb);
                 }
             }
+            if (LAB >= 4) {
+                if (acc[0][0][0] == 123.456f) X[tid] = (_Float16)(acc[0][1][1] + acc[MT - 1][2][2] + acc[MT - 1][3][3]);
+            } else
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    _Float16 *cellp = X + (size_t)(t >> 1) * IMGH + (size_t)(cell0 + 40 * (t & 1)) * PH + (wave * MT + mt) * 32 + 4 * kg;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        bo_h4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int r = 4 * q + e;
+                            float v = acc[mt][t][r] + bv[mt][r];
+                            if (L.kind == 3) v = v * gate[mt][t >> 1][r];
+                            if (L.kind >= 2) v += (float)skip[mt][t][q][e];
+                            o[e] = (_Float16)fmaxf(v, 0.0f);
+                        }
+                        if (L.kind != 1) skip[mt][t][q] = o;
+                        *reinterpret_cast<bo_h4 *>(cellp + 8 * q) = o;
+                    }
+                }
             if (LAB != 6) __syncthreads();
         }
         // ---- the two 1x1 head convolutions + ReLU on the tower output in X: one 32x32 job per (32 head channels, board, half) ----

@@ -213,12 +213,12 @@ int main() {
             for (int B : {512}) {
                 hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
                 auto go = [&]() {
-                    if (variant == 1) hipLaunchKernelGGL((bo_k_tower_h<256, 1>), dim3(256), dim3(512), 0, 0, x, tw, tp, tl, NL, B, hh);
-                    else if (variant == 2) hipLaunchKernelGGL((bo_k_tower_h<256, 2>), dim3(256), dim3(512), 0, 0, x, tw, tp, tl, NL, B, hh);
-                    else if (variant == 3) hipLaunchKernelGGL((bo_k_tower_h<256, 4>), dim3(256), dim3(512), 0, 0, x, tw, tp, tl, NL, B, hh);
-                    else if (variant == 4) hipLaunchKernelGGL((bo_k_tower_h<256, 5>), dim3(256), dim3(512), 0, 0, x, tw, tp, tl, NL, B, hh);
-                    else if (variant == 5) hipLaunchKernelGGL((bo_k_tower_h<256, 6>), dim3(256), dim3(512), 0, 0, x, tw, tp, tl, NL, B, hh);
-                    else hipLaunchKernelGGL((bo_k_tower_h<256, 0>), dim3(256), dim3(512), 0, 0, x, tw, tp, tl, NL, B, hh);
+                    if (variant == 1) hipLaunchKernelGGL((bo_k_tower_h<256, 2, 1>), dim3(256), dim3(256), 0, 0, x, tw, tp, tl, NL, B, hh);
+                    else if (variant == 2) hipLaunchKernelGGL((bo_k_tower_h<256, 2, 2>), dim3(256), dim3(256), 0, 0, x, tw, tp, tl, NL, B, hh);
+                    else if (variant == 3) hipLaunchKernelGGL((bo_k_tower_h<256, 2, 4>), dim3(256), dim3(256), 0, 0, x, tw, tp, tl, NL, B, hh);
+                    else if (variant == 4) hipLaunchKernelGGL((bo_k_tower_h<256, 2, 5>), dim3(256), dim3(256), 0, 0, x, tw, tp, tl, NL, B, hh);
+                    else if (variant == 5) hipLaunchKernelGGL((bo_k_tower_h<256, 2, 6>), dim3(256), dim3(256), 0, 0, x, tw, tp, tl, NL, B, hh);
+                    else hipLaunchKernelGGL((bo_k_tower_h<256, 2, 0>), dim3(256), dim3(256), 0, 0, x, tw, tp, tl, NL, B, hh);
                 };
                 for (int i = 0; i < 3; i++) go();
                 (void)hipEventRecord(e0, 0);
