@@ -38,34 +38,63 @@ extern "C" __global__ void __launch_bounds__(256)
 bo_k_se_residual(float *__restrict__ x, const float *__restrict__ bias, const float *__restrict__ w1 /*[H][C]*/,
                  const float *__restrict__ w2 /*[C][H]*/, const float *__restrict__ res, int C, int H) {
     extern __shared__ float tile[];  // [C][65] padded rows: conflict-free per-channel sums
-    __shared__ float mean[BO_SE_MAX_C], hid[BO_SE_MAX_H], gate[BO_SE_MAX_C];
-    const int b = blockIdx.x, t = threadIdx.x;
+    __shared__ float mean[BO_SE_MAX_C], hid[BO_SE_MAX_H], gate[BO_SE_MAX_C], part[256];
+    const int b = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
     float *xb = x + (size_t)b * C * 64;
     const float *rb = res + (size_t)b * C * 64;
-    for (int i = t; i < C * 64; i += 256) {  // coalesced load, + bias
+    // FC1 is spread over all 256 threads: 16 threads per hidden unit, each a slice of the C channels (a batch of one board --
+    // uci.py -- runs this kernel as a single workgroup, so its serial chains are the latency of the whole SE layer)
+    const int sl = t & 15, per = (C + 15) >> 4;
+    float w1r[BO_SE_MAX_C / 16];
+#pragma unroll
+    for (int i = 0; i < BO_SE_MAX_C / 16; i++) w1r[i] = 0.0f;
+    for (int h0 = 0; h0 < H; h0 += 16) {  // (H <= 16: one pass)
+        const int h = h0 + (t >> 4);
+        if (h0 == 0 && h < H && t < 256)
+#pragma unroll
+            for (int i = 0; i < BO_SE_MAX_C / 16; i++)
+                if (i < per && sl * per + i < C) w1r[i] = w1[h * C + sl * per + i];
+    }
+    for (int i = t; i < C * 64; i += nt) {  // coalesced load, + bias
         const int c = i >> 6, s = i & 63;
         tile[c * 65 + s] = xb[i] + bias[c];
     }
     __syncthreads();
-    for (int c = t; c < C; c += 256) {  // AdaptiveAvgPool2d(1)
+    for (int c = t; c < C; c += nt) {  // AdaptiveAvgPool2d(1)
         float a = 0.0f;
         for (int s = 0; s < 64; s++) a += tile[c * 65 + s];
         mean[c] = a * (1.0f / 64.0f);
     }
     __syncthreads();
-    if (t < H) {  // Linear(C, C/r, bias=False) + ReLU
+    for (int h0 = 0; h0 < H; h0 += 16) {  // Linear(C, C/r, bias=False) + ReLU
+        const int h = h0 + (t >> 4);
         float a = 0.0f;
-        for (int c = 0; c < C; c++) a += w1[t * C + c] * mean[c];
-        hid[t] = a > 0.0f ? a : 0.0f;
+        if (h < H && t < 256) {
+            if (h0 == 0) {
+#pragma unroll
+                for (int i = 0; i < BO_SE_MAX_C / 16; i++)
+                    if (i < per && sl * per + i < C) a += w1r[i] * mean[sl * per + i];
+            } else {
+                for (int i = 0; i < per; i++)
+                    if (sl * per + i < C) a += w1[h * C + sl * per + i] * mean[sl * per + i];
+            }
+        }
+        if (t < 256) part[t] = a;
+        __syncthreads();
+        if (sl == 0 && h < H && t < 256) {
+            float sum = 0.0f;
+            for (int i = 0; i < 16; i++) sum += part[(t & ~15) + i];
+            hid[h] = sum > 0.0f ? sum : 0.0f;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int c = t; c < C; c += 256) {  // Linear(C/r, C, bias=False) + Sigmoid
+    for (int c = t; c < C; c += nt) {  // Linear(C/r, C, bias=False) + Sigmoid
         float a = 0.0f;
         for (int j = 0; j < H; j++) a += w2[c * H + j] * hid[j];
         gate[c] = 1.0f / (1.0f + expf(-a));
     }
     __syncthreads();
-    for (int i = t; i < C * 64; i += 256) {  // scale, skip connection, ReLU
+    for (int i = t; i < C * 64; i += nt) {  // scale, skip connection, ReLU
         const int c = i >> 6, s = i & 63;
         const float v = tile[c * 65 + s] * gate[c] + rb[i];
         xb[i] = v > 0.0f ? v : 0.0f;
