@@ -394,3 +394,26 @@ def test_full_games_to_termination_match_oracle(backend):
 
 def test_edge_cases_maximum_sizes_and_error_paths(backend):
     EC.check_edge_cases(backend)
+
+
+def test_nn_tune_prefers_the_hand_written_evaluate_stage(backend):
+    """At the batch sizes of BASELINE.json's configurations the evaluate stage that nn_tune keeps is one of the hand-written
+    MFMA kernels (a silent fallback to the library convolutions would halve the throughput and still pass parity)."""
+    import torch
+    from betaone_amd import dropin
+    dropin.install()
+    import config, network
+    from betaone_amd.nn_tune import best_inference_copy
+
+    saved = (config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS)
+    try:
+        config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 8, 2, 128
+        torch.manual_seed(0)
+        net = network.PolicyValueNet().eval()
+        assert best_inference_copy(net, 256, "cuda:0").layout in ("nchw+tower_wg", "nchw+tower")
+        config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 3, 1, 256
+        big = network.PolicyValueNet().eval()
+        assert best_inference_copy(big, 1, "cuda:0").layout == "nchw+mfma_small"
+        assert best_inference_copy(big, 512, "cuda:0", torch.float16).layout == "nchw+tower_f16"
+    finally:
+        config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = saved
