@@ -443,6 +443,7 @@ extern "C" int bo_play(bo_engine *e, const int32_t *action, void *stream) {
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <unistd.h>
 namespace {
 struct BoPool {
     std::vector<std::thread> workers;
@@ -452,10 +453,12 @@ struct BoPool {
     int n_items = 0, chunk = 1, generation = 0, pending = 0;
     std::atomic<int> next{0};
     bool stop = false;
+    pid_t owner = getpid();
     explicit BoPool(int n) {
         for (int i = 0; i < n; i++) workers.emplace_back([this] { loop(); });
     }
     ~BoPool() {
+        if (getpid() != owner) { for (auto &t : workers) t.detach(); return; }
         { std::lock_guard<std::mutex> l(m); stop = true; }
         cv_go.notify_all();
         for (auto &t : workers) t.join();
@@ -483,7 +486,8 @@ struct BoPool {
         }
     }
     void run(int n, const std::function<void(int)> &f) {
-        if (workers.empty() || n < 64) { for (int i = 0; i < n; i++) f(i); return; }
+        // (a fork()ed child inherits the object but not the threads: it works inline)
+        if (workers.empty() || n < 64 || getpid() != owner) { for (int i = 0; i < n; i++) f(i); return; }
         {
             std::lock_guard<std::mutex> l(m);
             job = &f; n_items = n; chunk = 8; next = 0; pending = (int)workers.size(); generation++;
