@@ -458,7 +458,6 @@ struct BoPool {
         for (int i = 0; i < n; i++) workers.emplace_back([this] { loop(); });
     }
     ~BoPool() {
-        if (getpid() != owner) { for (auto &t : workers) t.detach(); return; }
         { std::lock_guard<std::mutex> l(m); stop = true; }
         cv_go.notify_all();
         for (auto &t : workers) t.join();
@@ -499,14 +498,16 @@ struct BoPool {
     }
 };
 BoPool &host_pool() {
-    static BoPool pool([] {
+    // never destroyed: the workers end with the process (a destructor would have to join threads that a fork()ed child
+    // does not have, or run during interpreter shutdown)
+    static BoPool *pool = new BoPool([] {
         const char *v = getenv("BO_HOST_THREADS");
         int n = v ? atoi(v) : 4;
         const int hw = (int)std::thread::hardware_concurrency();
         if (hw > 0 && n > hw / 2) n = hw / 2;  // leave room for the other ranks of a node
         return n < 1 ? 0 : n - 1;
     }());
-    return pool;
+    return *pool;
 }
 }  // namespace
 
