@@ -182,7 +182,15 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
     EngCfg &c = e->d.c;
     c.G = cfg->n_games; c.S = cfg->num_simulations; c.B = cfg->mcts_batch_size;
     e->fast = fast;
-    c.NCAP = fast ? 1 + (c.S + cfg->leaves_per_step + 1) * 64 : c.S + 2 * root_m + 4;
+    // Node capacity in reference semantics: a leaf evaluated with k rows of a batch gets int(W*sqrt(k)) children (mcts.py:55-57), and
+    // the k over all evaluated leaves of a search sum to at most S, so at most S * max_k int(W*sqrt(k))/k nodes beside the root's
+    // (= S for the reference's W = 1.5; a larger WIDEN_COEFF creates more nodes per simulation).
+    double per_sim = 1.0;
+    for (int k = 1; k <= cfg->mcts_batch_size; k++) {
+        const double r = (double)(int)(cfg->widen_coeff * sqrt((double)k)) / (double)k;
+        if (r > per_sim) per_sim = r;
+    }
+    c.NCAP = fast ? 1 + (c.S + cfg->leaves_per_step + 1) * 64 : (int)ceil(c.S * per_sim) + 2 * root_m + 4;
     c.PLY_CAP = cfg->max_plies; c.TRK_CAP = cfg->max_plies;
     c.UL_MAX = fast ? 1 : c.B; c.CH_MAX = ch_max < 1 ? 1 : ch_max;
     c.cpuct = (float)cfg->cpuct;

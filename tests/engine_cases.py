@@ -225,7 +225,8 @@ def check_golden_game(backend, name):
 
 
 # ---- many games in lock step vs the oracle (fresh inputs, not fixtures) ----------------------------------------
-def check_multi_game_vs_oracle(backend, n_games=5, plies=6, sims=60, batch=16, scale=6.0):
+def check_multi_game_vs_oracle(backend, n_games=5, plies=6, sims=60, batch=16, scale=6.0, **search_cfg):
+    """search_cfg: cpuct / widen_coeff / dirichlet_alpha / dirichlet_eps overrides (engine and oracle get the same)."""
     from fake_model import fake_logits_values
 
     def eval_fn_for(salt):
@@ -236,11 +237,11 @@ def check_multi_game_vs_oracle(backend, n_games=5, plies=6, sims=60, batch=16, s
             return (e / e.sum(axis=1, keepdims=True)).astype(np.float32), v
         return fn
 
-    cfg = dict(num_simulations=sims, batch_size=batch, max_game_moves=plies)
+    cfg = dict(num_simulations=sims, batch_size=batch, max_game_moves=plies, **search_cfg)
     eng = make_engine(backend, n_games, cfg)
     eng.reset(list(range(n_games)))
     fns = [eval_fn_for(1000 + g) for g in range(n_games)]
-    got = play_games(backend, eng, fns, [np.random.RandomState(g) for g in range(n_games)], 0.1, plies)
+    got = play_games(backend, eng, fns, [np.random.RandomState(g) for g in range(n_games)], cfg.get("dirichlet_alpha", 0.1), plies)
     ocfg = O.default_config(**cfg)
     for g in range(n_games):
         ref = O.self_play(fns[g], np.random.RandomState(g), ocfg)
@@ -329,3 +330,13 @@ class pytest_raises:
     def __exit__(self, et, ev, tb):
         assert et is not None and issubclass(et, self.exc), f"expected {self.exc}"
         return True
+
+
+SEARCH_CONFIG_SWEEP = [
+    dict(sims=7, batch=96),                                     # fewer simulations than one batch
+    dict(sims=100, batch=1),                                    # one row per evaluation
+    dict(sims=97, batch=13, cpuct=2.5, widen_coeff=1.0),        # ragged last batch, the narrowest widening the engine takes
+    dict(sims=64, batch=8, widen_coeff=4.0),                    # widening faster than the child cap grows
+    dict(sims=80, batch=16, dirichlet_alpha=0.0),               # no root noise
+    dict(sims=80, batch=16, dirichlet_alpha=0.9, dirichlet_eps=1.0, cpuct=0.3),  # priors replaced by noise, exploitation-heavy
+]

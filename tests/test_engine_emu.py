@@ -43,3 +43,9 @@ def test_full_games_to_termination_match_oracle(backend):
 
 def test_edge_cases_maximum_sizes_and_error_paths(backend):
     EC.check_edge_cases(backend)
+
+
+@pytest.mark.parametrize("cfg", EC.SEARCH_CONFIG_SWEEP, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_search_configuration_sweep_matches_oracle(backend, cfg):
+    """Batch sizes around the simulation count, unusual CPUCT / widening / Dirichlet settings: moves, pi and states bit-exact."""
+    EC.check_multi_game_vs_oracle(backend, n_games=2, plies=3, **cfg)

@@ -417,3 +417,9 @@ def test_nn_tune_prefers_the_hand_written_evaluate_stage(backend):
         assert best_inference_copy(big, 512, "cuda:0", torch.float16).layout == "nchw+tower_f16"
     finally:
         config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = saved
+
+
+@pytest.mark.parametrize("cfg", EC.SEARCH_CONFIG_SWEEP, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_search_configuration_sweep_matches_oracle(backend, cfg):
+    """Batch sizes around the simulation count, unusual CPUCT / widening / Dirichlet settings: moves, pi and states bit-exact."""
+    EC.check_multi_game_vs_oracle(backend, n_games=8, plies=5, **cfg)
