@@ -340,3 +340,44 @@ SEARCH_CONFIG_SWEEP = [
     dict(sims=80, batch=16, dirichlet_alpha=0.0),               # no root noise
     dict(sims=80, batch=16, dirichlet_alpha=0.9, dirichlet_eps=1.0, cpuct=0.3),  # priors replaced by noise, exploitation-heavy
 ]
+
+
+START_FENS = [
+    "r3k2r/p1ppqpb1/bn2pnp1/3PN3/1p2P3/2N2Q1p/PPPBBPPP/R3K2R b KQkq - 0 1",   # black to move, all castling rights, 40+ moves
+    "rnbqkbnr/ppp1pppp/8/8/3pP3/8/PPPP1PPP/RNBQKBNR b KQkq e3 0 3",           # en passant available at the root
+    "8/P6k/8/8/8/8/p6K/8 w - - 0 60",                                          # promotions (4 pieces each) next move, move 60: low temperature
+    "k7/8/1K6/8/8/8/8/7R w - - 96 80",                                         # fifty-move rule inside the search horizon
+    "4k3/8/8/8/8/2n5/8/R3K2R w KQ - 3 30",                                     # in check at the root, temperature threshold move
+    "6k1/5ppp/8/8/8/8/5PPP/3R2K1 w - - 0 1",                                   # back-rank mate in one for white
+]
+
+
+def check_games_from_positions_vs_oracle(backend, plies=5, sims=40, batch=8, scale=5.0):
+    """Self-play games started from positions with the features the start position lacks: side to move, en passant,
+    promotion, check, a ticking halfmove clock, forced mates (terminal simulations), fullmove numbers around the temperature
+    threshold.  Moves, pi, dense states and z bit-exact against the oracle."""
+    from fake_model import fake_logits_values
+
+    def eval_fn_for(salt):
+        def fn(planes):
+            logits, v = fake_logits_values(planes, scale, salt)
+            x = logits.astype(np.float64)
+            e = np.exp(x - x.max(axis=1, keepdims=True))
+            return (e / e.sum(axis=1, keepdims=True)).astype(np.float32), v
+        return fn
+
+    n = len(START_FENS)
+    cfg = dict(num_simulations=sims, batch_size=batch, max_game_moves=plies)
+    eng = make_engine(backend, n, cfg)
+    eng.reset(list(range(n)), START_FENS)
+    fns = [eval_fn_for(77 + g) for g in range(n)]
+    got = play_games(backend, eng, fns, [np.random.RandomState(40 + g) for g in range(n)], 0.1, plies)
+    ocfg = O.default_config(**cfg)
+    for g in range(n):
+        ref = O.self_play(fns[g], np.random.RandomState(40 + g), ocfg, start_fen=START_FENS[g])
+        assert ref is not None, START_FENS[g]
+        assert [O.move_to_uci(m) for m in ref["moves"]] == got[g]["moves"], START_FENS[g]
+        for (st, pi, z), gpi, gst, gz in zip(ref["records"], got[g]["pis"], got[g]["states"], got[g]["z"]):
+            assert np.array_equal(pi.view(np.uint32), gpi.view(np.uint32)), START_FENS[g]
+            assert np.array_equal(st, gst), START_FENS[g]
+            assert z == gz

@@ -49,3 +49,7 @@ def test_edge_cases_maximum_sizes_and_error_paths(backend):
 def test_search_configuration_sweep_matches_oracle(backend, cfg):
     """Batch sizes around the simulation count, unusual CPUCT / widening / Dirichlet settings: moves, pi and states bit-exact."""
     EC.check_multi_game_vs_oracle(backend, n_games=2, plies=3, **cfg)
+
+
+def test_games_from_special_start_positions_match_oracle(backend):
+    EC.check_games_from_positions_vs_oracle(backend)

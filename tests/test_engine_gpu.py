@@ -423,3 +423,7 @@ def test_nn_tune_prefers_the_hand_written_evaluate_stage(backend):
 def test_search_configuration_sweep_matches_oracle(backend, cfg):
     """Batch sizes around the simulation count, unusual CPUCT / widening / Dirichlet settings: moves, pi and states bit-exact."""
     EC.check_multi_game_vs_oracle(backend, n_games=8, plies=5, **cfg)
+
+
+def test_games_from_special_start_positions_match_oracle(backend):
+    EC.check_games_from_positions_vs_oracle(backend)
