@@ -259,10 +259,12 @@ def main():
         next_id[0] += world
         return i, i, None
 
+    exchange = records.LaggedGameExchange(device) if dist is not None else None
+
     def one_step():
         ro.play_ply(on_finished=on_finished, refill=refill)
-        if dist is not None:  # the path's only exchange step: finished games' records to every rank (RCCL over xGMI)
-            records.all_gather_games(finished_batch, device)
+        if exchange is not None:  # the path's only exchange step: finished games' records to every rank (RCCL over xGMI);
+            exchange.push(finished_batch)  # the size all-gather completes while the next ply runs
         finished_batch.clear()
 
     for _ in range(args.warmup):
@@ -275,6 +277,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
+    if exchange is not None:
+        exchange.flush()  # the last step's records are delivered inside the timed region
     torch.cuda.synchronize(device)
     if dist is not None:
         dist.barrier()

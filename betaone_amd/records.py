@@ -126,6 +126,65 @@ def all_gather_games(finished: Sequence, device: Optional[torch.device] = None, 
     return games
 
 
+class LaggedGameExchange:
+    """all_gather_games with the size exchange one step behind: `push(finished)` starts the (tiny) size all-gather of this
+    step's records asynchronously and completes the PREVIOUS step's exchange, whose sizes arrived while a whole ply ran on
+    the GPU -- the host never waits for a collective it has just issued.  Every rank must call push() once per step and
+    flush() once at the end; records are delivered one step late."""
+
+    def __init__(self, device: Optional[torch.device] = None, group=None):
+        self.device, self.group, self._pending = device, group, None
+
+    def _start(self, finished):
+        import torch.distributed as dist
+
+        payload = b"".join(pack_game(f) for f in finished)
+        if not dist.is_available() or not dist.is_initialized():
+            return (payload, None, None)
+        world = dist.get_world_size(self.group)
+        backend = dist.get_backend(self.group)
+        dev = self.device if (self.device is not None and backend == "nccl") else torch.device("cpu")
+        sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+        mine = torch.tensor([len(payload)], dtype=torch.int64, device=dev)
+        work = dist.all_gather_into_tensor(sizes, mine, group=self.group, async_op=True)
+        return (payload, sizes, (work, mine, dev))
+
+    def _finish(self, pending) -> List[dict]:
+        import torch.distributed as dist
+
+        payload, sizes, h = pending
+        if h is None:
+            return unpack_games(payload) if payload else []
+        work, _mine, dev = h
+        work.wait()
+        sizes_h = sizes.cpu().tolist()
+        mx = max(sizes_h)
+        if mx == 0:
+            return []
+        pad = torch.zeros(mx, dtype=torch.uint8)
+        if payload:
+            pad[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
+        pad = pad.to(dev)
+        gathered = torch.empty(len(sizes_h) * mx, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(gathered, pad, group=self.group)
+        g = gathered.cpu().numpy()
+        games: List[dict] = []
+        for r in range(len(sizes_h)):
+            games.extend(unpack_games(g[r * mx:r * mx + sizes_h[r]].tobytes()))
+        return games
+
+    def push(self, finished: Sequence) -> List[dict]:
+        nxt = self._start(finished)
+        out = self._finish(self._pending) if self._pending is not None else []
+        self._pending = nxt
+        return out
+
+    def flush(self) -> List[dict]:
+        out = self._finish(self._pending) if self._pending is not None else []
+        self._pending = None
+        return out
+
+
 def shard_game_ids(n_games_total: int, rank: int, world: int) -> List[int]:
     """Game id g runs on GPU g mod world; its RNG seed travels with the id."""
     return list(range(rank, n_games_total, world))

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, lagged=False):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -42,12 +42,15 @@ def _worker(rank, world, port, out_dir):
     ro.start_games(list(range(len(ids))), ids, [np.random.RandomState(i) for i in ids])
     fins = []
     gathered = []
+    ex = records.LaggedGameExchange() if lagged else None        # bench.py's form: the size exchange one step behind
     for _step in range(6):   # every rank makes the SAME number of exchange steps (as bench.py does: one per step)
         batch = []
         if any(g is not None for g in ro.games):
             ro.play_ply(on_finished=batch.append)
         fins.extend(batch)
-        gathered.extend(records.all_gather_games(batch))         # the path's only exchange step
+        gathered.extend(ex.push(batch) if lagged else records.all_gather_games(batch))   # the path's only exchange step
+    if lagged:
+        gathered.extend(ex.flush())
     assert not any(g is not None for g in ro.games)
     ro.close()
     mine = {g.game_id: [m for m in g.moves] for g in fins}
@@ -61,9 +64,10 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_shard_games_and_all_gather_records(tmp_path):
+@pytest.mark.parametrize("lagged", [False, True])
+def test_two_ranks_shard_games_and_all_gather_records(tmp_path, lagged):
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), lagged), nprocs=world, join=True)
     a = np.load(tmp_path / "rank0.npy")
     b = np.load(tmp_path / "rank1.npy")
     assert np.array_equal(a, b)                       # every rank ends with every game's record
