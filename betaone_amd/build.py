@@ -8,7 +8,6 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libbetaone_hip.so")
 SOURCES = ["bo_engine.cpp"]
-HEADERS = ["bo_wave.h", "bo_chess.h", "bo_tree.h", "bo_select_wide.h", "bo_rt.h", "../../include/betaone_engine.h"]
 # strict IEEE binary32 in the tree arithmetic (parity with the reference's NumPy float32 scalars):
 # no FMA contraction, correctly rounded fp32 divide, denormals kept.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
@@ -22,11 +21,29 @@ def hipcc() -> str:
     return "hipcc"
 
 
+def dependencies():
+    """Everything libbetaone_hip.so is compiled from: every file of csrc/ (bo_engine.cpp includes all the headers), the
+    public header, and this file (the flags)."""
+    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".cpp", ".hip"))]
+    return deps + [os.path.join(HERE, "..", "include", "betaone_engine.h"), os.path.abspath(__file__)]
+
+
+def source_hash() -> str:
+    import hashlib
+
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for f in dependencies()[:-1]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    """Stale = the library is missing or was not built from the sources next to it (content hash kept in a sidecar file:
+    the .so is git-ignored but travels to the GPU box, where file times say nothing)."""
+    if not os.path.exists(LIB) or not os.path.exists(LIB + ".srchash"):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return open(LIB + ".srchash").read().strip() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -35,6 +52,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        with open(LIB + ".srchash", "w") as f:
+            f.write(source_hash() + "\n")
     return LIB
 
 

@@ -522,6 +522,7 @@ BoPool &host_pool() {
 extern "C" int bo_rng_seed(bo_engine *e, int slot, uint32_t seed) {
     if (!e || slot < 0 || slot >= e->d.c.G) return fail(BO_E_ARG, "bad slot");
     hr_seed(&e->rng[slot], seed);
+    if ((int)e->noise_pending.size() == e->d.c.G) e->noise_pending[slot] = 0;  // a new game: the old root's deferred draw is void
     return BO_OK;
 }
 
@@ -567,6 +568,7 @@ static int selfplay_begin_impl(bo_engine *e, const int32_t *want, float *nn_in_d
     host_pool().run(G, [&](int g) {
         const int go = want[g] && e->h_term[g] == 0;
         e->h_go[g] = go;
+        if (want[g]) e->noise_pending[g] = 0;
         if (go && alpha > 0) {
             if (defer_noise) e->noise_pending[g] = 1;
             else hr_dirichlet(&e->rng[g], alpha, e->h_nl[g], &e->h_noise[(size_t)g * BO_MAX_MOVES]);  // mcts.py:192
@@ -758,19 +760,14 @@ extern "C" int bo_select_wide(const void *blocks_dev, const int32_t *root_block_
 #else
     if (!blocks_dev || !root_block_dev || !root_n_dev || !sqrt_lut_dev || !out_leaf_dev || !out_levels_dev || n_trees < 1)
         return fail(BO_E_ARG, "bad arguments");
-    // grid_blocks: low 20 bits = workgroups (0 = auto), bits 20..23 = tuning variant (0 default; sweeps only)
-    const int variant = (grid_blocks >> 20) & 15;
-    grid_blocks &= 0xFFFFF;
-    const int U = variant == 1 ? 2 : variant == 2 ? 8 : 4;
+    const int U = 4;  // trees in flight per half-wave (bo_select_wide.h)
     if (grid_blocks < 1) {
         // one workgroup per 8*U trees and no grid-stride tail; measured on MI355X at 262 144 trees: 4096 (strided) 85.9 us,
         // 8192 (exact) 83.1 us, 16384 (half of the workgroups exit at once) 81.3 us -- launch twice the exact grid.
         grid_blocks = 2 * ((n_trees + 8 * U - 1) / (8 * U));
-        if (grid_blocks > 65536) grid_blocks = 65536;
     }
-    auto kern = variant == 1 ? bo_k_select_wide_u2 : variant == 2 ? bo_k_select_wide_u8 : variant == 3 ? bo_k_select_wide_u4_plain
-                                                                                                  : bo_k_select_wide;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid_blocks), dim3(256), 0, (hipStream_t)stream,
+    if (grid_blocks > 65536) grid_blocks = 65536;
+    hipLaunchKernelGGL(bo_k_select_wide, dim3((unsigned)grid_blocks), dim3(256), 0, (hipStream_t)stream,
                        (const WideBlock *)blocks_dev, (const int *)root_block_dev, (const int *)root_n_dev, sqrt_lut_dev,
                        n_trees, max_depth, cpuct, (int *)out_leaf_dev, (int *)out_levels_dev);
     RT((int)hipGetLastError());

@@ -112,8 +112,5 @@ select_wide_body(const wide_i4 *__restrict__ recs /* WideBlock[] viewed as 16-by
          int *__restrict__ out_levels) {                                                                                \
         select_wide_body<U, NT>(reinterpret_cast<const wide_i4 *>(blocks), root_block, root_n, sqrt_lut, n_trees, max_depth, cpuct, out_leaf, out_levels);   \
     }
-BO_WIDE_KERNEL(bo_k_select_wide, 4, true)
-BO_WIDE_KERNEL(bo_k_select_wide_u2, 2, true)
-BO_WIDE_KERNEL(bo_k_select_wide_u8, 8, true)
-BO_WIDE_KERNEL(bo_k_select_wide_u4_plain, 4, false)
+BO_WIDE_KERNEL(bo_k_select_wide, 4, true)  // measured: 2 and 8 trees per half-wave and plain (cached) loads are all slower
 #endif

@@ -30,8 +30,9 @@ _TABLES = {
     #                 True  = what the reference does on CUDA (torch.autocast around the net, mcts.py:183,285)
     #   SEARCH_MODE   "reference" = BetaOne's own search semantics, bit-exact; "fast" = csrc/bo_fast.h (virtual loss,
     #                 FAST_LEAVES leaves per game per step, full-width expansion: a conventional AlphaZero search)
-    #   ENGINE_MAX_PLIES  capacity of one game's position stack on the GPU
-    "engine": dict(AUTOCAST=False, SEARCH_MODE="reference", FAST_LEAVES=16, ENGINE_MAX_PLIES=2048),
+    #   ENGINE_MAX_PLIES  capacity of one game's position stack on the GPU; None = MAX_GAME_MOVES + 2 in self-play
+    #                 (2.7 MB per slot at 16384; a smaller value stops longer games like the move limit does)
+    "engine": dict(AUTOCAST=False, SEARCH_MODE="reference", FAST_LEAVES=16, ENGINE_MAX_PLIES=None),
 }
 for _group in _TABLES.values():
     globals().update(_group)

@@ -19,31 +19,17 @@ from betaone_amd import engine as E
 _lock = threading.Lock()
 _ctx = {}            # config tuple -> (Engine, nn_in tensor)
 _fast = {}           # id(model) -> (parameter versions, inference copy, captured hipGraph state)
-_test_backend = None  # tests only: (ctypes library, torch device string)
-
-
-def _set_test_backend(lib, device: str = "cpu"):
-    """tests/ only: bind the drop-in to the wave-emulator build of the engine."""
-    global _test_backend
-    _test_backend = (lib, device) if lib is not None else None
-    _ctx.clear()
 
 
 def _context():
+    device = E.runtime_device(config.DEVICE)  # 'cuda' -> cuda:<current device>; raises off the GPU (no CPU path)
     key = (config.NUM_SIMULATIONS, config.MCTS_BATCH_SIZE, config.CPUCT, config.WIDEN_COEFF, config.DIRICHLET_ALPHA,
-           config.DIRICHLET_EPSILON, _test_backend is not None)
+           config.DIRICHLET_EPSILON, str(device), id(E.load_hip_library()))
     if key not in _ctx:
-        if _test_backend is not None:
-            lib, dev = _test_backend
-        else:
-            lib, dev = None, config.DEVICE
-            if not str(dev).startswith("cuda"):
-                raise E.EngineError("mcts.run_mcts needs config.DEVICE == 'cuda' (MI355X); there is no CPU path")
-        device = torch.device(dev)
         eng = E.Engine(1, num_simulations=config.NUM_SIMULATIONS, mcts_batch_size=config.MCTS_BATCH_SIZE,
                        cpuct=config.CPUCT, widen_coeff=config.WIDEN_COEFF, dirichlet_alpha=config.DIRICHLET_ALPHA,
-                       dirichlet_epsilon=config.DIRICHLET_EPSILON, max_plies=config.ENGINE_MAX_PLIES,
-                       device=device.index or 0, lib=lib)
+                       dirichlet_epsilon=config.DIRICHLET_EPSILON, max_plies=config.ENGINE_MAX_PLIES or 16386,
+                       device=device.index if device.index is not None else 0)
         nn_in = torch.zeros((1, config.INPUT_CHANNELS, 8, 8), dtype=torch.float32, device=device)
         _ctx.clear()  # one live engine is enough for the single-search path
         _ctx[key] = (eng, nn_in)
@@ -143,7 +129,7 @@ class _GraphStep:
 def _fast_path(model, eng, nn_in):
     """Tuned inference copy (BN folded, fused epilogues when fp32) + captured step; rebuilt when the caller's
     parameters change (their version counters move on load_state_dict / optimizer steps)."""
-    if _test_backend is not None or nn_in.device.type != "cuda" or config.AUTOCAST or not hasattr(model, "for_inference"):
+    if nn_in.device.type != "cuda" or config.AUTOCAST or not hasattr(model, "for_inference"):
         return None
     ver = tuple(p._version for p in model.parameters())
     hit = _fast.get(id(model))

@@ -21,14 +21,6 @@ from betaone_amd.rollout import FinishedGame, Rollout
 
 SelfPlayData = Tuple[torch.Tensor, np.ndarray, float]
 
-_test_backend = None  # tests only: (ctypes library, device string)
-
-
-def _set_test_backend(lib, device: str = "cpu"):
-    global _test_backend
-    _test_backend = (lib, device) if lib is not None else None
-
-
 def apply_temperature(probs: np.ndarray, temperature: float) -> np.ndarray:
     return sampling.apply_temperature(probs, temperature, np.random)
 
@@ -39,26 +31,24 @@ def select_move_with_temperature(probs: np.ndarray, move_number: int) -> int:
 
 
 def _rollout(model, n_slots: int, rng_mode: str = "python") -> Rollout:
-    lib, dev = (None, config.DEVICE) if _test_backend is None else _test_backend
-    if _test_backend is None and not str(dev).startswith("cuda"):
-        raise E.EngineError("self_play needs config.DEVICE == 'cuda' (MI355X); there is no CPU path")
-    if _test_backend is None and hasattr(model, "for_inference"):  # BN-folded copy in the faster layout for n_slots rows
+    dev = E.runtime_device(config.DEVICE)  # raises off the GPU: there is no CPU path
+    if dev.type == "cuda" and hasattr(model, "for_inference"):  # BN-folded copy in the faster layout for n_slots rows
         from betaone_amd.nn_tune import best_inference_copy
 
         rows = n_slots * (config.FAST_LEAVES if config.SEARCH_MODE == "fast" else 1)
         model = best_inference_copy(model, rows, dev, next(model.parameters()).dtype)
     return Rollout(model, n_slots, num_simulations=config.NUM_SIMULATIONS, mcts_batch_size=config.MCTS_BATCH_SIZE,
                    cpuct=config.CPUCT, widen_coeff=config.WIDEN_COEFF, dirichlet_alpha=config.DIRICHLET_ALPHA,
-                   dirichlet_epsilon=config.DIRICHLET_EPSILON, max_plies=config.ENGINE_MAX_PLIES,
+                   dirichlet_epsilon=config.DIRICHLET_EPSILON, max_plies=config.ENGINE_MAX_PLIES,  # None = room for MAX_GAME_MOVES
                    max_game_moves=config.MAX_GAME_MOVES,
                    temperature=(config.TEMPERATURE_THRESHOLD, config.TEMPERATURE_INITIAL, config.TEMPERATURE_FINAL),
-                   device=dev, autocast=config.AUTOCAST, use_graph=_test_backend is None, rng_mode=rng_mode,
-                   fast=config.SEARCH_MODE == "fast", leaves_per_step=config.FAST_LEAVES, lib=lib)
+                   device=dev, autocast=config.AUTOCAST, rng_mode=rng_mode,
+                   fast=config.SEARCH_MODE == "fast", leaves_per_step=config.FAST_LEAVES)
 
 
 def _records(ro: Rollout, fin: FinishedGame) -> List[SelfPlayData]:
     n = len(fin.pis)
-    states = ro.encode_finished_in_slot(fin.slot, n).cpu()
+    states = ro.encode_finished_in_slot(fin.slot, n, fin.first_ply).cpu()
     out = []
     for i in range(n):
         idx, val = fin.pis[i]
@@ -95,16 +85,28 @@ def run_self_play_games(model, game_ids: Sequence[int], seeds: Optional[Sequence
     try:
         while any(g is not None for g in ro.games):
             ro.play_ply(on_finished=finished, refill=next_game)
-            bad = np.nonzero(ro.eng.status()["status"])[0]
-            for g in bad:  # aborted games return None (self_play.py:119,167,180)
-                if ro.games[g] is not None:
-                    results[ro.games[g].game_id] = None
-                    ro.games[g] = None
-            if len(bad):
-                break
+            _settle_status(ro, results, finished, next_game)
     finally:
         ro.close()
     return results
+
+
+def _settle_status(ro: Rollout, results, finished, next_game):
+    """Per-game conditions end THAT game only, as in the reference (one game per call there): an unplayable move is the
+    abort of self_play.py:167 (-> None); a slot whose position stack is full (config.ENGINE_MAX_PLIES smaller than
+    MAX_GAME_MOVES) is the move-limit stop of self_play.py:186 (records kept).  Anything else is an engine fault."""
+    st = ro.eng.status_bits()
+    for g in np.nonzero(st)[0]:
+        g, bits = int(g), int(st[g])
+        if ro.games[g] is None:
+            continue
+        if bits & ~(E.ST_PLY_OVERFLOW | E.ST_ILLEGAL_ACTION):
+            raise E.EngineError(f"game {ro.games[g].game_id} (slot {g}): {ro.eng.describe_status(bits)}")
+        if bits & E.ST_ILLEGAL_ACTION:
+            results[ro.games[g].game_id] = None
+            ro.retire(g, None, next_game)
+        else:
+            ro.retire(g, finished, next_game)
 
 
 def run_self_play_game(model, game_id: int) -> Optional[List[SelfPlayData]]:
@@ -119,11 +121,11 @@ def run_self_play_game(model, game_id: int) -> Optional[List[SelfPlayData]]:
         out[0] = _records(ro, fin)
 
     ro.start_games([0], [game_id], [np.random])
+    results = {}
     try:
         while ro.games[0] is not None:
             ro.play_ply(on_finished=finished)
-            if ro.eng.status()["status"][0]:
-                return None
+            _settle_status(ro, results, finished, None)
     finally:
         ro.close()
     return out[0]

@@ -2,8 +2,7 @@
 betaone_amd/engine.py -- thin ctypes binding of the C ABI in include/betaone_engine.h.
 
 The product only ever loads csrc/libbetaone_hip.so (hipcc, gfx950) and raises if it is missing or
-cannot be loaded -- there is no CPU fallback.  (Tests may bind the same class to the wave-emulator
-build of the same sources by passing their own CDLL; see tests/wave_emulator.)
+cannot be loaded -- there is no CPU fallback and no backend switch in this package.
 """
 from __future__ import annotations
 
@@ -27,6 +26,7 @@ POLICY_NONE, POLICY_LOGITS, POLICY_PROBS = 0, 1, 2
 
 STATUS_BITS = {1: "node overflow", 2: "depth overflow", 4: "NaN PUCT score", 8: "ply overflow",
                16: "illegal action", 32: "leaf cache overflow", 64: "tracker overflow"}
+ST_PLY_OVERFLOW, ST_ILLEGAL_ACTION = 8, 16   # per-GAME conditions (the reference aborts that game only); the rest are engine faults
 
 
 class EngineError(RuntimeError):
@@ -118,13 +118,27 @@ def load_hip_library() -> C.CDLL:
     """The product's only loader: csrc/libbetaone_hip.so or an exception."""
     global _hip_lib
     if _hip_lib is None:
+        from . import build as _build
+
         if not os.path.exists(HIP_LIB_PATH):
             raise EngineError(f"{HIP_LIB_PATH} is missing: build it with `python -m betaone_amd.build` "
                               "(hipcc --offload-arch=gfx950); betaone_amd has no CPU fallback")
+        if _build.needs_build():
+            raise EngineError(f"{HIP_LIB_PATH} was not built from the sources next to it (csrc/*.h changed since): "
+                              "run `python -m betaone_amd.build`")
         _hip_lib = bind(C.CDLL(HIP_LIB_PATH))
         if _hip_lib.bo_abi_version() != 1:
             raise EngineError("libbetaone_hip.so ABI version mismatch")
     return _hip_lib
+
+
+def runtime_device(requested) -> torch.device:
+    """The torch device a product path runs on: an MI355X ('cuda' / 'cuda:N', index resolved once against torch's
+    current device so that the engine, its NN rows and the model agree on every rank) or an exception."""
+    dev = torch.device(requested)
+    if dev.type != "cuda":
+        raise EngineError(f"betaone_amd runs on an MI355X (device 'cuda' / 'cuda:N', got {requested!r}); there is no CPU path")
+    return torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
 
 
 def move_to_uci(m: int) -> str:
@@ -146,9 +160,8 @@ class Engine:
 
     def __init__(self, n_games: int, num_simulations: int = 250, mcts_batch_size: int = 96, cpuct: float = 1.0,
                  widen_coeff: float = 1.5, dirichlet_alpha: float = 0.1, dirichlet_epsilon: float = 0.25,
-                 max_plies: int = 1024, device: int = 0, lib: Optional[C.CDLL] = None, fast: bool = False,
-                 leaves_per_step: int = 8):
-        self.lib = lib if lib is not None else load_hip_library()
+                 max_plies: int = 1024, device: int = 0, fast: bool = False, leaves_per_step: int = 8):
+        self.lib = load_hip_library()
         self.G = int(n_games)
         self.fast, self.L = bool(fast), int(leaves_per_step) if fast else 1
         self.cfg = BoConfig(n_games, num_simulations, mcts_batch_size, max_plies, cpuct, widen_coeff, dirichlet_alpha,
@@ -294,8 +307,9 @@ class Engine:
         return nl, tm, go
 
     # -- records / introspection --------------------------------------------------------------------
-    def export_game(self, slot: int, stream: int = 0):
-        cap = self.cfg.max_plies + 1
+    def export_game(self, slot: int, stream: int = 0, n_plies: Optional[int] = None):
+        """(positions[n+1], moves[n]) of the game in `slot`; n_plies = the caller's own count sizes the buffers."""
+        cap = (self.cfg.max_plies if n_plies is None else min(int(n_plies), self.cfg.max_plies)) + 1
         pos = (BoPosition * cap)()
         mv = np.zeros(cap, dtype=np.int32)
         n = C.c_int32()
@@ -319,13 +333,22 @@ class Engine:
         self._check(self.lib.bo_engine_status(self.h, *[_p(out[k]) for k in names], stream))
         return out
 
+    def status_bits(self, stream: int = 0) -> np.ndarray:
+        """Only the per-slot status words (one small copy): 0 = fine, else a combination of STATUS_BITS."""
+        st = np.zeros(self.G, np.int32)
+        self._check(self.lib.bo_engine_status(self.h, _p(st), None, None, None, None, None, stream))
+        return st
+
+    @staticmethod
+    def describe_status(bits: int) -> str:
+        return ", ".join(v for b, v in STATUS_BITS.items() if bits & b)
+
     def check_status(self):
-        st = self.status()["status"]
+        st = self.status_bits()
         bad = np.nonzero(st)[0]
         if len(bad):
             g = int(bad[0])
-            msg = ", ".join(v for b, v in STATUS_BITS.items() if st[g] & b)
-            raise EngineError(f"game slot {g}: {msg}")
+            raise EngineError(f"game slot {g}: {self.describe_status(int(st[g]))}")
 
     def profile(self, enable: int = -1, read: bool = True, stream: int = 0):
         out = np.zeros((self.G, 10), dtype=np.uint64) if read else None

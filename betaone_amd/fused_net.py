@@ -97,10 +97,10 @@ def conv3x3_mfma(lib, x, wpacked, bias, c_out, mode=0, residual=None, out=None):
 
 
 class FusedPolicyValueNet(nn.Module):
-    def __init__(self, net, lib=None, conv="miopen"):
+    def __init__(self, net, conv="miopen"):
         """net: a PolicyValueNet (any device); weights are copied, BN folded."""
         super().__init__()
-        self.lib = lib if lib is not None else E.load_hip_library()
+        self.lib = E.load_hip_library()
         self.conv = conv
         f = net.for_inference(dtype=torch.float32, channels_last=False)
         dev = next(f.parameters()).device

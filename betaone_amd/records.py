@@ -33,6 +33,8 @@ POS_BYTES = C.sizeof(E.BoPosition)
 
 def pack_game(fin) -> bytes:
     """FinishedGame (betaone_amd.rollout) -> bytes."""
+    if getattr(fin, "first_ply", 0):
+        raise ValueError("pack_game: a game continued from a move prefix has no pi for its first plies")
     n = len(fin.pis)
     ptr = np.zeros(n + 1, dtype=np.int32)
     for i, (idx, _) in enumerate(fin.pis):
@@ -67,10 +69,10 @@ def unpack_games(buf: bytes) -> List[dict]:
     return out
 
 
-def expand_game(game: dict, device="cuda:0", lib=None) -> List[Tuple[torch.Tensor, np.ndarray, float]]:
+def expand_game(game: dict, device="cuda:0") -> List[Tuple[torch.Tensor, np.ndarray, float]]:
     """Compact record -> the reference's dense SelfPlayData list (self_play.py:200-216), planes by the
     engine's encode kernel on `device`."""
-    lib = lib if lib is not None else E.load_hip_library()
+    lib = E.load_hip_library()
     n = game["n_plies"]
     if n == 0:
         return []

@@ -36,8 +36,9 @@ class GameState:
     start_fen: Optional[str] = None
     start_fullmove: int = 1
     start_white: bool = True
-    plies: int = 0
-    pis: List = field(default_factory=list)   # per ply: (action indices, float32 probabilities)
+    plies: int = 0                   # moves on the game's stack (incl. a prefix handed to start_games)
+    first_ply: int = 0               # length of that prefix: the first ply searched here
+    pis: List = field(default_factory=list)   # per searched ply: (action indices, float32 probabilities)
 
     def fullmove_number(self) -> int:          # board.fullmove_number of the current root (self_play.py:104)
         return self.start_fullmove + (self.plies + (0 if self.start_white else 1)) // 2
@@ -49,12 +50,13 @@ class FinishedGame:
     slot: int
     moves: List[int]                 # from|to<<6|promo<<12
     positions: List[E.BoPosition]    # positions[i] = position before moves[i]; last = final position
-    pis: List                        # sparse pi per ply
+    pis: List                        # sparse pi of ply first_ply + i
     outcome: float                   # utils.get_game_outcome of the final board, 0.0 if not over (self_play.py:190-197)
     terminal: int                    # 0 stopped by move limit, 1 checkmate, 2 draw
+    first_ply: int = 0               # plies before it were handed to start_games(moves=...), not searched here
 
-    def z(self, i: int) -> float:    # self_play.py:202
-        return self.outcome if self.positions[i].turn == 1 else -self.outcome
+    def z(self, i: int) -> float:    # self_play.py:202, for record i (ply first_ply + i)
+        return self.outcome if self.positions[self.first_ply + i].turn == 1 else -self.outcome
 
 
 def _fen_meta(fen: Optional[str]):
@@ -69,24 +71,23 @@ def _fen_meta(fen: Optional[str]):
 class Rollout:
     def __init__(self, model: torch.nn.Module, n_games: int, *, num_simulations: int = 250, mcts_batch_size: int = 96,
                  cpuct: float = 1.0, widen_coeff: float = 1.5, dirichlet_alpha: float = 0.1,
-                 dirichlet_epsilon: float = 0.25, max_plies: int = 2048, max_game_moves: int = 16384,
+                 dirichlet_epsilon: float = 0.25, max_plies: Optional[int] = None, max_game_moves: int = 16384,
                  temperature=(30, 1.0, 0.1), device: str = "cuda:0", use_graph: bool = True, autocast: bool = False,
-                 rng_mode: str = "python", policy_kind: str = "logits", fast: bool = False, leaves_per_step: int = 16,
-                 lib=None):
-        if not str(device).startswith("cuda") and lib is None:
-            raise E.EngineError("betaone_amd.Rollout runs on an MI355X (device='cuda:N'); there is no CPU path")
-        self.device = torch.device(device)
+                 rng_mode: str = "python", policy_kind: str = "logits", fast: bool = False, leaves_per_step: int = 16):
+        self.device = E.runtime_device(device)  # 'cuda' -> cuda:<current device>: engine, NN rows and model on ONE GPU
         self.G = int(n_games)
         self.S, self.B = int(num_simulations), int(mcts_batch_size)
         self.alpha = float(dirichlet_alpha)
         self.max_game_moves = int(max_game_moves)
+        if max_plies is None:  # room for the longest game the caller allows (self_play.py:102; config.MAX_GAME_MOVES = 16384)
+            max_plies = min(self.max_game_moves, 16384) + 2
         self.temperature = temperature
         self.model = model
         self.autocast = autocast
-        dev_index = self.device.index or 0
+        dev_index = self.device.index if self.device.index is not None else 0
         self.eng = E.Engine(self.G, num_simulations=self.S, mcts_batch_size=self.B, cpuct=cpuct, widen_coeff=widen_coeff,
                             dirichlet_alpha=dirichlet_alpha, dirichlet_epsilon=dirichlet_epsilon, max_plies=max_plies,
-                            device=dev_index, lib=lib, fast=fast, leaves_per_step=leaves_per_step)
+                            device=dev_index, fast=fast, leaves_per_step=leaves_per_step)
         # fast=True: csrc/bo_fast.h (virtual loss, L leaves per game per step) -- NOT the reference's search semantics
         self.fast, self.L = bool(fast), self.eng.L
         self.nn_in = torch.zeros((self.G * self.L, E.INPUT_CHANNELS, 8, 8), dtype=torch.float32, device=self.device)
@@ -179,7 +180,7 @@ class Rollout:
             self.games[s] = GameState(game_id=int(game_ids[i]), rng=rngs[i], start_fen=fen, start_fullmove=full,
                                       start_white=white)
             if moves is not None and moves[i]:
-                self.games[s].plies = len(moves[i].split())
+                self.games[s].plies = self.games[s].first_ply = len(moves[i].split())
             self._active[s] = True
             if self._begun_want is not None:
                 self._begun_want[s] = False  # a search begun for the slot's previous occupant does not count
@@ -366,7 +367,7 @@ class Rollout:
         gs = self.games[g]
         if self.rng_mode == "native":
             gs.plies = int(self._plies[g])
-        positions, moves = self.eng.export_game(g, self._stream())
+        positions, moves = self.eng.export_game(g, self._stream(), n_plies=gs.plies)
         outcome = 1.0 if terminal == 1 else 0.0
         pis = gs.pis
         if self.rng_mode == "native":  # gather this game's sparse pis from the per-step arrays
@@ -374,17 +375,35 @@ class Rollout:
             for st in range(int(self._start_step[g]), self._step):
                 n, idx, val = self._hist[st]
                 pis.append((idx[g, :n[g]].copy(), val[g, :n[g]].copy()))
+        # one (state, pi) per move actually played (self_play.py:122,171): a start position that is already over yields
+        # none, and a move the engine refused (no room left in the slot's position stack) leaves no record either
+        pis = pis[:max(0, len(moves) - gs.first_ply)]
         return FinishedGame(game_id=gs.game_id, slot=g, moves=moves, positions=positions, pis=pis, outcome=outcome,
-                            terminal=terminal)
+                            terminal=terminal, first_ply=gs.first_ply)
 
     # ---- training records ---------------------------------------------------------------------------------
-    def encode_finished_in_slot(self, g: int, n_records: int) -> torch.Tensor:
-        """Dense (state) tensors [n,120,8,8] of the game still resident in slot g (self_play.py:200-208:
-        END-of-game tracker).  Call from `on_finished`, i.e. before the slot is refilled."""
+    def encode_finished_in_slot(self, g: int, n_records: int, first_ply: int = 0) -> torch.Tensor:
+        """Dense (state) tensors [n,120,8,8] of plies first_ply.. of the game still resident in slot g
+        (self_play.py:200-208: END-of-game tracker).  Call from `on_finished`, i.e. before the slot is refilled."""
         out = torch.empty((max(1, n_records), E.INPUT_CHANNELS, 8, 8), dtype=torch.float32, device=self.device)
         if n_records:
-            self.eng.encode_game(g, 0, n_records, out.data_ptr(), self._stream())
+            self.eng.encode_game(g, first_ply, n_records, out.data_ptr(), self._stream())
         return out[:n_records]
+
+    def retire(self, g: int, on_finished: Optional[Callable[[FinishedGame], None]] = None,
+               refill: Optional[Callable[[int], Optional[tuple]]] = None) -> None:
+        """Take the game in slot g out of play between two plies -- the reference's per-game abort paths
+        (self_play.py:119,167,180 return None; :186 move limit) -- and hand the slot to the next game.  With `on_finished`
+        the moves played so far are reported like a game stopped by the move limit; without it the game is dropped."""
+        if self.games[g] is None:
+            return
+        if on_finished is not None:
+            on_finished(self._finish(g, 0))
+        self.games[g] = None
+        self._active[g] = False
+        nxt = refill(g) if refill is not None else None
+        if nxt is not None:
+            self.start_games([g], [nxt[0]], [nxt[1]], [nxt[2]])  # its first search is begun by the next play_ply
 
     def close(self):
         self._graph = None

@@ -55,8 +55,8 @@ def build(n_trees: int, nodes: int = 800, seed: int = 0, device="cuda:0", n_max:
     return dict(blocks=blocks, root_block=root_block, root_n=root_n, sqrt_lut=lut, n_trees=n_trees, nodes=nodes)
 
 
-def run(w: dict, max_depth: int = 64, cpuct: float = 1.0, grid_blocks: int = 0, lib=None, out=None):
-    lib = lib if lib is not None else E.load_hip_library()
+def run(w: dict, max_depth: int = 64, cpuct: float = 1.0, grid_blocks: int = 0, out=None):
+    lib = E.load_hip_library()
     dev = w["blocks"].device
     if out is None:
         out = (torch.empty(w["n_trees"], dtype=torch.int32, device=dev), torch.empty(w["n_trees"], dtype=torch.int32, device=dev))

@@ -8,15 +8,19 @@ games.  Keeps the reference's contracts:
   * results go to DATA_DIR/iter_{i}/game_{j}.pkl in save_game_data's format (self_play.py:220-231), which
     train.load_recent_data reads unchanged (train.py:187-219);
   * resume = skip game ids whose file already exists (main.py:26-36 check_existing_self_play_data).
-Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N -m betaone_amd.selfplay_main ...`;
-game id j runs on rank j mod N (its RNG seed is derived from (iteration, j), so results do not depend on N).
+Multi-GPU, one command like the reference's (main.py:166-175 starts its N workers itself): `--gpus N` starts N ranks,
+one process per GPU (a `torch.distributed.run` child, started before this process touches a GPU); game id j runs on
+rank j mod N (its RNG seed is derived from (iteration, j), so results do not depend on N).  Under an external
+torchrun the RANK / LOCAL_RANK / WORLD_SIZE variables are honoured instead.
 
-    python -m betaone_amd.selfplay_main --iteration 3 --games 1000 --slots 256
+    python -m betaone_amd.selfplay_main --iteration 3 --games 1000 --slots 256 --gpus 8
 """
 from __future__ import annotations
 
 import argparse
 import os
+import subprocess
+import sys
 import time
 from typing import Callable, Dict, List, Optional
 
@@ -59,13 +63,33 @@ def run_iteration(model, iteration: int, n_games: int, n_slots: int, rank: int =
     return done
 
 
+def launch_ranks(n: int, child_args: List[str], env: Optional[dict] = None) -> int:
+    """Start `n` ranks of `python <child_args>` on this node through torch.distributed.run (one process per GPU, rendezvous on
+    127.0.0.1) as a CHILD process and return its exit code.  Call before the parent has touched a GPU."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + child_args
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e["PYTHONPATH"] = pkg_parent + (os.pathsep + e["PYTHONPATH"] if e.get("PYTHONPATH") else "")
+    return subprocess.call(cmd, env=e)
+
+
 def main(argv: Optional[List[str]] = None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--iteration", type=int, required=True)
     ap.add_argument("--games", type=int, default=None, help="games in this iteration (default config.GAMES_MINIMUM)")
     ap.add_argument("--slots", type=int, default=256, help="concurrent games per GPU")
     ap.add_argument("--model", default=None, help="state_dict file (default SAVE_DIR/best_model.pth)")
+    ap.add_argument("--gpus", type=int, default=1, help="ranks to start on this node (ignored under torchrun)")
     args = ap.parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, ["-m", "betaone_amd.selfplay_main"] + list(sys.argv[1:] if argv is None else argv)))
     import torch
 
     from betaone_amd import dropin
@@ -78,6 +102,7 @@ def main(argv: Optional[List[str]] = None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
         torch.cuda.set_device(local)
+        config.DEVICE = f"cuda:{local}"  # explicit: engine, NN rows and model of this rank on its own GPU
     model = network.PolicyValueNet().to(config.DEVICE)
     path = args.model or os.path.join(config.SAVE_DIR, "best_model.pth")
     if os.path.exists(path):

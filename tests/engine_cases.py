@@ -299,10 +299,10 @@ def check_edge_cases(backend):
     res = s.search([1], [T.softmax_eval(5)], [np.random.RandomState(0)], 0.1)
     assert int(res["total"][0]) == 100
     # unsupported configurations are refused at create time, with a message
-    lib = eng.lib
+    mk = (lambda *a, **k: __import__("engine_harness").emu_call(E.Engine, *a, **k)) if backend == "emu" else E.Engine
     for kw in (dict(widen_coeff=0.5), dict(widen_coeff=4.0, mcts_batch_size=96), dict(n_games=0)):
         with pytest_raises(E.EngineError):
-            E.Engine(kw.pop("n_games", 1), lib=lib, **kw)
+            mk(kw.pop("n_games", 1), **kw)
     with pytest_raises(E.EngineError):
         eng.reset([0], ["this is not a fen"], [None])
     with pytest_raises(E.EngineError):
@@ -310,7 +310,7 @@ def check_edge_cases(backend):
     with pytest_raises(E.EngineError):
         eng.reset([5], [None], [None])
     # a game longer than max_plies sets a status bit instead of writing out of bounds
-    small = E.Engine(1, num_simulations=8, mcts_batch_size=8, max_plies=6, lib=lib)
+    small = mk(1, num_simulations=8, mcts_batch_size=8, max_plies=6)
     small.reset([0])
     ss = Searcher(backend, small)
     for _ in range(8):

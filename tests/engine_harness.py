@@ -34,6 +34,30 @@ def emu_lib():
     return _emu
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def emulator_backend():
+    """Test infrastructure: inside this block betaone_amd.engine hands out the wave-emulator build of the device code and a
+    CPU torch device, so kernel logic runs in a GPU-less container.  The product has no such switch -- this patches the
+    two module functions from the outside and restores them."""
+    import torch
+
+    saved = (E.load_hip_library, E.runtime_device)
+    E.load_hip_library = emu_lib
+    E.runtime_device = lambda requested: torch.device("cpu")
+    try:
+        yield
+    finally:
+        E.load_hip_library, E.runtime_device = saved
+
+
+def emu_call(fn, *a, **kw):
+    with emulator_backend():
+        return fn(*a, **kw)
+
+
 class Buf:
     """float32 device buffer with a raw address."""
 
@@ -72,7 +96,7 @@ def make_engine(backend: str, n_games: int, cfg: dict, max_plies: int = 512) -> 
               dirichlet_alpha=cfg.get("dirichlet_alpha", 0.1), dirichlet_epsilon=cfg.get("dirichlet_eps", 0.25),
               max_plies=max_plies)
     if backend == "emu":
-        return E.Engine(n_games, lib=emu_lib(), **kw)
+        return emu_call(E.Engine, n_games, **kw)
     return E.Engine(n_games, **kw)
 
 

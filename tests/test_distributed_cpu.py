@@ -27,7 +27,7 @@ def _worker(rank, world, port, out_dir, lagged=False):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from betaone_amd import records
     from betaone_amd.rollout import Rollout
-    from engine_harness import emu_lib
+    from engine_harness import emu_call
     from fake_model import FakeNet
 
     class Net(torch.nn.Module):
@@ -37,8 +37,8 @@ def _worker(rank, world, port, out_dir, lagged=False):
     n_total = 6
     ids = records.shard_game_ids(n_total, rank, world)           # game id -> rank = id mod world
     assert ids == list(range(rank, n_total, world))
-    ro = Rollout(Net(), len(ids), num_simulations=30, mcts_batch_size=16, max_game_moves=3 + rank, device="cpu",
-                 use_graph=False, lib=emu_lib())
+    ro = emu_call(Rollout, Net(), len(ids), num_simulations=30, mcts_batch_size=16, max_game_moves=3 + rank, device="cpu",
+                  use_graph=False)
     ro.start_games(list(range(len(ids))), ids, [np.random.RandomState(i) for i in ids])
     fins = []
     gathered = []
@@ -79,7 +79,7 @@ def test_results_do_not_depend_on_the_sharding():
     """game id + seed travel together: the same game on a different rank/slot count gives the same record."""
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     from betaone_amd.rollout import Rollout
-    from engine_harness import emu_lib
+    from engine_harness import emu_call
     from fake_model import FakeNet
 
     class Net(torch.nn.Module):
@@ -87,8 +87,8 @@ def test_results_do_not_depend_on_the_sharding():
             return FakeNet(scale=0.0, salt=21)(x)
 
     def play(ids):
-        ro = Rollout(Net(), len(ids), num_simulations=30, mcts_batch_size=16, max_game_moves=4, device="cpu",
-                     use_graph=False, lib=emu_lib())
+        ro = emu_call(Rollout, Net(), len(ids), num_simulations=30, mcts_batch_size=16, max_game_moves=4, device="cpu",
+                      use_graph=False)
         ro.start_games(list(range(len(ids))), ids, [np.random.RandomState(i) for i in ids])
         fins = []
         while any(g is not None for g in ro.games):

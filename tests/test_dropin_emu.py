@@ -24,19 +24,23 @@ import self_play  # noqa: E402
 import utils  # noqa: E402
 
 import golden_util as G  # noqa: E402
-from engine_harness import emu_lib  # noqa: E402
+from engine_harness import emulator_backend  # noqa: E402
 from fake_model import FakeNet, fake_logits_values, hash_init_  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 
 @pytest.fixture(autouse=True)
-def _emu_backend():
-    saved = {k: getattr(config, k) for k in ("NUM_SIMULATIONS", "MCTS_BATCH_SIZE", "MAX_GAME_MOVES", "DIRICHLET_ALPHA")}
-    mcts._set_test_backend(emu_lib(), "cpu")
-    self_play._set_test_backend(emu_lib(), "cpu")
-    yield
-    mcts._set_test_backend(None)
-    self_play._set_test_backend(None)
+def _emu_backend(request):
+    """Every test of this file drives the drop-in modules on the wave-emulator build of the device code (patched in from
+    the outside, see engine_harness.emulator_backend) -- except those marked `product_backend`."""
+    saved = {k: getattr(config, k) for k in ("NUM_SIMULATIONS", "MCTS_BATCH_SIZE", "MAX_GAME_MOVES", "DIRICHLET_ALPHA", "DATA_DIR")}
+    mcts._ctx.clear()
+    if request.node.get_closest_marker("product_backend"):
+        yield
+    else:
+        with emulator_backend():
+            yield
+    mcts._ctx.clear()
     for k, v in saved.items():
         setattr(config, k, v)
 
@@ -190,11 +194,10 @@ def test_network_matches_reference_outputs(name):
         config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = saved
 
 
+@pytest.mark.product_backend
 def test_product_paths_refuse_to_run_without_the_gpu():
     from betaone_amd import engine as E
 
-    mcts._set_test_backend(None)
-    self_play._set_test_backend(None)
     if not torch.cuda.is_available():
         board, history, tracker = context(chess.STARTING_FEN, [])
         with pytest.raises(E.EngineError):
@@ -231,3 +234,50 @@ def test_selfplay_orchestration_writes_reference_pickles_and_resumes(tmp_path):
     a = pickle.load(open(tmp_path / "data" / "iter_7" / "game_1.pkl", "rb"))
     b = pickle.load(open(tmp_path / "data2" / "iter_7" / "game_1.pkl", "rb"))
     assert all(torch.equal(x[0], y[0]) and np.array_equal(x[1], y[1]) for x, y in zip(a, b))
+
+
+def test_one_overlong_game_does_not_end_the_others():
+    """config.ENGINE_MAX_PLIES smaller than the games: a slot whose position stack is full stops THAT game like the
+    reference's move limit (self_play.py:186: records of the moves played are kept) and every other game -- running or
+    still queued -- is played to its own end (the reference plays one game per call, so games cannot affect each other)."""
+    config.NUM_SIMULATIONS, config.MCTS_BATCH_SIZE, config.MAX_GAME_MOVES = 24, 8, 6
+    model = FakeNet(scale=0.0, salt=13)
+    full = self_play.run_self_play_games(model, [0, 1, 2, 3, 4], seeds=[20, 21, 22, 23, 24], n_slots=2)
+    assert all(len(full[g]) == 6 for g in range(5))
+    # game 1 starts from a 3-move prefix-free FEN deep into a game; capacity 5 positions = at most 3 moves per slot
+    config.ENGINE_MAX_PLIES = 5
+    try:
+        cut = self_play.run_self_play_games(model, [0, 1, 2, 3, 4], seeds=[20, 21, 22, 23, 24], n_slots=2)
+    finally:
+        config.ENGINE_MAX_PLIES = None
+    assert sorted(cut) == [0, 1, 2, 3, 4]
+    for g in range(5):  # every game reported, each with the records of the moves that fitted, equal to the full run's prefix
+        assert cut[g] is not None and 1 <= len(cut[g]) < 6
+        for (s1, p1, _z1), (s2, p2, _z2) in zip(cut[g], full[g]):
+            assert np.array_equal(p1, p2)
+            assert torch.equal(s1[98:112], s2[98:112])   # the current-position block; repetition planes of older blocks use the end-of-game tracker
+
+
+def test_game_from_a_finished_position_yields_no_examples():
+    """A start position that is already over: the reference's loop body never runs and the game returns zero examples
+    (self_play.py:101,200-216); the batched native-RNG path must not attach a stale pi of the slot's previous occupant."""
+    config.NUM_SIMULATIONS, config.MCTS_BATCH_SIZE, config.MAX_GAME_MOVES = 24, 8, 3
+    model = FakeNet(scale=0.0, salt=17)
+    mate = "k6R/8/1K6/8/8/8/8/8 b - - 1 1"
+    out = self_play.run_self_play_games(model, [0, 1, 2], seeds=[1, 2, 3], n_slots=1, start_fens=[None, mate, None])
+    assert len(out[0]) == 3 and len(out[2]) == 3
+    assert out[1] == []
+
+
+@pytest.mark.product_backend
+def test_device_string_without_index_resolves_to_the_current_device(monkeypatch):
+    """Every rank of a torchrun job passes config.DEVICE == 'cuda' after torch.cuda.set_device(LOCAL_RANK): the engine,
+    its NN rows and the model must all land on THAT GPU (not on GPU 0)."""
+    from betaone_amd import engine as E
+
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 3)
+    assert E.runtime_device("cuda") == torch.device("cuda", 3)
+    assert E.runtime_device(torch.device("cuda")) == torch.device("cuda", 3)
+    assert E.runtime_device("cuda:1") == torch.device("cuda", 1)
+    with pytest.raises(E.EngineError):
+        E.runtime_device("cpu")

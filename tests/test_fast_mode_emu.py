@@ -5,7 +5,7 @@ import pytest
 
 import engine_cases as EC
 from betaone_amd import engine as E
-from engine_harness import Buf, emu_lib
+from engine_harness import Buf, emu_call
 from fake_model import fake_logits_values
 from fast_reference import fast_search
 from oracle import oracle as O
@@ -22,7 +22,7 @@ def softmax_eval(salt, scale=6.0):
 
 def run_engine_search(backend, fen, moves, sims, L, eval_fn, seed, alpha=0.1, G=1):
     kw = dict(num_simulations=sims, dirichlet_alpha=alpha, fast=True, leaves_per_step=L, max_plies=256)
-    eng = E.Engine(G, lib=emu_lib(), **kw) if backend == "emu" else E.Engine(G, **kw)
+    eng = emu_call(E.Engine, G, **kw) if backend == "emu" else E.Engine(G, **kw)
     eng.reset(list(range(G)), [fen] * G, [" ".join(moves) or None] * G)
     nl, term, _ = eng.root_info()
     rngs = [np.random.RandomState(seed + g) for g in range(G)]

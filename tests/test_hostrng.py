@@ -4,12 +4,12 @@ import numpy as np
 import pytest
 
 from betaone_amd import engine as E, sampling
-from engine_harness import emu_lib
+from engine_harness import emu_call
 
 
 @pytest.fixture(scope="module")
 def eng():
-    return E.Engine(4, num_simulations=10, lib=emu_lib())
+    return emu_call(E.Engine, 4, num_simulations=10)
 
 
 @pytest.mark.parametrize("seed", [0, 1, 7, 12345, 2**31 + 5, 2**32 - 1])
@@ -61,7 +61,7 @@ def test_sampling_matches_numpy_draw_for_draw(eng):
 def test_dirichlet_matches_numpy(eng, alpha):
     """bo_selfplay_begin draws the root noise natively: compare the stream position afterwards and the noise via
     a search's visible effect is covered elsewhere; here: state equality after the same number of draws."""
-    e = E.Engine(3, num_simulations=10, dirichlet_alpha=alpha, lib=emu_lib())
+    e = emu_call(E.Engine, 3, num_simulations=10, dirichlet_alpha=alpha)
     e.reset([0, 1, 2], [None, "r3k2r/p1ppqpb1/bn2pnp1/3PN3/1p2P3/2N2Q1p/PPPBBPPP/R3K2R w KQkq - 0 1", None])
     nn_in = np.zeros((3, 120, 8, 8), dtype=np.float32)
     for g, seed in enumerate([5, 6, 7]):
@@ -94,8 +94,8 @@ def test_native_rollout_equals_python_rollout_and_oracle():
     seeds = [3, 4, 5, 6]
 
     def play(mode):
-        ro = Rollout(Net(), 4, num_simulations=40, mcts_batch_size=16, max_game_moves=7, device="cpu", use_graph=False,
-                     rng_mode=mode, lib=emu_lib())
+        ro = emu_call(Rollout, Net(), 4, num_simulations=40, mcts_batch_size=16, max_game_moves=7, device="cpu", use_graph=False,
+                      rng_mode=mode)
         rngs = seeds if mode == "native" else [np.random.RandomState(s) for s in seeds]
         ro.start_games([0, 1, 2, 3], [0, 1, 2, 3], rngs, fens)
         fins = {}
@@ -136,8 +136,8 @@ def test_native_rollout_with_slot_recycling_equals_python_rollout():
     start = ["k7/8/1K6/8/8/8/8/7R w - - 96 60", None, "6k1/5ppp/8/8/8/8/5PPP/3R2K1 w - - 0 30"]
 
     def play(mode):
-        ro = Rollout(Net(), 3, num_simulations=24, mcts_batch_size=8, max_game_moves=5, device="cpu", use_graph=False,
-                     rng_mode=mode, lib=emu_lib())
+        ro = emu_call(Rollout, Net(), 3, num_simulations=24, mcts_batch_size=8, max_game_moves=5, device="cpu", use_graph=False,
+                      rng_mode=mode)
         mk = (lambda s: s) if mode == "native" else (lambda s: np.random.RandomState(s))
         ro.start_games([0, 1, 2], [0, 1, 2], [mk(10), mk(11), mk(12)], start)
         nxt, fins = [3], {}

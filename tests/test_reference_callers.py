@@ -22,8 +22,8 @@ import config
 config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 1, 1, 32
 config.NUM_SIMULATIONS = 120
 import network, mcts
-from engine_harness import emu_lib
-mcts._set_test_backend(emu_lib(), "cpu")        # no GPU here: the emulator build of the same device code
+from engine_harness import emulator_backend
+_emu = emulator_backend(); _emu.__enter__()      # no GPU here: the emulator build of the same device code, for this whole process
 os.makedirs("checkpoints", exist_ok=True)
 torch.manual_seed(0)
 torch.save(network.PolicyValueNet().state_dict(), os.path.join("checkpoints", "stable_model(half).pth"))
