@@ -13,12 +13,20 @@ Workload at N=1: 256 concurrent games x 800 sims/move, MCTS_BATCH_SIZE 96, net 8
 "step" = one ply of every game (256 searches of 800 simulations + the moves).  Weak scaling: every rank
 runs its own 256 games (game id -> rank by id mod world); the only collective is the record all-gather.
 
+The timed region is STEADY-STATE self-play: before it, `--preroll` plies are played (untimed, staggered slot starts, same
+engine, same settings) so that the resident games are at every stage of a game, finished games leave and new ones start
+in every step, and games/hour is measured, not extrapolated.  The opening-only figure (all games at the start position) is
+reported as the labelled extra `opening_phase`.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (a torch.distributed.run child
+process, started before this process touches a GPU) and relays rank 0's JSON line.
+
 Also measured live, per the contract:
   roofline      PUCT-select kernel on the wide synthetic workload of SURVEY.md section 8d (HIP events on the
                 kernel's stream; algorithmic bytes = measured levels x 392 B)
   roofline_step the in-loop tree-step kernel (latency-bound, cache-resident; reported for honesty)
-  cpu_baseline  the CPU oracle (oracle/, a C port of the reference) + the same net under torch-CPU,
-                timed on this box's host cores on a bounded sample
+  cpu_baseline  the CPU oracle (oracle/, a C port of the reference) + the same net under torch-CPU: one game per core on
+                the box's host cores (the reference's mp.Pool, main.py:168), bounded sample; per-core and x cores
 """
 from __future__ import annotations
 
@@ -53,6 +61,12 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-cores", type=int, default=0, help="0 = the box's CPU share (affinity mask, at most 16)")
+    ap.add_argument("--preroll", type=int, default=640, help="untimed plies played before warm-up to reach steady state (0 = opening phase)")
+    ap.add_argument("--opening-steps", type=int, default=20, help="plies of the labelled opening-only extra measurement (0 = skip)")
+    ap.add_argument("--softmax", default="torch", choices=["torch", "engine"], help="policy softmax: torch.softmax in the graph (the reference's op) or the step kernel's own")
+    ap.add_argument("--exchange-every", type=int, default=16, help="N>1: plies per record-exchange period")
+    ap.add_argument("--dump-games", default="", help="write the move lists of finished games to this JSON file")
     ap.add_argument("--wide-trees", type=int, default=0, help="0 = 262144 if >= 150 GB of HBM is free, else 131072")
     ap.add_argument("--wide-nodes", type=int, default=800)
     ap.add_argument("--fast", action="store_true", help="FAST search mode (virtual loss; not the reference's semantics; not the headline)")
@@ -177,43 +191,132 @@ def step_roofline(ro, n_steps_timed):
             "evals": int(st["evals"].sum()), "flushes": int(st["flushes"].sum())}
 
 
-def cpu_baseline(args):
-    """The reference's algorithm on the host CPU: oracle/ (C port of mcts.py/self_play.py + python-chess
-    rules) with the same net under torch-CPU fp32."""
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def _cpu_worker(job):
+    """One host core = one self-play game at a time, like one worker of the reference's mp.Pool (main.py:39-65, :168):
+    the CPU oracle (C port of mcts.py / self_play.py + python-chess rules) with the same net under torch-CPU, 1 thread."""
+    net_name, sims, batch, seconds, worker, threads = job
+    torch.set_num_threads(threads)
     from oracle import oracle as O
 
-    net, _ = make_net(args.net, "cpu", "fp32")
-    threads = max(1, min(os.cpu_count() or 1, 16))
-    torch.set_num_threads(threads)
+    net, _ = make_net(net_name, "cpu", "fp32")
 
     def eval_fn(planes):
         with torch.no_grad():
             logits, value = net(torch.from_numpy(np.ascontiguousarray(planes)))
             return torch.softmax(logits, dim=1).numpy(), value.reshape(-1).numpy()
 
-    cfg = O.default_config(num_simulations=args.sims, batch_size=args.batch)
-    t0, sims, plies, games, evals = time.perf_counter(), 0, 0, 0, 0
-    while time.perf_counter() - t0 < args.cpu_seconds:
-        g = O.self_play(eval_fn, np.random.RandomState(games), cfg, max_plies=6)
-        sims += g["n_sims"]; plies += len(g["moves"]); evals += g["n_evals"]; games += 1
-    dt = time.perf_counter() - t0
-    cpu_model = "unknown CPU"
-    try:
-        for ln in open("/proc/cpuinfo"):
-            if ln.startswith("model name"):
-                cpu_model = ln.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    return {"value": round(sims / dt, 1), "unit": "nodes/s", "cores": threads, "kind": "port", "cpu": cpu_model,
-            "sample": f"{games} game prefixes x 6 plies ({plies} searches of {args.sims} sims, {evals} unique NN evals) "
-                      f"in {dt:.1f} s; oracle/ C port single-threaded, net {args.net} fp32 under torch-CPU with {threads} threads; "
-                      f"the port evaluates each unique leaf once (the Python reference evaluates up to 96 duplicate rows per batch)"}
+    cfg = O.default_config(num_simulations=sims, batch_size=batch)
+    O.self_play(eval_fn, np.random.RandomState(10_000 + worker), cfg, max_plies=1)  # warm-up (first torch call, oracle load)
+    t0, n_sims, plies, games, evals = time.perf_counter(), 0, 0, 0, 0
+    while time.perf_counter() - t0 < seconds:
+        g = O.self_play(eval_fn, np.random.RandomState(1000 * worker + games), cfg, max_plies=6)
+        n_sims += g["n_sims"]; plies += len(g["moves"]); evals += g["n_evals"]; games += 1
+    return n_sims, plies, evals, games, time.perf_counter() - t0
+
+
+def cpu_baseline(args):
+    """The reference's algorithm on the host CPU, shaped like the reference's own parallelism: one
+    game per core x cores, plus the single-game figure with the net on all those threads."""
+    import multiprocessing as mp
+
+    cores = args.cpu_cores or max(1, min(len(os.sched_getaffinity(0)), 16))
+    os.environ["BETAONE_DEVICE"] = "cpu"  # the helper processes never open the GPU (config.py would probe it at import)
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(args.net, args.sims, args.batch, args.cpu_seconds, w, 1) for w in range(cores)])
+    del os.environ["BETAONE_DEVICE"]
+    rates = [r[0] / r[4] for r in res]
+    total = float(sum(rates))
+    sims, plies, evals, games = (sum(r[k] for r in res) for k in range(4))
+    one = _cpu_worker((args.net, args.sims, args.batch, min(8.0, args.cpu_seconds), 999, cores))
+    return {"value": round(total, 1), "unit": "nodes/s", "cores": cores, "kind": "port", "cpu": _cpu_model(),
+            "per_core": round(total / cores, 1), "per_core_min_max": [round(min(rates), 1), round(max(rates), 1)],
+            "single_game_all_threads": round(one[0] / one[4], 1),
+            "sample": f"{cores} processes x 1 thread, one game at a time each (the reference's mp.Pool shape, main.py:168), {args.cpu_seconds:.0f} s: "
+                      f"{games} game prefixes x 6 plies ({plies} searches of {args.sims} sims, {evals} unique NN evals); oracle/ C port + "
+                      f"net {args.net} fp32 under torch-CPU; the port evaluates each unique leaf once (the Python reference evaluates up to 96 "
+                      f"duplicate rows per batch and runs the rules in Python); single_game_all_threads = 1 game, net on {cores} threads"}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1, not under torchrun): start the N ranks as a child torch.distributed.run job -- before
+    this process has touched a GPU -- and exit with its code; rank 0 of the child prints the JSON line."""
+    from betaone_amd.selfplay_main import launch_ranks
+
+    sys.stdout.flush()
+    return launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:])
+
+
+class Driver:
+    """The step loop around one Rollout: finished games are counted (and handed to the exchange), their slots refilled."""
+
+    def __init__(self, ro, rank, world, exchange, dump=None):
+        self.ro, self.rank, self.world, self.exchange, self.dump = ro, rank, world, exchange, dump
+        self.next_id = rank
+        self.batch, self.n_finished, self.plies_finished, self.lengths = [], 0, 0, []
+        self.n_received = 0
+
+    def new_id(self):
+        i = self.next_id
+        self.next_id += self.world
+        return i
+
+    def on_finished(self, fin):
+        self.batch.append(fin)
+        self.n_finished += 1
+        self.plies_finished += len(fin.moves)
+        self.lengths.append(len(fin.moves))
+        if self.dump is not None:
+            self.dump.append({"game_id": fin.game_id, "terminal": fin.terminal, "moves": [int(m) for m in fin.moves]})
+
+    def refill(self, _slot):
+        i = self.new_id()
+        return i, i, None  # game id -> rank = id mod world; RandomState(seed = game id) stream
+
+    def step(self):
+        self.ro.play_ply(on_finished=self.on_finished, refill=self.refill)
+        if self.exchange is not None:  # the path's only exchange step: finished games' records to every rank (RCCL over xGMI),
+            self.n_received += len(self.exchange.push(self.batch))  # pipelined: nothing here waits for a collective
+        self.batch.clear()
+
+    def preroll(self, plies, G):
+        """Untimed: bring the resident games to every stage of a game.  Slot s enters play at step s * (plies / 2) / G, so after
+        `plies` steps every slot has been playing for at least plies / 2 steps and the starts are spread evenly."""
+        ro, window = self.ro, max(1, plies // 2)
+        started = 0
+        for k in range(plies):
+            upto = G if plies < 2 else min(G, (k + 1) * G // window + 1)
+            if upto > started:
+                slots = list(range(started, upto))
+                ids = [self.new_id() for _ in slots]
+                ro.start_games(slots, ids, ids)
+                started = upto
+            self.step()
+        if started < G:
+            slots = list(range(started, G))
+            ids = [self.new_id() for _ in slots]
+            ro.start_games(slots, ids, ids)
 
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        sys.exit(self_launch(args))
+    world = int(env_world or "1")
+    if world != args.gpus and not args.force_dist:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -241,84 +344,105 @@ def main():
         net = CastIn(net, {"fp16": torch.float16, "bf16": torch.bfloat16}[args.net_dtype])
     G = args.games
     ro = Rollout(net, G, num_simulations=args.sims, mcts_batch_size=args.batch, device=str(device), use_graph=not args.no_graph,
-                 rng_mode="native", max_game_moves=args.max_game_moves, fast=args.fast, leaves_per_step=args.leaves)
-    ids = [rank + world * s for s in range(G)]  # game id -> rank = id mod world; RandomState(seed = game id) streams
-    ro.start_games(list(range(G)), ids, ids)
-    next_id = [rank + world * G]
-    finished_batch, n_finished, finished_timed, plies_finished, timing = [], [0], [0], [0], [False]
+                 rng_mode="native", max_game_moves=args.max_game_moves, fast=args.fast, leaves_per_step=args.leaves,
+                 policy_kind="probs" if args.softmax == "torch" else "logits")
+    exchange = records.PeriodicGameExchange(device, every=args.exchange_every) if dist is not None else None
+    dump = [] if args.dump_games else None
+    drv = Driver(ro, rank, world, exchange, dump)
 
-    def on_finished(fin):
-        finished_batch.append(fin)
-        n_finished[0] += 1
-        if timing[0]:
-            finished_timed[0] += 1
-            plies_finished[0] += len(fin.moves)
-
-    def refill(_slot):
-        i = next_id[0]
-        next_id[0] += world
-        return i, i, None
-
-    exchange = records.LaggedGameExchange(device) if dist is not None else None
-
-    def one_step():
-        ro.play_ply(on_finished=on_finished, refill=refill)
-        if exchange is not None:  # the path's only exchange step: finished games' records to every rank (RCCL over xGMI);
-            exchange.push(finished_batch)  # the size all-gather completes while the next ply runs
-        finished_batch.clear()
-
+    t_pre = time.perf_counter()
+    if args.preroll > 0:
+        drv.preroll(args.preroll, G)
+    else:
+        ids = [drv.new_id() for _ in range(G)]
+        ro.start_games(list(range(G)), ids, ids)
     for _ in range(args.warmup):
-        one_step()
+        drv.step()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(device)
-    s0, p0, f0, h0 = ro.n_sims, ro.n_plies, ro.n_forward, ro.host_seconds
-    timing[0] = True
+    t_pre = time.perf_counter() - t_pre
+    fin_pre = drv.n_finished
+    s0, p0, f0, h0, n0, pf0 = ro.n_sims, ro.n_plies, ro.n_forward, ro.host_seconds, drv.n_finished, drv.plies_finished
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        one_step()
+        drv.step()
     if exchange is not None:
-        exchange.flush()  # the last step's records are delivered inside the timed region
+        drv.n_received += len(exchange.flush())  # every record is delivered inside the timed region
     torch.cuda.synchronize(device)
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    mine = [ro.n_sims - s0, ro.n_plies - p0, ro.n_forward - f0, drv.n_finished - n0, drv.plies_finished - pf0,
+            drv.n_finished, drv.plies_finished]
     if dist is not None:
         rdev = device if args.dist_backend == "nccl" else torch.device("cpu")
         t = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tot = torch.tensor([ro.n_sims - s0, ro.n_plies - p0, ro.n_forward - f0], dtype=torch.float64, device=rdev)
+        tot = torch.tensor(mine, dtype=torch.float64, device=rdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        sims, plies, fwd = [float(x) for x in tot.tolist()]
-    else:
-        sims, plies, fwd = float(ro.n_sims - s0), float(ro.n_plies - p0), float(ro.n_forward - f0)
+        mine = tot.tolist()
+    sims, plies, fwd, fin_timed, fin_plies_timed, fin_all, fin_plies_all = [float(x) for x in mine]
     ro.eng.check_status()
+    host_frac = (ro.host_seconds - h0) / dt
+
+    opening = None
+    if rank == 0 and args.opening_steps > 0 and args.preroll > 0 and dist is None:
+        # labelled extra: every game at the start position (what round 1 reported as the headline)
+        ids = [drv.new_id() for _ in range(G)]
+        ro.start_games(list(range(G)), ids, ids)
+        for _ in range(3):
+            drv.step()
+        torch.cuda.synchronize(device)
+        so, po = ro.n_sims, ro.n_plies
+        to = time.perf_counter()
+        for _ in range(args.opening_steps):
+            drv.step()
+        torch.cuda.synchronize(device)
+        do = time.perf_counter() - to
+        opening = {"nodes_per_sec": round((ro.n_sims - so) / do, 1), "ms_per_step": round(do / args.opening_steps * 1e3, 3),
+                   "steps": args.opening_steps, "note": "all games within their first ~25 plies; not the headline"}
 
     out = None
     if rank == 0:
+        mean_len = fin_plies_all / fin_all if fin_all else None
+        cfg_name = ("BASELINE.json configs[4] per-GPU shard (f16 net, f32 tree)" if (args.net, args.net_dtype, G, args.sims) == ("20x256", "fp16", 512, 800)
+                    else "BASELINE.json configs[1]" if (args.net, args.net_dtype, G, args.sims) == ("10x128", "fp32", 256, 400)
+                    else "BASELINE.json configs[2] per-GPU shard" if (args.net, args.net_dtype, G, args.sims) == ("10x128", "fp32", 256, 800)
+                    else "custom configuration")
         out = {
             "metric": "mcts_nodes_per_sec", "value": round(sims / dt, 1), "unit": "nodes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "fp16": "f16", "bf16": "bf16"}[args.net_dtype], "data": "synthetic",
             "config": {"workload": f"{G} concurrent self-play games per GPU x {args.sims} sims/move, MCTS_BATCH_SIZE {args.batch}, "
                                    f"net {args.net} ({'+'.join(map(str, NETS[args.net][:2]))} blocks x {NETS[args.net][2]} filters, "
-                                   f"random init, {args.net_dtype}, BN folded), start position, per-game seeds = game id; "
-                                   + ("BASELINE.json configs[4] per-GPU shard (f16 net, f32 tree)" if (args.net, args.net_dtype, G) == ("20x256", "fp16", 512)
-                                      else "BASELINE.json configs[1]" if (args.net, args.net_dtype, G, args.sims) == ("10x128", "fp32", 256, 400)
-                                      else "BASELINE.json configs[2] per-GPU shard" if (args.net, args.net_dtype, G, args.sims) == ("10x128", "fp32", 256, 800)
-                                      else "custom configuration"),
+                                   f"random init, {args.net_dtype}, BN folded), games from the start position, per-game seeds = game id, "
+                                   + (f"steady state (games at every stage after {args.preroll} untimed pre-roll plies with staggered starts; finished games are "
+                                      f"exported and their slots refilled inside the timed region); " if args.preroll > 0 else "opening phase (all games start together); ")
+                                   + cfg_name,
                        "games_per_gpu": G, "sims_per_move": args.sims, "net": args.net, "net_dtype": args.net_dtype,
-                       "hipgraph": not args.no_graph, "net_layout": net_layout,
+                       "hipgraph": not args.no_graph, "net_layout": net_layout, "policy_softmax": args.softmax, "preroll_plies": args.preroll,
                        "search_mode": ("fast: virtual loss, %d leaves/step, full-width expansion (NOT the reference's semantics)" % args.leaves)
-                                      if args.fast else "reference semantics (bit-exact)", "parallelism": f"games sharded over {world} GPU(s), record all-gather only"},
+                                      if args.fast else "reference semantics (bit-exact)",
+                       "parallelism": f"games sharded over {world} GPU(s) by id; record all-gather every {args.exchange_every} plies, pipelined" if world > 1
+                                      else "1 GPU"},
             "plies_per_sec": round(plies / dt, 2), "nn_forwards_per_sec": round(fwd / dt / world, 2),
-            "unique_nn_evals_per_sec": round(fwd * G * (args.leaves if args.fast else 1) / dt, 1), "games_finished": n_finished[0],
-            "games_per_hour_at_100_plies": round(plies / dt * 3600 / 100.0, 1),
-            "games_per_hour_measured": (round(finished_timed[0] * world * 3600.0 / dt, 1) if finished_timed[0] else None),
-            "mean_plies_of_finished_games": (round(plies_finished[0] / finished_timed[0], 1) if finished_timed[0] else None),
-            "host_fraction": round((ro.host_seconds - h0) / dt, 4),
+            "unique_nn_evals_per_sec": round(fwd * G * (args.leaves if args.fast else 1) / dt, 1),
+            "games_finished_in_timed_region": int(fin_timed),
+            "games_per_hour_measured": (round(fin_timed * 3600.0 / dt, 1) if fin_timed else None),
+            "mean_plies_of_finished_games": (round(fin_plies_timed / fin_timed, 1) if fin_timed else None),
+            "games_finished_since_start": int(fin_all),
+            "mean_plies_of_all_finished_games": (round(mean_len, 1) if mean_len else None),
+            "games_per_hour_from_ply_rate": (round(plies / dt * 3600.0 / mean_len, 1) if mean_len else None),
+            "untimed_setup_seconds": round(t_pre, 2),
+            "host_fraction": round(host_frac, 4),
         }
+        if opening:
+            out["opening_phase"] = opening
+        if exchange is not None:
+            out["record_exchange"] = {"size_gathers": exchange.n_size_gathers, "payload_gathers": exchange.n_payload_gathers,
+                                      "ticks_that_blocked": exchange.blocked_ticks, "records_received_rank0": drv.n_received}
     if rank == 0 and not args.no_roofline:
         sr = step_roofline(ro, args.steps)
         out["roofline_step"] = {"bound": "latency", "note": "parity-mode trees are cache-resident (a few KB per game)",
@@ -326,6 +450,9 @@ def main():
     ro.close()
     del ro
     torch.cuda.empty_cache()
+    if dump is not None:
+        with open(args.dump_games if world == 1 else f"{args.dump_games}.rank{rank}", "w") as f:
+            json.dump(dump, f)
     if rank == 0 and not args.no_roofline:
         out["roofline"] = select_roofline(args, device)
         if not args.fast and args.net_dtype == "fp32":

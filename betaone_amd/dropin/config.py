@@ -3,13 +3,18 @@ config -- the module-level constants of /root/reference/config.py, same names an
 time by the rollout path (so `config.NUM_SIMULATIONS = 800` before a call works exactly as in the reference).
 Constants are grouped in tables and published as module attributes.
 """
+import os
+
 import torch
 
-_HAS_GPU = torch.cuda.is_available()
+# reference config.py:9 probes torch.cuda.is_available() at import; BETAONE_DEVICE (e.g. "cpu" for host-side helper
+# processes that must not open the GPU, or "cuda:3") states the device without probing
+_DEVICE_ENV = os.environ.get("BETAONE_DEVICE", "")
+_HAS_GPU = _DEVICE_ENV.startswith("cuda") if _DEVICE_ENV else torch.cuda.is_available()
 
 _TABLES = {
     # reference config.py:9-10
-    "hardware": dict(DEVICE="cuda" if _HAS_GPU else "cpu", USE_AMP=_HAS_GPU),
+    "hardware": dict(DEVICE=_DEVICE_ENV or ("cuda" if _HAS_GPU else "cpu"), USE_AMP=_HAS_GPU),
     # config.py:13-29 -- 8 history blocks x (12 piece + 2 repetition planes) + 8 scalar planes; 8x8x73 move planes
     "encoding": dict(BOARD_SIZE=8, INPUT_CHANNELS=8 * 14 + 8, NUM_ACTIONS=64 * 73),
     # config.py:32-41
@@ -32,7 +37,10 @@ _TABLES = {
     #                 FAST_LEAVES leaves per game per step, full-width expansion: a conventional AlphaZero search)
     #   ENGINE_MAX_PLIES  capacity of one game's position stack on the GPU; None = MAX_GAME_MOVES + 2 in self-play
     #                 (2.7 MB per slot at 16384; a smaller value stops longer games like the move limit does)
-    "engine": dict(AUTOCAST=False, SEARCH_MODE="reference", FAST_LEAVES=16, ENGINE_MAX_PLIES=None),
+    #   POLICY_SOFTMAX  "torch" = torch.softmax(logits, dim=1) exactly where the reference calls it (mcts.py:185,287), inside
+    #                 the captured graph; the engine gathers probabilities (the seam the parity tests record).
+    #                 "engine" = the step kernel's own softmax over the logits row (hardware exp; within 1e-5 relative)
+    "engine": dict(AUTOCAST=False, SEARCH_MODE="reference", FAST_LEAVES=16, ENGINE_MAX_PLIES=None, POLICY_SOFTMAX="torch"),
 }
 for _group in _TABLES.values():
     globals().update(_group)

@@ -92,14 +92,22 @@ def _make_move(board, m: int):
     return cls(f, t, promotion=promo or None)
 
 
+def _policy_kind() -> int:
+    return E.POLICY_PROBS if config.POLICY_SOFTMAX == "torch" else E.POLICY_LOGITS
+
+
 def _evaluate(model, nn_in):
+    """-> (policy, value): the policy is softmax probabilities (mcts.py:185,287) or raw logits, see config.POLICY_SOFTMAX."""
     with torch.no_grad():
         if config.AUTOCAST:
             with torch.autocast(nn_in.device.type):
                 logits, value = model(nn_in)
         else:
             logits, value = model(nn_in)
-    return logits.float().contiguous(), value.float().contiguous()
+        logits = logits.float()
+        if _policy_kind() == E.POLICY_PROBS:
+            logits = torch.softmax(logits, dim=1)
+    return logits.contiguous(), value.float().contiguous()
 
 
 class _GraphStep:
@@ -107,7 +115,7 @@ class _GraphStep:
     uci.py calls run_mcts back to back on one position (uci.py:72-93), 1 + ceil(sims/96) batch-1 evaluations each."""
 
     def __init__(self, model, eng, nn_in):
-        self.model, self.eng, self.nn_in = model, eng, nn_in
+        self.model, self.eng, self.nn_in, self.kind = model, eng, nn_in, _policy_kind()
         dev = nn_in.device
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -119,7 +127,7 @@ class _GraphStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = _evaluate(model, nn_in)
-            eng.step(self.out[0].data_ptr(), self.out[1].data_ptr(), E.POLICY_LOGITS, nn_in.data_ptr(),
+            eng.step(self.out[0].data_ptr(), self.out[1].data_ptr(), self.kind, nn_in.data_ptr(),
                      torch.cuda.current_stream(dev).cuda_stream)
 
     def __call__(self):
@@ -133,7 +141,7 @@ def _fast_path(model, eng, nn_in):
         return None
     ver = tuple(p._version for p in model.parameters())
     hit = _fast.get(id(model))
-    if hit is None or hit[0] != ver or hit[2].eng is not eng:
+    if hit is None or hit[0] != ver or hit[2].eng is not eng or hit[2].kind != _policy_kind():
         from betaone_amd.nn_tune import best_inference_copy
 
         net = best_inference_copy(model, 1, nn_in.device, next(model.parameters()).dtype)
@@ -173,7 +181,7 @@ def run_mcts(root_board, model, history: List, tracker) -> Tuple[object, np.ndar
                 graph_step()
             else:
                 keep = _evaluate(model, nn_in)
-                eng.step(keep[0].data_ptr(), keep[1].data_ptr(), E.POLICY_LOGITS, nn_in.data_ptr(), stream)
+                eng.step(keep[0].data_ptr(), keep[1].data_ptr(), _policy_kind(), nn_in.data_ptr(), stream)
         eng.check_status()
         res = eng.result(stream)
         if res["best_idx"][0] < 0:

@@ -43,6 +43,7 @@ def _rollout(model, n_slots: int, rng_mode: str = "python") -> Rollout:
                    max_game_moves=config.MAX_GAME_MOVES,
                    temperature=(config.TEMPERATURE_THRESHOLD, config.TEMPERATURE_INITIAL, config.TEMPERATURE_FINAL),
                    device=dev, autocast=config.AUTOCAST, rng_mode=rng_mode,
+                   policy_kind="probs" if config.POLICY_SOFTMAX == "torch" else "logits",
                    fast=config.SEARCH_MODE == "fast", leaves_per_step=config.FAST_LEAVES)
 
 

@@ -128,63 +128,111 @@ def all_gather_games(finished: Sequence, device: Optional[torch.device] = None, 
     return games
 
 
-class LaggedGameExchange:
-    """all_gather_games with the size exchange one step behind: `push(finished)` starts the (tiny) size all-gather of this
-    step's records asynchronously and completes the PREVIOUS step's exchange, whose sizes arrived while a whole ply ran on
-    the GPU -- the host never waits for a collective it has just issued.  Every rank must call push() once per step and
-    flush() once at the end; records are delivered one step late."""
+class _Gather:
+    """One all-gather in flight: `src` (uint8 / int64, equal length on every rank) -> host array, without a blocking call
+    on the issuing side.  RCCL: H2D, collective and D2H all run on a side stream behind an event; gloo: async work handle."""
 
-    def __init__(self, device: Optional[torch.device] = None, group=None):
-        self.device, self.group, self._pending = device, group, None
-
-    def _start(self, finished):
+    def __init__(self, src: np.ndarray, world: int, group, device: Optional[torch.device], side):
         import torch.distributed as dist
 
-        payload = b"".join(pack_game(f) for f in finished)
-        if not dist.is_available() or not dist.is_initialized():
-            return (payload, None, None)
-        world = dist.get_world_size(self.group)
-        backend = dist.get_backend(self.group)
-        dev = self.device if (self.device is not None and backend == "nccl") else torch.device("cpu")
-        sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-        mine = torch.tensor([len(payload)], dtype=torch.int64, device=dev)
-        work = dist.all_gather_into_tensor(sizes, mine, group=self.group, async_op=True)
-        return (payload, sizes, (work, mine, dev))
+        self.n, self.world = src.size, world
+        if device is not None:  # backend nccl (= RCCL over xGMI)
+            self.h_in = torch.from_numpy(src).pin_memory()
+            self.d_in = torch.empty(src.size, dtype=self.h_in.dtype, device=device)
+            self.d_out = torch.empty(world * src.size, dtype=self.h_in.dtype, device=device)
+            self.h_out = torch.empty(world * src.size, dtype=self.h_in.dtype).pin_memory()
+            self.event = torch.cuda.Event()
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                self.d_in.copy_(self.h_in, non_blocking=True)
+                work = dist.all_gather_into_tensor(self.d_out, self.d_in, group=group, async_op=True)
+                work.wait()  # the SIDE stream waits for the collective; the host and the compute stream do not
+                self.h_out.copy_(self.d_out, non_blocking=True)
+                self.event.record(side)
+            self.work = None
+        else:
+            self.h_in = torch.from_numpy(src)
+            self.h_out = torch.empty(world * src.size, dtype=self.h_in.dtype)
+            self.work = dist.all_gather_into_tensor(self.h_out, self.h_in, group=group, async_op=True)
+            self.event = None
 
-    def _finish(self, pending) -> List[dict]:
+    def done(self) -> bool:
+        return self.event.query() if self.event is not None else self.work.is_completed()
+
+    def result(self) -> np.ndarray:
+        if self.event is not None:
+            self.event.synchronize()  # already complete when a whole exchange period of plies ran in between
+        else:
+            self.work.wait()
+        return self.h_out.numpy().reshape(self.world, self.n)
+
+
+class PeriodicGameExchange:
+    """The path's only exchange step -- finished games' compact records to every rank -- taken off
+    the critical path of the plies.  Every rank calls `push(finished)` once per ply; records accumulate on the host and
+    every `every` plies one exchange period begins:
+        tick t    : sizes of the accumulated payload  -> all-gather (8 B per rank), asynchronous
+        tick t+1  : sizes read (complete long ago); if any rank has records, the padded payload -> all-gather, asynchronous
+        tick t+2  : payload read, records of ALL ranks returned from push()
+    Nothing in a ply's loop blocks on a collective: RCCL work, its H2D / D2H staging and their completion event live on a side
+    stream, and a period in which no rank finished a game costs one 8-byte all-gather and no payload step.  `flush()`
+    drains the pipeline at the end (three ticks, the same on every rank)."""
+
+    def __init__(self, device: Optional[torch.device] = None, group=None, every: int = 16):
         import torch.distributed as dist
 
-        payload, sizes, h = pending
-        if h is None:
-            return unpack_games(payload) if payload else []
-        work, _mine, dev = h
-        work.wait()
-        sizes_h = sizes.cpu().tolist()
-        mx = max(sizes_h)
-        if mx == 0:
-            return []
-        pad = torch.zeros(mx, dtype=torch.uint8)
-        if payload:
-            pad[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
-        pad = pad.to(dev)
-        gathered = torch.empty(len(sizes_h) * mx, dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(gathered, pad, group=self.group)
-        g = gathered.cpu().numpy()
-        games: List[dict] = []
-        for r in range(len(sizes_h)):
-            games.extend(unpack_games(g[r * mx:r * mx + sizes_h[r]].tobytes()))
-        return games
+        self.group, self.every = group, max(1, int(every))
+        self.dist_on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.dist_on else 1
+        nccl = self.dist_on and dist.get_backend(group) == "nccl"
+        self.device = torch.device(device) if (nccl and device is not None) else None
+        self.side = torch.cuda.Stream(self.device) if self.device is not None else None
+        self._buf: List[bytes] = []
+        self._calls = 0
+        self._sizes = None      # (payload bytes, _Gather of the sizes)
+        self._payload = None    # (sizes list, _Gather of the payload)
+        self.n_size_gathers = self.n_payload_gathers = 0
+        self.blocked_ticks = 0  # ticks that found their collective unfinished (should stay 0)
+
+    def _tick(self, start_new: bool) -> List[dict]:
+        out: List[dict] = []
+        if not self.dist_on:
+            if self._buf:
+                out = unpack_games(b"".join(self._buf))
+                self._buf = []
+            return out
+        if self._payload is not None:
+            sizes, g = self._payload
+            self.blocked_ticks += 0 if g.done() else 1
+            rows = g.result()
+            for r in range(self.world):
+                out.extend(unpack_games(rows[r, :sizes[r]].tobytes()))
+            self._payload = None
+        if self._sizes is not None:
+            payload, g = self._sizes
+            self.blocked_ticks += 0 if g.done() else 1
+            sizes = [int(x) for x in g.result().reshape(-1)]
+            self._sizes = None
+            mx = max(sizes)
+            if mx > 0:  # every rank sees the same sizes, so every rank takes (or skips) the payload step together
+                pad = np.zeros((mx + 15) // 16 * 16, dtype=np.uint8)
+                pad[:len(payload)] = np.frombuffer(payload, dtype=np.uint8)
+                self._payload = (sizes, _Gather(pad, self.world, self.group, self.device, self.side))
+                self.n_payload_gathers += 1
+        if start_new:
+            payload = b"".join(self._buf)
+            self._buf = []
+            self._sizes = (payload, _Gather(np.array([len(payload)], dtype=np.int64), self.world, self.group, self.device, self.side))
+            self.n_size_gathers += 1
+        return out
 
     def push(self, finished: Sequence) -> List[dict]:
-        nxt = self._start(finished)
-        out = self._finish(self._pending) if self._pending is not None else []
-        self._pending = nxt
-        return out
+        self._buf.extend(pack_game(f) for f in finished)
+        self._calls += 1
+        return self._tick(True) if self._calls % self.every == 0 else []
 
     def flush(self) -> List[dict]:
-        out = self._finish(self._pending) if self._pending is not None else []
-        self._pending = None
-        return out
+        return self._tick(True) + self._tick(False) + self._tick(False)
 
 
 def shard_game_ids(n_games_total: int, rank: int, world: int) -> List[int]:

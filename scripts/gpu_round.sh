@@ -1,0 +1,36 @@
+#!/bin/bash
+# scripts/gpu_round.sh -- one gpurun call: GPU tests, then the bench lines; stops at the first step that timed out / was killed.
+# usage (on the GPU box): bash scripts/gpu_round.sh <tag> [steps...]   steps: tests bench softmax dist2 steady
+set -u
+tag=$1; shift
+out=gpurun_out
+mkdir -p $out
+run() {  # name, timeout, command...
+  local name=$1 to=$2; shift 2
+  echo "=== $name: $*" | tee -a $out/${tag}_steps.log
+  timeout -k 10 $to "$@" > $out/${tag}_${name}.log 2>&1
+  local rc=$?
+  echo "=== $name rc=$rc" | tee -a $out/${tag}_steps.log
+  tail -n 4 $out/${tag}_${name}.log
+  if [ $rc -ge 124 ]; then echo "step $name timed out or was killed: stopping"; exit $rc; fi
+  return 0
+}
+for step in "$@"; do
+  case $step in
+    tests)   run gpu_tests 1000 python -m pytest tests -m gpu -q -x ;;
+    testsall) run gpu_tests 1000 python -m pytest tests -m gpu -q ;;
+    newtests) run gpu_newtests 900 python -m pytest tests/test_baseline_configs_gpu.py tests/test_dropin_gpu.py -m gpu -q ;;
+    bench)   run bench_default 600 python bench.py ;;
+    softmax) run bench_softmax_engine 300 python bench.py --softmax engine --no-cpu-baseline --no-roofline ;;
+    opening) run bench_opening 300 python bench.py --preroll 0 --no-cpu-baseline --no-roofline ;;
+    dist2)   run bench_dist2_gloo 400 python bench.py --gpus 2 --share-gpu --dist-backend gloo --games 128 --steps 40 --exchange-every 4 --no-cpu-baseline --no-roofline ;;
+    steady)  run bench_steady600 400 python bench.py --steps 600 --no-cpu-baseline --no-roofline --dump-games $out/${tag}_games.json ;;
+    cfg1)    run bench_cfg1 300 python bench.py --sims 400 --no-cpu-baseline --no-roofline ;;
+    cfg4)    run bench_cfg4 400 python bench.py --games 512 --net 20x256 --net-dtype fp16 --no-cpu-baseline --no-roofline ;;
+    g2048)   run bench_g2048 400 python bench.py --games 2048 --no-cpu-baseline --no-roofline ;;
+    fast)    run bench_fast 400 python bench.py --fast --leaves 16 --preroll 64 --no-cpu-baseline --no-roofline ;;
+    uci)     run uci_latency 300 python tests/uci_latency.py ;;
+    *) echo "unknown step $step"; exit 1 ;;
+  esac
+done
+echo "=== all steps done" | tee -a $out/${tag}_steps.log

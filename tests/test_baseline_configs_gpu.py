@@ -1,0 +1,223 @@
+"""BASELINE.json configs[2], [3], [4] at their full per-GPU workloads on the product path (cuda:0, libbetaone_hip.so,
+hipGraph on, the hand-written evaluate-stage kernels), each checked against the CPU oracle from the recorded
+(planes -> softmax probabilities, value) seam onward: moves, pi and trees bit for bit.
+
+The evaluations run inside captured graphs, so the seam is recorded from OUTSIDE the graph: the NN input rows of the
+watched slots are read before a replay, the probabilities / values the step kernel consumed after it."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "shim"))
+    from betaone_amd import dropin
+    from betaone_amd import engine as E
+
+    E.load_hip_library()
+    dropin.install()
+    import config
+
+    keys = ("RESIDUAL_BLOCKS", "SE_RESIDUAL_BLOCKS", "CONV_FILTERS", "NUM_SIMULATIONS", "MCTS_BATCH_SIZE", "POLICY_SOFTMAX")
+    saved = {k: getattr(config, k) for k in keys}
+    yield config
+    for k, v in saved.items():
+        setattr(config, k, v)
+
+
+class SeamRecorder:
+    """Wraps the two evaluate entry points of a native-RNG Rollout; records (planes key -> probs, value) of `watch` slots."""
+
+    def __init__(self, ro, watch):
+        from fake_model import planes_key
+
+        self.ro, self.watch, self.seam, self.key = ro, list(watch), {}, planes_key
+        self._step, self._fwd = ro._eval_and_step, ro._forward_only
+        ro._eval_and_step, ro._forward_only = self.eval_and_step, self.forward_only
+
+    def _planes(self):
+        return self.ro.nn_in[self.watch].cpu().numpy()
+
+    def _store(self, planes, probs, value):
+        probs, value = probs[self.watch].float().cpu().numpy(), value.reshape(-1)[self.watch].float().cpu().numpy()
+        for i in range(len(self.watch)):
+            self.seam[self.key(planes[i])] = (probs[i].copy(), np.float32(value[i]))
+
+    def eval_and_step(self):
+        planes = self._planes()
+        self._step()
+        self._store(planes, self.ro._logits, self.ro._value)
+
+    def forward_only(self):
+        planes = self._planes()
+        self._fwd()
+        self._store(planes, self.ro._f_logits, self.ro._f_value)
+
+    def eval_fn(self, planes):
+        probs = np.zeros((planes.shape[0], 4672), np.float32)
+        vals = np.zeros(planes.shape[0], np.float32)
+        for i in range(planes.shape[0]):
+            probs[i], vals[i] = self.seam[self.key(planes[i])]
+        return probs, vals
+
+
+def _check_games_against_oracle(ro, rec, watch, sims, plies):
+    from betaone_amd import engine as E
+    from oracle import oracle as O
+
+    G = ro.G
+    ro.eng.check_status()
+    st = ro.eng.status()
+    assert (st["evals"] >= plies * 2).all() and (st["flushes"] >= plies).all()
+    for step in range(ro._step):  # size-independent invariants for EVERY game: pi is a distribution over <= 2 moves (E2)
+        n, idx, val = ro._hist[step]
+        assert (n >= 1).all() and (n <= 2).all()
+        sums = np.array([val[g, :n[g]].sum() for g in range(G)])
+        assert np.abs(sums - 1.0).max() < 1e-6
+    games = {g: ro._finish(g, 0) for g in watch}
+    for g in watch:
+        ref = O.self_play(rec.eval_fn, np.random.RandomState(g), O.default_config(num_simulations=sims, max_game_moves=plies))
+        assert [O.move_to_uci(m) for m in ref["moves"]] == [E.move_to_uci(m) for m in games[g].moves], g
+        assert len(games[g].pis) == plies
+        for (_, rpi, _), (idx, val) in zip(ref["records"], games[g].pis):
+            assert sorted(np.nonzero(rpi)[0].tolist()) == sorted(idx.tolist())
+            for i, v in zip(idx, val):
+                assert np.float32(rpi[i]).view(np.uint32) == np.float32(v).view(np.uint32)
+
+
+def test_config2_shard_256_games_800_sims_10x128_graph_and_winograd_tower(env):
+    """configs[2]'s per-GPU shard exactly as bench.py runs it: 256 games x 800 sims, net 8+2 x 128 fp32 on the hand-written
+    Winograd tower kernel, native RNG streams, hipGraph-captured evaluate -> step."""
+    import torch
+    import network
+    from betaone_amd.fused_net import FusedPolicyValueNet
+    from betaone_amd.rollout import Rollout
+
+    config = env
+    config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 8, 2, 128
+    G, SIMS, PLIES, WATCH = 256, 800, 4, (0, 101, 255)
+    torch.manual_seed(0)
+    net = FusedPolicyValueNet(network.PolicyValueNet().to("cuda:0").eval(), conv="tower_wg").to("cuda:0")
+    ro = Rollout(net, G, num_simulations=SIMS, mcts_batch_size=96, device="cuda:0", use_graph=True, rng_mode="native",
+                 policy_kind="probs")
+    rec = SeamRecorder(ro, WATCH)
+    ro.start_games(list(range(G)), list(range(G)), list(range(G)))
+    for _ in range(PLIES):
+        assert ro.play_ply() == G
+    assert ro._graph is not None and ro.n_forward >= PLIES * 10
+    _check_games_against_oracle(ro, rec, WATCH, SIMS, PLIES)
+    ro.close()
+
+
+def test_config4_shard_512_games_800_sims_20x256_fp16_tower(env):
+    """configs[4]'s per-GPU shard: 512 games x 800 sims, net 15+5 x 256 evaluated in fp16 by the two-boards-per-workgroup
+    tower kernel; the tree is float32 given the (fp16-computed) seam, so it must still equal the oracle's bit for bit.
+    Plus: the fp16 logits stay within the stated bound of the same net in float32."""
+    import torch
+    import network
+    from betaone_amd.fused_net import FusedPolicyValueNet
+    from betaone_amd.rollout import Rollout
+
+    config = env
+    config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 15, 5, 256
+    G, SIMS, PLIES, WATCH = 512, 800, 3, (0, 255, 511)
+    torch.manual_seed(0)
+    plain = network.PolicyValueNet().to("cuda:0").eval()
+    net = FusedPolicyValueNet(plain, conv="tower_f16").to("cuda:0")
+    ro = Rollout(net, G, num_simulations=SIMS, mcts_batch_size=96, device="cuda:0", use_graph=True, rng_mode="native",
+                 policy_kind="probs")
+    rec = SeamRecorder(ro, WATCH)
+    ro.start_games(list(range(G)), list(range(G)), list(range(G)))
+    for _ in range(PLIES):
+        assert ro.play_ply() == G
+    _check_games_against_oracle(ro, rec, WATCH, SIMS, PLIES)
+    # fp16 evaluate stage vs the float32 net on the 512 positions now in the NN rows: error of the size of torch-fp16's own
+    x = ro.nn_in.clone()
+    half = plain.for_inference(dtype=torch.float16, channels_last=False)
+    with torch.no_grad():
+        l32, v32 = plain(x)
+        l16, v16 = net(x)
+        lt, vt = half(x.half())
+    e_ours = max((l32 - l16.float()).abs().max().item(), (v32 - v16.float()).abs().max().item())
+    e_torch = max((l32 - lt.float()).abs().max().item(), (v32 - vt.float()).abs().max().item())
+    scale = max(1.0, l32.abs().max().item())
+    assert e_ours <= max(3.0 * e_torch, 4e-3 * scale), (e_ours, e_torch, scale)
+    ro.close()
+
+
+def test_config3_uci_search_1600_sims_20x256_dropin_graph_path(env):
+    """configs[3]: the call uci.py makes (uci.py:62-63) -- mcts.run_mcts at 1600 simulations with the 15+5 x 256 net at batch 1
+    through the captured-graph path of the drop-in, history in uci.py's form (root board duplicated, quirk E5).  Best move, pi
+    and the whole tree against oracle.run_mcts fed with the recorded seam."""
+    import torch
+    import chess
+    import mcts
+    import network
+    import utils
+    from engine_harness import canonical_tree
+    from fake_model import hash_init_, planes_key
+    from oracle import oracle as O
+
+    config = env
+    config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 15, 5, 256
+    config.NUM_SIMULATIONS, config.MCTS_BATCH_SIZE, config.POLICY_SOFTMAX = 1600, 96, "torch"
+    model = hash_init_(network.PolicyValueNet().eval()).to("cuda")
+    moves = "e2e4 e7e5 g1f3 b8c6 f1b5 a7a6 b5a4 g8f6".split()
+    board = chess.Board()
+    tracker = utils.RepetitionTracker()
+    tracker.add_board(board)
+    hist = [board.copy()]
+    for u in moves:
+        board.push(chess.Move.from_uci(u)); tracker.add_board(board); hist.append(board.copy())
+    history = hist[-8:][-7:]  # uci.py:62: history[-7:] of a list that already ends with the root board
+
+    seam = {}
+    orig = mcts._GraphStep.__call__
+
+    def recording_call(self):
+        planes = self.nn_in.cpu().numpy()
+        orig(self)
+        seam[planes_key(planes[0])] = (self.out[0][0].float().cpu().numpy().copy(), np.float32(self.out[1].reshape(-1)[0].item()))
+
+    mcts._GraphStep.__call__ = recording_call
+    try:
+        results = []
+        for _ in range(2):  # the first call tunes + captures, the second replays
+            np.random.seed(9)
+            best, pi = mcts.run_mcts(board, model, history, tracker)
+            results.append((best.uci(), pi.copy()))
+        eng = next(iter(mcts._ctx.values()))[0]
+        got = canonical_tree(eng.debug_tree(0))
+        graph_step = next(iter(mcts._fast.values()))[2]
+        assert graph_step.kind == 2 and graph_step.graph is not None  # BO_POLICY_PROBS through a captured hipGraph
+    finally:
+        mcts._GraphStep.__call__ = orig
+    assert results[0][0] == results[1][0] and np.array_equal(results[0][1], results[1][1])
+
+    def eval_fn(planes):
+        probs = np.zeros((planes.shape[0], 4672), np.float32)
+        vals = np.zeros(planes.shape[0], np.float32)
+        for i in range(planes.shape[0]):
+            probs[i], vals[i] = seam[planes_key(planes[i])]
+        return probs, vals
+
+    ob = O.Board()
+    ot = O.PyTracker(); ot.add_board(ob)
+    for u in moves:
+        ob.push(u); ot.add_board(ob)
+    oh = ob.positions()[-8:][-7:]
+    r = O.run_mcts(ob, oh, ot, eval_fn, np.random.RandomState(9), O.default_config(num_simulations=1600, batch_size=96))
+    assert results[0][0] == O.move_to_uci(r["best"])
+    assert np.array_equal(results[0][1].view(np.uint32), r["pi"].view(np.uint32))
+    exp = {"/".join(k): list(v) for k, v in O.canonical_tree(r["nodes"]).items()}
+    assert got == exp
+    assert len(seam) >= 1 + 1600 // 96  # one root evaluation + one leaf per batch

@@ -1,5 +1,5 @@
 """CPU tests of the N>1 path: games shard by id over ranks (no data-path collective), finished games
-travel as compact records through ONE all-gather (gloo here, RCCL on the GPUs).  world_size = 2."""
+travel as compact records through ONE all-gather (gloo here, RCCL on the GPUs).  world_size = 2 and 4."""
 import os
 import socket
 import sys
@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, lagged=False):
+def _worker(rank, world, port, out_dir, every=0):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -34,26 +34,34 @@ def _worker(rank, world, port, out_dir, lagged=False):
         def forward(self, x):
             return FakeNet(scale=0.0, salt=21)(x)
 
-    n_total = 6
+    n_total = 3 * world
     ids = records.shard_game_ids(n_total, rank, world)           # game id -> rank = id mod world
     assert ids == list(range(rank, n_total, world))
+    # uneven finish times: rank r's games stop after 3 + r moves, so in most steps only some ranks (or none) have records
     ro = emu_call(Rollout, Net(), len(ids), num_simulations=30, mcts_batch_size=16, max_game_moves=3 + rank, device="cpu",
                   use_graph=False)
     ro.start_games(list(range(len(ids))), ids, [np.random.RandomState(i) for i in ids])
     fins = []
     gathered = []
-    ex = records.LaggedGameExchange() if lagged else None        # bench.py's form: the size exchange one step behind
-    for _step in range(6):   # every rank makes the SAME number of exchange steps (as bench.py does: one per step)
+    ex = records.PeriodicGameExchange(every=every) if every else None   # bench.py's form: pipelined, every `every` plies
+    n_steps = 5 + world
+    for _step in range(n_steps):   # every rank makes the SAME number of exchange steps (as bench.py does: one per step)
         batch = []
         if any(g is not None for g in ro.games):
             ro.play_ply(on_finished=batch.append)
         fins.extend(batch)
-        gathered.extend(ex.push(batch) if lagged else records.all_gather_games(batch))   # the path's only exchange step
-    if lagged:
+        gathered.extend(ex.push(batch) if every else records.all_gather_games(batch))   # the path's only exchange step
+    if every:
         gathered.extend(ex.flush())
+        ticks = n_steps // every
+        assert ex.n_size_gathers == ticks + 1                     # one 8-byte all-gather per period (+ the flush's)
+        assert ex.n_payload_gathers <= ticks + 1 and ex.n_payload_gathers >= 1
+        if every == 1:  # periods in which NO rank finished a game took no payload step
+            assert ex.n_payload_gathers <= world
     assert not any(g is not None for g in ro.games)
     ro.close()
     mine = {g.game_id: [m for m in g.moves] for g in fins}
+    assert len(gathered) == n_total and len({g["game_id"] for g in gathered}) == n_total   # every record exactly once
     np.save(os.path.join(out_dir, f"rank{rank}.npy"),
             np.array([[g["game_id"], g["n_plies"], g["terminal"]] + list(g["moves"][:3]) for g in
                       sorted(gathered, key=lambda x: x["game_id"])], dtype=np.int64))
@@ -64,15 +72,16 @@ def _worker(rank, world, port, out_dir, lagged=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("lagged", [False, True])
-def test_two_ranks_shard_games_and_all_gather_records(tmp_path, lagged):
-    world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), lagged), nprocs=world, join=True)
+@pytest.mark.parametrize("world,every", [(2, 0), (2, 1), (2, 3), (4, 2)])
+def test_ranks_shard_games_and_all_gather_records(tmp_path, world, every):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), every), nprocs=world, join=True)
     a = np.load(tmp_path / "rank0.npy")
-    b = np.load(tmp_path / "rank1.npy")
-    assert np.array_equal(a, b)                       # every rank ends with every game's record
-    assert sorted(a[:, 0].tolist()) == [0, 1, 2, 3, 4, 5]
-    assert all(a[a[:, 0] % 2 == 0][:, 1] == 3) and all(a[a[:, 0] % 2 == 1][:, 1] == 4)
+    for r in range(1, world):
+        assert np.array_equal(a, np.load(tmp_path / f"rank{r}.npy"))   # every rank ends with every game's record
+    assert sorted(a[:, 0].tolist()) == list(range(3 * world))
+    for r in range(world):
+        assert all(a[a[:, 0] % world == r][:, 1] == 3 + r)
 
 
 def test_results_do_not_depend_on_the_sharding():
