@@ -418,6 +418,22 @@ extern "C" int bo_search_poll(bo_engine *e, int32_t *n_running, int32_t *n_reque
     return BO_OK;
 }
 
+extern "C" int bo_search_stop(bo_engine *e, const int32_t *stop_mask, int32_t *sims_done, void *stream) {
+    if (!e) return fail(BO_E_ARG, "null engine");
+    if (e->fast) return fail(BO_E_CONFIG, "bo_search_stop: reference-semantics engines only");
+    const size_t G = (size_t)e->d.c.G;
+    const int *d_mask = nullptr;
+    if (stop_mask) {
+        memcpy(e->h_go, stop_mask, G * 4);
+        RT(rt_h2d(e->d_go, e->h_go, G * 4, stream));
+        d_mask = e->d_go;
+    }
+    RT(RT_LAUNCH(bo_k_stop, e->d.c.G, stream, e->d, d_mask));
+    if (sims_done) RT(rt_d2h(sims_done, e->d.sims_done, G * 4, stream));
+    RT(rt_sync(stream));
+    return BO_OK;
+}
+
 extern "C" int bo_search_result(bo_engine *e, int32_t *res_n, int32_t *res_idx, float *res_val, int32_t *best_idx,
                                 int32_t *best_move, int32_t *total_visits, void *stream) {
     if (!e) return fail(BO_E_ARG, "null engine");

@@ -889,6 +889,22 @@ BO_KERNEL void bo_k_search_begin(Eng e, const int *go, float *nn_in) {
     if (bo_lane() == 0) e.phase[g] = PH_RUN;
 }
 
+// End running searches early, between two steps: flush the pending rows as the tail batch (mcts.py:256-257), drop the
+// outstanding evaluation request, phase = DONE.  The tree then is the reference's tree after sims_done simulations.
+BO_KERNEL void bo_k_stop(Eng e, const int *mask) {
+    BO_SHARED int path[BO_PATH_CAP];
+    const int g = bo_block(), lane = bo_lane();
+    if ((mask && !mask[g]) || e.phase[g] != PH_RUN) return;
+    int flags = 0, n_nodes = e.n_nodes[g];
+    if (e.rows[g] > 0) flush_pending(e, g, e.n_runs[g], e.n_ul[g], &n_nodes, path, &flags);
+    bo_sync();
+    if (lane == 0) {
+        e.rows[g] = 0; e.n_runs[g] = 0; e.n_ul[g] = 0; e.n_nodes[g] = n_nodes;
+        e.req_node[g] = -1; e.phase[g] = PH_DONE;
+        if (flags) e.status[g] |= flags;
+    }
+}
+
 // pi and best move of a finished search (mcts.py:259-280)
 BO_KERNEL void bo_k_result(Eng e) {
     const int g = bo_block(), lane = bo_lane();

@@ -17,6 +17,25 @@ import config
 from betaone_amd import engine as E
 
 _lock = threading.Lock()
+# Interruptible search.  The reference polls its stop flag only between whole searches
+# (uci.py:73); here a running search is interrupted between two evaluate->step replays: set `stop_event` (or call
+# request_stop()) from another thread and run_mcts returns the result of the simulations completed so far -- exactly what
+# the reference returns for that NUM_SIMULATIONS.  uci.py keeps its own module-level `stop_event` (uci.py:44) and runs as
+# __main__: that event is honoured too, so the unchanged uci.py stops mid-search.  The caller clears the event.
+stop_event = threading.Event()
+RUN_AHEAD = 4
+last_search = {"simulations": 0, "stopped": False}   # of the most recent run_mcts call
+
+
+def request_stop():
+    stop_event.set()
+
+
+def _stop_requested() -> bool:
+    if stop_event.is_set():
+        return True
+    ev = getattr(sys.modules.get("__main__"), "stop_event", None)
+    return isinstance(ev, threading.Event) and ev.is_set()
 _ctx = {}            # config tuple -> (Engine, nn_in tensor)
 _fast = {}           # id(model) -> (parameter versions, inference copy, captured hipGraph state)
 
@@ -170,18 +189,36 @@ def run_mcts(root_board, model, history: List, tracker) -> Tuple[object, np.ndar
         graph_step = _fast_path(model, eng, nn_in)
         keep = None
         burst = 1 + -(-config.NUM_SIMULATIONS // config.MCTS_BATCH_SIZE) if (graph_step is not None and terminal[0] == 0) else 0
-        while True:
+        stopped = False
+        ahead = []  # completion events of the replays in flight: the host stays at most RUN_AHEAD replays in front of the GPU,
+        while not stopped:  # so a stop request takes effect within that many evaluations (and the queue never runs dry)
             for _ in range(burst):  # the expected number of evaluations without a host round trip in between
+                if _stop_requested():
+                    stopped = True
+                    break
                 graph_step()
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(nn_in.device))
+                ahead.append(ev)
+                if len(ahead) > RUN_AHEAD:
+                    ahead.pop(0).synchronize()
             burst = 0
+            if stopped:
+                break
             running, _, _ = eng.poll(stream, want_mask=False)
             if running == 0:
                 break
-            if graph_step is not None:
+            if _stop_requested():
+                stopped = True
+            elif graph_step is not None:
                 graph_step()
             else:
                 keep = _evaluate(model, nn_in)
                 eng.step(keep[0].data_ptr(), keep[1].data_ptr(), _policy_kind(), nn_in.data_ptr(), stream)
+        sims_done = config.NUM_SIMULATIONS
+        if stopped:  # tail flush + result of the simulations completed so far (mcts.py:256-280 at that NUM_SIMULATIONS)
+            sims_done = int(eng.search_stop(None, stream)[0])
+        last_search.update(simulations=sims_done, stopped=stopped)
         eng.check_status()
         res = eng.result(stream)
         if res["best_idx"][0] < 0:

@@ -66,6 +66,7 @@ _SYMBOLS = {
     "bo_search_begin": (C.c_int, [C.c_void_p, _I32P, _F64P, C.c_void_p, C.c_void_p]),
     "bo_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "bo_search_poll": (C.c_int, [C.c_void_p, _I32P, _I32P, _I32P, C.c_void_p]),
+    "bo_search_stop": (C.c_int, [C.c_void_p, _I32P, _I32P, C.c_void_p]),
     "bo_search_result": (C.c_int, [C.c_void_p, _I32P, _I32P, _F32P, _I32P, _I32P, _I32P, C.c_void_p]),
     "bo_play": (C.c_int, [C.c_void_p, _I32P, C.c_void_p]),
     "bo_game_export": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BoPosition), _I32P, C.c_int32, _I32P, C.c_void_p]),
@@ -244,6 +245,13 @@ class Engine:
         mask = np.zeros(self.G, dtype=np.int32) if want_mask else None
         self._check(self.lib.bo_search_poll(self.h, C.byref(run), C.byref(req), _p(mask) if want_mask else None, stream))
         return run.value, req.value, mask
+
+    def search_stop(self, mask=None, stream: int = 0) -> np.ndarray:
+        """Interrupt the running searches (all, or those with mask[g] != 0) between two steps; -> simulations completed per game."""
+        m = _i32(mask) if mask is not None else None
+        done = np.zeros(self.G, dtype=np.int32)
+        self._check(self.lib.bo_search_stop(self.h, _p(m) if m is not None else None, _p(done), stream))
+        return done
 
     def result(self, stream: int = 0) -> Dict[str, np.ndarray]:
         G = self.G

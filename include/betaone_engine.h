@@ -123,6 +123,13 @@ int bo_step(bo_engine *e, const float *policy_dev, const float *value_dev, int p
  * requested_mask (optional, [G] int32) marks the rows the net must evaluate.  Synchronises. */
 int bo_search_poll(bo_engine *e, int32_t *n_running, int32_t *n_requested, int32_t *requested_mask, void *stream);
 
+/* Interrupt running searches between two steps (the reference can only stop between whole
+ * searches, uci.py:73): for every game with stop_mask[g] != 0 (NULL = all) whose search is running, the pending rows are
+ * flushed exactly like the tail batch of mcts.py:256-257, an evaluation still outstanding is dropped, and the search is
+ * marked finished -- bo_search_result then returns what the reference returns for NUM_SIMULATIONS = sims_done[g]
+ * (optional out, [G] int32: simulations completed per game).  Reference-semantics engines only.  Synchronises. */
+int bo_search_stop(bo_engine *e, const int32_t *stop_mask, int32_t *sims_done, void *stream);
+
 /* Result of the finished searches (mcts.py:259-280): sparse pi (res_n[g] entries of
  * (action index, probability) at [g*BO_RES_CAP ..]), best move as action index (-1: no legal
  * move, the reference raises ValueError) and as from|to<<6|promo<<12, total root-child visits.

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture()
 def env():
     import torch
 
@@ -27,9 +27,14 @@ def env():
     dropin.install()
     import config
 
-    keys = ("RESIDUAL_BLOCKS", "SE_RESIDUAL_BLOCKS", "CONV_FILTERS", "NUM_SIMULATIONS", "MCTS_BATCH_SIZE", "POLICY_SOFTMAX")
+    import mcts
+
+    keys = ("RESIDUAL_BLOCKS", "SE_RESIDUAL_BLOCKS", "CONV_FILTERS", "NUM_SIMULATIONS", "MCTS_BATCH_SIZE", "POLICY_SOFTMAX", "DATA_DIR",
+            "MAX_GAME_MOVES")
     saved = {k: getattr(config, k) for k in keys}
+    mcts.stop_event.clear()
     yield config
+    mcts.stop_event.clear()
     for k, v in saved.items():
         setattr(config, k, v)
 
@@ -221,3 +226,185 @@ def test_config3_uci_search_1600_sims_20x256_dropin_graph_path(env):
     exp = {"/".join(k): list(v) for k, v in O.canonical_tree(r["nodes"]).items()}
     assert got == exp
     assert len(seam) >= 1 + 1600 // 96  # one root evaluation + one leaf per batch
+
+
+def _uci_position(moves):
+    """What uci.py builds for `position startpos moves ...` (uci.py:161-199): board, tracker of every position, history[-8:]
+    INCLUDING the current board."""
+    import chess
+    import utils
+
+    board = chess.Board()
+    tracker = utils.RepetitionTracker()
+    tracker.add_board(board)
+    hist = [board.copy()]
+    for u in moves:
+        board.push(chess.Move.from_uci(u)); tracker.add_board(board); hist.append(board.copy())
+    return board, hist[-8:], tracker
+
+
+def test_config3_interrupted_search_on_gpu_equals_oracle_at_the_simulations_done(env):
+    """Row f2 on the product path: a 1600-simulation search (15+5 x 256 net, captured graph) interrupted after k replays
+    returns the reference's result for NUM_SIMULATIONS = k x 96, checked against the oracle from the recorded seam."""
+    import mcts
+    import network
+    from fake_model import hash_init_, planes_key
+    from oracle import oracle as O
+
+    config = env
+    config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 15, 5, 256
+    config.NUM_SIMULATIONS, config.MCTS_BATCH_SIZE, config.POLICY_SOFTMAX = 1600, 96, "torch"
+    model = hash_init_(network.PolicyValueNet().eval()).to("cuda")
+    moves = "d2d4 d7d5 c2c4 e7e6 b1c3".split()
+    board, hist8, tracker = _uci_position(moves)
+    history = hist8[-7:]
+    np.random.seed(4)
+    mcts.run_mcts(board, model, history, tracker)  # tune + capture
+    assert mcts.last_search == {"simulations": 1600, "stopped": False}
+
+    seam, calls = {}, [0]
+    orig = mcts._GraphStep.__call__
+
+    def recording_call(self):
+        planes = self.nn_in.cpu().numpy()
+        orig(self)
+        seam[planes_key(planes[0])] = (self.out[0][0].float().cpu().numpy().copy(), np.float32(self.out[1].reshape(-1)[0].item()))
+        calls[0] += 1
+        if calls[0] == 8:
+            mcts.request_stop()
+
+    mcts._GraphStep.__call__ = recording_call
+    try:
+        np.random.seed(4)
+        best, pi = mcts.run_mcts(board, model, history, tracker)
+    finally:
+        mcts._GraphStep.__call__ = orig
+        mcts.stop_event.clear()
+    assert mcts.last_search == {"simulations": 7 * 96, "stopped": True}   # root evaluation + 7 leaf evaluations consumed
+
+    def eval_fn(planes):
+        probs = np.zeros((planes.shape[0], 4672), np.float32)
+        vals = np.zeros(planes.shape[0], np.float32)
+        for i in range(planes.shape[0]):
+            probs[i], vals[i] = seam[planes_key(planes[i])]
+        return probs, vals
+
+    ob = O.Board()
+    ot = O.PyTracker(); ot.add_board(ob)
+    for u in moves:
+        ob.push(u); ot.add_board(ob)
+    r = O.run_mcts(ob, ob.positions()[-8:][-7:], ot, eval_fn, np.random.RandomState(4), O.default_config(num_simulations=7 * 96))
+    assert best.uci() == O.move_to_uci(r["best"])
+    assert np.array_equal(pi.view(np.uint32), r["pi"].view(np.uint32))
+
+
+def test_config3_uci_shaped_session_latency_and_stop(env):
+    """The call sequence of uci.py on the GPU box (the reference file itself cannot travel): `position ... / go movetime /
+    stop` -- a worker thread runs run_mcts back to back on a copy of the position (uci.py:48-120) while the main thread waits,
+    then sets the stop flag.  Config 3: 1600 simulations, 15+5 x 256 net, hipGraph path.  Asserts the per-search latency
+    (<= 12 ms median) and that a stop ends the running search between two steps."""
+    import threading
+    import time
+
+    import torch
+    import mcts
+    import network
+
+    config = env
+    config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 15, 5, 256
+    config.NUM_SIMULATIONS, config.MCTS_BATCH_SIZE = 1600, 96
+    torch.manual_seed(0)
+    model = network.PolicyValueNet().to("cuda").eval()
+    board, history, tracker = _uci_position("e2e4 e7e5 g1f3 b8c6 f1b5 a7a6".split())
+    out = {"lat": [], "moves": [], "stopped_mid_search": 0}
+
+    def search_worker(board, history, tracker, time_limit_ms):   # the shape of uci.py:48-120
+        start = time.time()
+        while True:
+            t0 = time.perf_counter()
+            best, _pi = mcts.run_mcts(board, model, history[max(0, len(history) - 7):], tracker)
+            out["lat"].append((time.perf_counter() - t0) * 1e3)
+            out["moves"].append(best.uci())
+            out["stopped_mid_search"] += 1 if mcts.last_search["stopped"] else 0
+            if mcts.stop_event.is_set() or (time.time() - start) * 1e3 >= time_limit_ms:
+                break
+
+    np.random.seed(0)
+    for _ in range(3):
+        mcts.run_mcts(board, model, history[-7:], tracker)   # first call tunes the inference copy and captures the graph
+    # go movetime 400
+    th = threading.Thread(target=search_worker, args=(board.copy(), list(history), tracker, 400.0), daemon=True)
+    th.start(); th.join(timeout=30.0)
+    assert not th.is_alive() and len(out["lat"]) >= 10
+    med = float(np.median(out["lat"]))
+    print(f"uci-shaped session: {len(out['lat'])} searches of 1600 sims in 400 ms, median {med:.2f} ms, min {min(out['lat']):.2f} ms")
+    assert med <= 12.0, out["lat"]
+    legal = {m.uci() for m in board.legal_moves}
+    assert set(out["moves"]) <= legal
+    # go infinite ... stop
+    n_before = len(out["lat"])
+    config.NUM_SIMULATIONS = 96 * 4000   # a long search (~2 s): the stop must land inside it
+    th = threading.Thread(target=search_worker, args=(board.copy(), list(history), tracker, 60_000.0), daemon=True)
+    th.start()
+    time.sleep(0.5)
+    t_stop = time.perf_counter()
+    mcts.request_stop()
+    th.join(timeout=10.0)
+    dt_stop = (time.perf_counter() - t_stop) * 1e3
+    mcts.stop_event.clear()
+    assert not th.is_alive()
+    assert out["stopped_mid_search"] == 1 and len(out["lat"]) == n_before + 1
+    assert 0 < mcts.last_search["simulations"] < 96 * 4000 and mcts.last_search["simulations"] % 96 == 0
+    assert out["moves"][-1] in legal
+    print(f"stop -> bestmove after {dt_stop:.1f} ms ({mcts.last_search['simulations']} simulations done)")
+    assert dt_stop < 250.0
+
+
+def test_orchestrator_iteration_on_gpu_writes_reference_pickles_and_resumes(env, tmp_path):
+    """Row f4 on the product path: betaone_amd.selfplay_main.run_iteration (the replacement of main.py:142-191) plays 24 games
+    in 8 slots on cuda:0, writes the reference's pickles, resumes by skipping what is on disk (main.py:26-36), and what it
+    wrote loads through the contract of train.load_recent_data / ChessDataset.__getitem__ (train.py:179-184, :207-214)."""
+    import glob
+    import pickle
+
+    import torch
+    import network
+    from betaone_amd import selfplay_main as M
+
+    config = env
+    config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 3, 1, 64
+    config.NUM_SIMULATIONS, config.MCTS_BATCH_SIZE, config.MAX_GAME_MOVES = 100, 96, 12
+    config.DATA_DIR = str(tmp_path / "data")
+    torch.manual_seed(0)
+    model = network.PolicyValueNet().to("cuda").eval()
+    logs = []
+    done = M.run_iteration(model, 5, n_games=24, n_slots=8, log=logs.append)
+    assert sorted(done) == list(range(24)) and all(1 <= v <= 12 for v in done.values())
+    files = sorted(glob.glob(os.path.join(config.DATA_DIR, "iter_5", "game_*.pkl")))
+    assert len(files) == 24
+    all_data = []
+    for f in files:  # train.load_recent_data's acceptance test (train.py:207-214)
+        game = pickle.load(open(f, "rb"))
+        assert isinstance(game, list) and game
+        all_data.extend(game)
+    assert len(all_data) == sum(done.values())
+    for state, policy, value in all_data[:50]:  # ChessDataset.__getitem__ (train.py:179-184)
+        policy_tensor = torch.from_numpy(policy).float()
+        value_tensor = torch.tensor([value], dtype=torch.float32)
+        assert isinstance(state, torch.Tensor) and state.dtype == torch.float32 and tuple(state.shape) == (120, 8, 8)
+        assert state.device.type == "cpu" and tuple(policy_tensor.shape) == (4672,) and tuple(value_tensor.shape) == (1,)
+        assert abs(float(policy_tensor.sum()) - 1.0) < 1e-6 and float(value_tensor) in (-1.0, 0.0, 1.0)
+    batch = torch.stack([d[0] for d in all_data[:16]])  # a training batch forms
+    assert tuple(batch.shape) == (16, 120, 8, 8)
+    # resume: remove three files, a second call plays exactly those games again and reproduces them (seeds travel with the ids)
+    keep = {j: pickle.load(open(os.path.join(config.DATA_DIR, "iter_5", f"game_{j}.pkl"), "rb")) for j in (3, 11, 17)}
+    for j in keep:
+        os.remove(os.path.join(config.DATA_DIR, "iter_5", f"game_{j}.pkl"))
+    assert M.pending_game_ids(config.DATA_DIR, 5, 24) == [3, 11, 17]
+    again = M.run_iteration(model, 5, n_games=24, n_slots=8, log=logs.append)
+    assert sorted(again) == [3, 11, 17]
+    for j, old in keep.items():
+        new = pickle.load(open(os.path.join(config.DATA_DIR, "iter_5", f"game_{j}.pkl"), "rb"))
+        assert len(new) == len(old)
+        assert all(torch.equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] for a, b in zip(new, old))
+    assert M.run_iteration(model, 5, n_games=24, n_slots=8, log=logs.append) == {}

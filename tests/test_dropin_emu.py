@@ -281,3 +281,36 @@ def test_device_string_without_index_resolves_to_the_current_device(monkeypatch)
     assert E.runtime_device("cuda:1") == torch.device("cuda", 1)
     with pytest.raises(E.EngineError):
         E.runtime_device("cpu")
+
+
+@pytest.mark.parametrize("stop_after_evals", [0, 1, 3, 6])
+def test_interrupted_search_equals_a_complete_search_of_the_simulations_done(stop_after_evals):
+    """Row f2: a search interrupted between two steps returns exactly what the reference returns for NUM_SIMULATIONS = the
+    simulations completed so far (tail batch flushed as in mcts.py:256-257, the outstanding evaluation dropped)."""
+    config.NUM_SIMULATIONS = 800
+    fen, moves = chess.STARTING_FEN, "e2e4 e7e5 g1f3 b8c6 f1b5".split()
+    board, history, tracker = context(fen, moves)
+
+    class StoppingNet(FakeNet):
+        def __call__(self, x):
+            if len(self.calls) >= stop_after_evals:
+                mcts.request_stop()
+            return super().__call__(x)
+
+    mcts.stop_event.clear()
+    try:
+        np.random.seed(3)
+        best, pi = mcts.run_mcts(board, StoppingNet(scale=0.0, salt=8), history, tracker)
+    finally:
+        mcts.stop_event.clear()
+    info = dict(mcts.last_search)
+    assert info["stopped"] and info["simulations"] < 800
+    assert info["simulations"] == stop_after_evals * 96    # whole batches: 96 rows share one evaluation (E1)
+    ob, oh, ot = oracle_context(fen, moves)
+    r = O.run_mcts(ob, oh, ot, uniform_eval(8), np.random.RandomState(3), O.default_config(num_simulations=info["simulations"]))
+    assert best.uci() == O.move_to_uci(r["best"])
+    assert np.array_equal(pi.view(np.uint32), r["pi"].view(np.uint32))
+    # and an uninterrupted call afterwards is a full search again
+    np.random.seed(3)
+    mcts.run_mcts(board, FakeNet(scale=0.0, salt=8), history, tracker)
+    assert mcts.last_search == {"simulations": 800, "stopped": False}
