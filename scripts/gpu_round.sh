@@ -19,7 +19,7 @@ for step in "$@"; do
   case $step in
     tests)   run gpu_tests 1000 python -m pytest tests -m gpu -q -x ;;
     testsall) run gpu_tests 1000 python -m pytest tests -m gpu -q ;;
-    newtests) run gpu_newtests 900 python -m pytest tests/test_baseline_configs_gpu.py tests/test_dropin_gpu.py -m gpu -q ;;
+    newtests) run gpu_newtests 900 python -m pytest tests/test_baseline_configs_gpu.py tests/test_dropin_gpu.py -m gpu -q -s ;;
     bench)   run bench_default 600 python bench.py ;;
     softmax) run bench_softmax_engine 300 python bench.py --softmax engine --no-cpu-baseline --no-roofline ;;
     opening) run bench_opening 300 python bench.py --preroll 0 --no-cpu-baseline --no-roofline ;;
@@ -30,6 +30,12 @@ for step in "$@"; do
     g2048)   run bench_g2048 400 python bench.py --games 2048 --no-cpu-baseline --no-roofline ;;
     fast)    run bench_fast 400 python bench.py --fast --leaves 16 --preroll 64 --no-cpu-baseline --no-roofline ;;
     uci)     run uci_latency 300 python tests/uci_latency.py ;;
+    nccl1)   run bench_nccl1 300 env RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 python bench.py --force-dist --exchange-every 4 --steps 60 --no-cpu-baseline --no-roofline ;;
+    uci_engine) run uci_latency_engine 300 env BO_UCI_SOFTMAX=engine python tests/uci_latency.py ;;
+    stepprof) run stepprof 400 python scripts/step_profile.py 640 100 1 ;
+              run stepprof_slow 400 python scripts/step_profile.py 640 100 300000 ;;
+    trace)   mkdir -p $out/${tag}_trace; run trace 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace -- python bench.py --steps 200 --opening-steps 0 --no-cpu-baseline --no-roofline ;
+             python scripts/kernel_percentiles.py $out/${tag}_trace > $out/${tag}_trace_percentiles.md 2>&1 ; rm -f $out/${tag}_trace/*/*_kernel_trace.csv.keep ; tail -n 30 $out/${tag}_trace_percentiles.md ;;
     *) echo "unknown step $step"; exit 1 ;;
   esac
 done

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""scripts/kernel_percentiles.py -- per-kernel launch-duration percentiles from rocprofv3's *_kernel_trace.csv
+(the --stats table only has the mean; the step kernel's cost is its tail).  usage: kernel_percentiles.py <dir> [name-substring ...]
+Only the second half of each kernel's launches is used (steady state of a bench run with pre-roll)."""
+import csv, glob, os, sys
+import numpy as np
+
+d = sys.argv[1]
+want = sys.argv[2:] or ["bo_k_", "Cijk", "softmax"]
+files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+if not files:
+    print("no kernel_trace.csv under", d); sys.exit(1)
+dur = {}
+for f in files:
+    for r in csv.DictReader(open(f)):
+        name = r.get("Kernel_Name") or r.get("Name") or ""
+        if not any(w in name for w in want):
+            continue
+        dur.setdefault(name[:80], []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+print("| kernel | launches (2nd half) | mean us | p50 | p90 | p99 | max |")
+print("|---|---|---|---|---|---|---|")
+for name, v in sorted(dur.items(), key=lambda kv: -sum(x[1] for x in kv[1])):
+    v.sort()
+    a = np.array([x[1] for x in v[len(v) // 2:]], dtype=np.float64) / 1e3
+    if len(a) == 0:
+        continue
+    print(f"| {name} | {len(a)} | {a.mean():.1f} | {np.percentile(a, 50):.1f} | {np.percentile(a, 90):.1f} | {np.percentile(a, 99):.1f} | {a.max():.1f} |")

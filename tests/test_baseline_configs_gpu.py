@@ -342,11 +342,15 @@ def test_config3_uci_shaped_session_latency_and_stop(env):
     legal = {m.uci() for m in board.legal_moves}
     assert set(out["moves"]) <= legal
     # go infinite ... stop
-    n_before = len(out["lat"])
     config.NUM_SIMULATIONS = 96 * 4000   # a long search (~2 s): the stop must land inside it
+    mcts.request_stop()
+    mcts.run_mcts(board, model, history[-7:], tracker)   # builds the engine + graph for these settings, returns at once
+    mcts.stop_event.clear()
+    assert mcts.last_search["stopped"]
+    n_before = len(out["lat"])
     th = threading.Thread(target=search_worker, args=(board.copy(), list(history), tracker, 60_000.0), daemon=True)
     th.start()
-    time.sleep(0.5)
+    time.sleep(0.3)
     t_stop = time.perf_counter()
     mcts.request_stop()
     th.join(timeout=10.0)

@@ -11,6 +11,7 @@ import chess, config, mcts, network, utils   # chess = oracle/shim stand-in for 
 
 sims = int(sys.argv[1]) if len(sys.argv) > 1 else 1600
 config.NUM_SIMULATIONS = sims
+config.POLICY_SOFTMAX = os.environ.get('BO_UCI_SOFTMAX', config.POLICY_SOFTMAX)
 config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 15, 5, 256
 torch.manual_seed(0)
 model = network.PolicyValueNet().to("cuda").eval()
