@@ -265,6 +265,7 @@ class Driver:
         self.next_id = rank
         self.batch, self.n_finished, self.plies_finished, self.lengths = [], 0, 0, []
         self.n_received = 0
+        self.exchange_seconds = 0.0
 
     def new_id(self):
         i = self.next_id
@@ -286,7 +287,9 @@ class Driver:
     def step(self):
         self.ro.play_ply(on_finished=self.on_finished, refill=self.refill)
         if self.exchange is not None:  # the path's only exchange step: finished games' records to every rank (RCCL over xGMI),
+            t0 = time.perf_counter()
             self.n_received += len(self.exchange.push(self.batch))  # pipelined: nothing here waits for a collective
+            self.exchange_seconds += time.perf_counter() - t0
         self.batch.clear()
 
     def preroll(self, plies, G):
@@ -442,7 +445,8 @@ def main():
             out["opening_phase"] = opening
         if exchange is not None:
             out["record_exchange"] = {"size_gathers": exchange.n_size_gathers, "payload_gathers": exchange.n_payload_gathers,
-                                      "ticks_that_blocked": exchange.blocked_ticks, "records_received_rank0": drv.n_received}
+                                      "ticks_that_blocked": exchange.blocked_ticks, "records_received_rank0": drv.n_received,
+                                      "host_seconds_in_exchange_rank0": round(drv.exchange_seconds, 4)}
     if rank == 0 and not args.no_roofline:
         sr = step_roofline(ro, args.steps)
         out["roofline_step"] = {"bound": "latency", "note": "parity-mode trees are cache-resident (a few KB per game)",

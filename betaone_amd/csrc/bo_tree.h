@@ -361,7 +361,8 @@ BO_DEV int select_leaf(const Eng &e, int g, int *flags, int *path, int *depth_ou
 // registers, and as long as it reproduces the same path the loop continues.  Returns the number of simulations
 // applied (>= 1); the caller re-selects from memory afterwards.  Bit-identical to backup_run + select_leaf.
 #define BO_BURST_LEVELS 4
-BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, int sims_left) {
+#define BO_BURST_WIN 256  // sqrt-table entries staged in LDS per level and refill (4 levels x 256 floats = 4 KB of the probs buffer)
+BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, int sims_left, float *lds_lut) {
     const size_t no = NOFF(e, g);
     const int lane = bo_lane(), grp = lane >> 4, j = lane & 15;
     int nv[BO_BURST_LEVELS + 1];  // uniform copies of the path nodes' visit counts
@@ -374,7 +375,6 @@ BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, 
         ncs[k] = k < d ? e.n_children[no + path[k]] : 0;
         chosen[k] = k < d ? path[k + 1] - fc[k] : -1;
     }
-    float rootq = e.q[no];
     int my_fc = 0, my_nc = 0, my_chosen = -1;  // this lane's child: group = level, j = child index
 #pragma unroll
     for (int k = 0; k < BO_BURST_LEVELS; k++)
@@ -388,17 +388,35 @@ BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, 
     const int cterm = (have && last && e.n_children[no + my_fc + j] == 0) ? (int)e.term[no + my_fc + j] : -1;
     float v_cur = v;
     int done = 0;
-    // sqrt(parent visits) of this lane's level for the NEXT re-evaluation: every level's count grows by one per simulation,
-    // so the table entry is requested one iteration ahead (it was a dependent global load inside every iteration)
-    int pv_next = nv[0] + 1;
-#pragma unroll
-    for (int k = 1; k < BO_BURST_LEVELS; k++)
-        if (grp == k) pv_next = nv[k - 1] + 1;
-    float sp_next = e.sqrt_lut[pv_next <= e.c.S + 1 ? pv_next : e.c.S + 1];
+    // sqrt(parent visits) of this lane's level: every level's count grows by one per simulation, so iteration i of the
+    // burst reads table entry pv0 + i of its level.  A window of BO_BURST_WIN entries per level is staged in LDS by all
+    // lanes at once (one memory round trip per 256 simulations; as a global load per iteration -- even requested one
+    // iteration ahead -- the L2 latency of ~700 cycles bounded every simulated visit: 1 M cycles for an 800-visit burst).
+    int win_base = 0;  // iteration index of lds_lut[grp][0]
+    {
+        const int idx_max = e.c.S + 1;
+        for (int t = lane; t < BO_BURST_LEVELS * BO_BURST_WIN; t += 64) {
+            const int k = t / BO_BURST_WIN, i = t % BO_BURST_WIN;
+            const int p = (k == 0 ? nv[0] : nv[k - 1]) + 1 + i;
+            lds_lut[t] = e.sqrt_lut[p <= idx_max ? p : idx_max];
+        }
+        bo_sync();
+    }
+    int it = 0;
     for (;;) {
-        const float sp = sp_next;
-        pv_next++;
-        sp_next = e.sqrt_lut[pv_next <= e.c.S + 1 ? pv_next : e.c.S + 1];
+        if (it - win_base >= BO_BURST_WIN) {  // wave-uniform: refill the windows
+            win_base = it;
+            const int idx_max = e.c.S + 1;
+            bo_sync();
+            for (int t = lane; t < BO_BURST_LEVELS * BO_BURST_WIN; t += 64) {
+                const int k = t / BO_BURST_WIN, i = t % BO_BURST_WIN;
+                const int p = (k == 0 ? nv[0] : nv[k - 1]) + 1 + i;  // nv[] already counts the simulations applied so far
+                lds_lut[t] = e.sqrt_lut[p <= idx_max ? p : idx_max];
+            }
+            bo_sync();
+        }
+        const float sp = lds_lut[grp * BO_BURST_WIN + (it - win_base)];
+        it++;
         // ---- apply one terminal simulation (MCTSNode.update along the path, mcts.py:120-144) ----
         if (have && j == my_chosen) {
             const float val = ((d - (grp + 1)) & 1) ? -v_cur : v_cur;  // the leaf sees v, its parent -v, ...
@@ -409,12 +427,8 @@ BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, 
         }
 #pragma unroll
         for (int k = 0; k <= BO_BURST_LEVELS; k++) nv[k] += k <= d ? 1 : 0;
-        {
-            const float val = (d & 1) ? -v_cur : v_cur;
-            const float dd = val - rootq;
-            const float ee = dd / (float)nv[0];
-            rootq = rootq + ee;
-        }
+        // (the root's own q_value is not maintained here: nothing reads it -- select_child scores children only, the
+        //  reference keeps it as a Python float that no code path looks at)
         done++;
         if (done >= sims_left) break;
         // ---- re-evaluate the descent from the registers (select_child at every level of the path) ----
@@ -454,7 +468,7 @@ BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, 
     }
     // ---- write the path back ----
     if (have) { e.n_visits[no + my_fc + j] = cn; e.q[no + my_fc + j] = cq; }
-    if (lane == 0) { e.n_visits[no] = nv[0]; e.q[no] = rootq; }
+    if (lane == 0) e.n_visits[no] = nv[0];
     bo_sync();
     return done;
 }
@@ -748,7 +762,7 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
             int applied = 1;
             bool small = depth <= BO_BURST_LEVELS;
             for (int k = 0; k < depth && small; k++) small = e.n_children[no + sh.path[k]] <= 16;
-            if (small) applied = terminal_burst(e, g, sh.path, depth, tv, e.c.S - sims);
+            if (small) applied = terminal_burst(e, g, sh.path, depth, tv, e.c.S - sims, sh.probs);
             else backup_run(e, g, leaf, tv, 1, sh.path, &flags);  // deep or wide path: one simulation the general way
             sims += applied;
             if (lane == 0) e.stat_term_sims[g] += applied;

@@ -130,17 +130,27 @@ def all_gather_games(finished: Sequence, device: Optional[torch.device] = None, 
 
 class _Gather:
     """One all-gather in flight: `src` (uint8 / int64, equal length on every rank) -> host array, without a blocking call
-    on the issuing side.  RCCL: H2D, collective and D2H all run on a side stream behind an event; gloo: async work handle."""
+    on the issuing side.  RCCL: H2D, collective and D2H all run on a side stream behind an event, through pinned and
+    device staging buffers that the owner keeps and re-uses (`bufs`, grow-only: pinned allocations are slow); gloo: async
+    work handle."""
 
-    def __init__(self, src: np.ndarray, world: int, group, device: Optional[torch.device], side):
+    def __init__(self, src: np.ndarray, world: int, group, device: Optional[torch.device], side, bufs: Optional[dict] = None):
         import torch.distributed as dist
 
         self.n, self.world = src.size, world
+        tdt = torch.from_numpy(src[:0]).dtype
         if device is not None:  # backend nccl (= RCCL over xGMI)
-            self.h_in = torch.from_numpy(src).pin_memory()
-            self.d_in = torch.empty(src.size, dtype=self.h_in.dtype, device=device)
-            self.d_out = torch.empty(world * src.size, dtype=self.h_in.dtype, device=device)
-            self.h_out = torch.empty(world * src.size, dtype=self.h_in.dtype).pin_memory()
+            key = str(tdt)
+            b = bufs.get(key) if bufs is not None else None
+            if b is None or b[0].numel() < src.size:
+                cap = max(64, 2 * src.size)
+                b = (torch.empty(cap, dtype=tdt).pin_memory(), torch.empty(cap, dtype=tdt, device=device),
+                     torch.empty(world * cap, dtype=tdt, device=device), torch.empty(world * cap, dtype=tdt).pin_memory())
+                if bufs is not None:
+                    bufs[key] = b
+            self.h_in, self.d_in = b[0][:src.size], b[1][:src.size]
+            self.d_out, self.h_out = b[2][:world * src.size], b[3][:world * src.size]
+            self.h_in.numpy()[:] = src
             self.event = torch.cuda.Event()
             side.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(side):
@@ -160,6 +170,7 @@ class _Gather:
         return self.event.query() if self.event is not None else self.work.is_completed()
 
     def result(self) -> np.ndarray:
+        """[world, n] view of the staging buffer: consume (copy out) before the next gather of the same dtype starts."""
         if self.event is not None:
             self.event.synchronize()  # already complete when a whole exchange period of plies ran in between
         else:
@@ -188,6 +199,7 @@ class PeriodicGameExchange:
         self.device = torch.device(device) if (nccl and device is not None) else None
         self.side = torch.cuda.Stream(self.device) if self.device is not None else None
         self._buf: List[bytes] = []
+        self._bufs: dict = {}   # staging buffers of the size gathers (int64) and of the payload gathers (uint8)
         self._calls = 0
         self._sizes = None      # (payload bytes, _Gather of the sizes)
         self._payload = None    # (sizes list, _Gather of the payload)
@@ -217,12 +229,12 @@ class PeriodicGameExchange:
             if mx > 0:  # every rank sees the same sizes, so every rank takes (or skips) the payload step together
                 pad = np.zeros((mx + 15) // 16 * 16, dtype=np.uint8)
                 pad[:len(payload)] = np.frombuffer(payload, dtype=np.uint8)
-                self._payload = (sizes, _Gather(pad, self.world, self.group, self.device, self.side))
+                self._payload = (sizes, _Gather(pad, self.world, self.group, self.device, self.side, self._bufs))
                 self.n_payload_gathers += 1
         if start_new:
             payload = b"".join(self._buf)
             self._buf = []
-            self._sizes = (payload, _Gather(np.array([len(payload)], dtype=np.int64), self.world, self.group, self.device, self.side))
+            self._sizes = (payload, _Gather(np.array([len(payload)], dtype=np.int64), self.world, self.group, self.device, self.side, self._bufs))
             self.n_size_gathers += 1
         return out
 

@@ -381,3 +381,37 @@ def check_games_from_positions_vs_oracle(backend, plies=5, sims=40, batch=8, sca
             assert np.array_equal(pi.view(np.uint32), gpi.view(np.uint32)), START_FENS[g]
             assert np.array_equal(st, gst), START_FENS[g]
             assert z == gz
+
+
+# ---- long runs of terminal simulations (mcts.py:235-238) -----------------------------------------------------------
+LONG_TERMINAL_RUN_CASES = [
+    ("k7/8/1K6/8/8/8/8/7R w - - 0 1", [], 800, 96),                      # mate in one: hundreds of visits end in the same mated leaf
+    ("7k/5Q2/6K1/8/8/8/8/8 w - - 0 1", [], 1500, 96),                      # several mating moves and stalemating ones side by side
+    ("8/8/4k3/8/8/3K4/8/6R1 w - - 98 80", [], 700, 64),                    # claimable fifty-move draws one ply below the root
+    (O.STARTING_FEN, "g1f3 g8f6 f3g1 f6g8 g1f3 g8f6 f3g1".split(), 600, 96),  # claimable repetitions
+]
+
+
+def check_long_terminal_runs_vs_oracle(backend, case):
+    """Whole trees, pi and best move against the oracle for searches dominated by terminal simulations (the register-resident
+    burst path of the step kernel, including its table-window refills after 256 simulated visits)."""
+    import test_fast_mode_emu as T
+
+    fen, moves, sims, batch = case
+    cfg = dict(num_simulations=sims, batch_size=batch)
+    eng = make_engine(backend, 1, cfg)
+    eng.reset([0], [fen], [" ".join(moves) or None])
+    fn = T.softmax_eval(3, scale=4.0)
+    res = Searcher(backend, eng).search([1], [fn], [np.random.RandomState(5)], 0.1)
+    b = O.Board(fen)
+    trk = O.PyTracker(); trk.add_board(b)
+    for u in moves:
+        b.push(u); trk.add_board(b)
+    pos = b.positions()
+    r = O.run_mcts(b, pos[max(0, len(pos) - 8):-1], trk, fn, np.random.RandomState(5), O.default_config(**cfg))
+    assert r["n_terminal_sims"] >= sims // 2, r["n_terminal_sims"]   # the case does exercise long terminal runs
+    assert E.move_to_uci(int(res["best_move"][0])) == O.move_to_uci(r["best"])
+    assert np.array_equal(dense_pi(res, 0).view(np.uint32), r["pi"].view(np.uint32))
+    exp = {"/".join(k): list(v) for k, v in O.canonical_tree(r["nodes"]).items()}
+    assert canonical_tree(eng.debug_tree(0)) == exp
+    assert int(eng.status()["term_sims"][0]) == r["n_terminal_sims"]

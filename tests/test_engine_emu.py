@@ -53,3 +53,8 @@ def test_search_configuration_sweep_matches_oracle(backend, cfg):
 
 def test_games_from_special_start_positions_match_oracle(backend):
     EC.check_games_from_positions_vs_oracle(backend)
+
+
+@pytest.mark.parametrize("case", EC.LONG_TERMINAL_RUN_CASES, ids=lambda c: f"{c[0].split()[0][:12]}-{c[2]}")
+def test_long_runs_of_terminal_simulations_match_oracle(backend, case):
+    EC.check_long_terminal_runs_vs_oracle(backend, case)
