@@ -5,7 +5,7 @@
 #include "../../include/betaone_engine.h"
 
 #include "bo_tree.h"
-#include "bo_fast.h"
+#include "bo_fastw.h"
 #include "bo_select_wide.h"
 #include "bo_nn_fused.h"
 #include "bo_conv.h"
@@ -33,7 +33,15 @@ static int fail(int code, const std::string &msg) {
 
 struct bo_engine {
     Eng d;
-    FastEng f;
+    FastW f;
+    int fast_reuse = 1;  // keep the played child's subtree for the next search (bo_fast_options)
+    // optional timing of the fast mode's select + backup kernel with HIP events on the launch stream (bo_fast_stats)
+    int sel_profile = 0, sel_pending = 0;
+    long long sel_launches = 0;
+    double sel_ms = 0.0;
+#if !defined(BO_WAVE_EMU)
+    hipEvent_t sel_ev0 = nullptr, sel_ev1 = nullptr;
+#endif
     bool fast = false;
     bo_config cfg;
     int device;
@@ -190,7 +198,8 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
         const double r = (double)(int)(cfg->widen_coeff * sqrt((double)k)) / (double)k;
         if (r > per_sim) per_sim = r;
     }
-    c.NCAP = fast ? 1 + (c.S + cfg->leaves_per_step + 1) * 64 : (int)ceil(c.S * per_sim) + 2 * root_m + 4;
+    // (fast mode keeps its trees in child-block arenas, bo_fastw.h; the node arrays below then only hold the root's slot)
+    c.NCAP = fast ? 2 : (int)ceil(c.S * per_sim) + 2 * root_m + 4;
     c.PLY_CAP = cfg->max_plies; c.TRK_CAP = cfg->max_plies;
     c.UL_MAX = fast ? 1 : c.B; c.CH_MAX = ch_max < 1 ? 1 : ch_max;
     c.cpuct = (float)cfg->cpuct;
@@ -231,14 +240,34 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
     rc |= e->alloc(&d.root_child_rank, G * 2 * BO_CH_CAP); rc |= e->alloc(&d.noise, G * BO_MAX_MOVES);
     rc |= e->alloc(&d.played, G * c.PLY_CAP);
     rc |= e->alloc(&d.prof, G * 10);
+    d.played_now = nullptr;
     if (fast) {
-        FastEng &f = e->f;
+        FastW &f = e->f;
         const size_t L = (size_t)cfg->leaves_per_step;
         f.L = (int)L;
-        rc |= e->alloc(&f.n_rows, G); rc |= e->alloc(&f.n_step_sims, G);
-        rc |= e->alloc(&f.row_leaf, G * L); rc |= e->alloc(&f.row_nlegal, G * L); rc |= e->alloc(&f.row_moves, G * L * BO_MAX_MOVES);
-        rc |= e->alloc(&f.sim_row, G * L); rc |= e->alloc(&f.sim_plen, G * L); rc |= e->alloc(&f.sim_path, G * L * BO_FAST_PATH_CAP);
-        if (!rc) { rt_memset(f.n_rows, 0, G * 4, nullptr); rt_memset(f.n_step_sims, 0, G * 4, nullptr); }
+        // Arena capacity per game, in 512-byte child blocks.  A search creates at most S + L + 1 runs (one per expanded
+        // node; a run is 1..7 blocks, 2 on average in chess: ~35 legal moves) on top of the subtree kept from the previous
+        // search, which re-rooting admits only up to KEEP blocks: NB = KEEP + 4 blocks per possible expansion.  A run that
+        // still does not fit is refused (status bit) -- the search goes on with that leaf unexpanded.
+        const size_t expansions = (size_t)c.S + L + 2;
+        f.NB = (int)(2 * expansions + 4 * expansions + 8);
+        const size_t NB = (size_t)f.NB;
+        for (int a = 0; a < 2; a++) {
+            rc |= e->alloc(&f.arena[a], G * NB * BO_FW_C); rc |= e->alloc(&f.amove[a], G * NB * BO_FW_C); rc |= e->alloc(&f.bpos[a], G * NB);
+        }
+        rc |= e->alloc(&f.cur, G); rc |= e->alloc(&f.top, G); rc |= e->alloc(&f.n_rows, G); rc |= e->alloc(&f.n_step, G);
+        rc |= e->alloc(&f.played_now, G); rc |= e->alloc(&f.stat_blocks, G); rc |= e->alloc(&f.stat_path_nodes, G);
+        rc |= e->alloc(&f.row_slot, G * L); rc |= e->alloc(&f.row_prun, G * L); rc |= e->alloc(&f.row_nlegal, G * L);
+        rc |= e->alloc(&f.row_term, G * L); rc |= e->alloc(&f.row_sim, G * L); rc |= e->alloc(&f.row_pos, G * L);
+        rc |= e->alloc(&f.row_moves, G * L * BO_MAX_MOVES);
+        rc |= e->alloc(&f.sim_row, G * L); rc |= e->alloc(&f.sim_plen, G * L); rc |= e->alloc(&f.sim_path, G * L * BO_FW_PATH_CAP);
+        if (!rc) {
+            int *zero[] = {f.cur, f.top, f.n_rows, f.n_step, f.played_now};
+            for (int *p : zero) rt_memset(p, 0, G * 4, nullptr);
+            rt_memset(f.stat_blocks, 0, G * 8, nullptr); rt_memset(f.stat_path_nodes, 0, G * 8, nullptr);
+            rt_memset(f.row_term, 0, G * L * 4, nullptr); rt_memset(f.row_nlegal, 0, G * L * 4, nullptr);
+            d.played_now = f.played_now;
+        }
     }
     if (rc) { bo_engine_destroy(e); return fail(BO_E_HIP, "device allocation failed"); }
     // host-built lookup tables: Python's math.sqrt / int() in double, rounded to binary32 once
@@ -266,6 +295,9 @@ extern "C" void bo_engine_destroy(bo_engine *e) {
     rt_set_device(e->device);
     for (void *p : e->allocs) rt_free(p);
     rt_host_free(e->h_res); rt_host_free(e->h_info); rt_host_free(e->h_noise); rt_host_free(e->h_go);
+#if !defined(BO_WAVE_EMU)
+    if (e->sel_ev0) { (void)hipEventDestroy(e->sel_ev0); (void)hipEventDestroy(e->sel_ev1); }
+#endif
     delete e;
 }
 
@@ -331,6 +363,7 @@ extern "C" int bo_games_reset_ex(bo_engine *e, int n, const int32_t *slots, cons
         a.slots = d_slots; a.start = d_start; a.moves = d_mv; a.n_moves = d_nm; a.max_moves = (int)max_moves;
         a.hist = d_hh; a.n_hist = d_nh; a.trk = d_tt; a.trk_cnt = d_tc; a.n_trk = d_nt; a.max_trk = (int)max_trk;
         rc = RT_LAUNCH(bo_k_setup, n, stream, e->d, a);
+        if (!rc && e->fast) rc = RT_LAUNCH(bo_k_fw_reset, n, stream, e->d, e->f, (const int *)d_slots);
     }
     int rc2 = rt_sync(stream);
     for (void *p : tmp) rt_free(p);
@@ -382,7 +415,7 @@ static int search_begin_impl(bo_engine *e, const int32_t *go, const double *nois
         if (rc) return rc;
     }
     e->nl_valid = false;
-    if (e->fast) RT(RT_LAUNCH(bo_k_fast_search_begin, e->d.c.G, stream, e->d, e->f, (const int *)e->d_go, nn_in_dev));
+    if (e->fast) RT(RT_LAUNCH(bo_k_fw_search_begin, e->d.c.G, stream, e->d, e->f, (const int *)e->d_go, nn_in_dev));
     else RT(RT_LAUNCH(bo_k_search_begin, e->d.c.G, stream, e->d, (const int *)e->d_go, nn_in_dev));
     return BO_OK;
 }
@@ -395,8 +428,29 @@ extern "C" int bo_step(bo_engine *e, const float *policy_dev, const float *value
                        void *stream) {
     if (!e || !nn_in_dev) return fail(BO_E_ARG, "null argument");
     if (policy_kind != BO_POLICY_NONE && (!policy_dev || !value_dev)) return fail(BO_E_ARG, "policy/value required");
-    if (e->fast) RT(RT_LAUNCH(bo_k_fast_step, e->d.c.G, stream, e->d, e->f, policy_dev, value_dev, policy_kind, nn_in_dev));
-    else RT(RT_LAUNCH(bo_k_step, e->d.c.G, stream, e->d, policy_dev, value_dev, policy_kind, nn_in_dev));
+    if (e->fast) {  // apply (one wave per row) -> backup + select (one wave per game) -> leaf positions and planes (one wave per row)
+        const int rows = e->d.c.G * e->f.L;
+        if (policy_kind != BO_POLICY_NONE) RT(RT_LAUNCH(bo_k_fw_apply, rows, stream, e->d, e->f, policy_dev, policy_kind));
+#if !defined(BO_WAVE_EMU)
+        if (e->sel_profile) {  // eager launches only (events recorded during a graph capture would become graph nodes)
+            if (!e->sel_ev0) { RT((int)hipEventCreate(&e->sel_ev0)); RT((int)hipEventCreate(&e->sel_ev1)); }
+            if (e->sel_pending) {
+                float ms = 0.0f;
+                RT((int)hipEventSynchronize(e->sel_ev1));
+                RT((int)hipEventElapsedTime(&ms, e->sel_ev0, e->sel_ev1));
+                e->sel_ms += ms; e->sel_launches++; e->sel_pending = 0;
+            }
+            RT((int)hipEventRecord(e->sel_ev0, (hipStream_t)stream));
+        }
+#endif
+        RT(RT_LAUNCH(bo_k_fw_select, e->d.c.G, stream, e->d, e->f, value_dev, policy_kind));
+#if !defined(BO_WAVE_EMU)
+        if (e->sel_profile) { RT((int)hipEventRecord(e->sel_ev1, (hipStream_t)stream)); e->sel_pending = 1; }
+#endif
+        RT(RT_LAUNCH(bo_k_fw_leaf, rows, stream, e->d, e->f, nn_in_dev));
+    } else {
+        RT(RT_LAUNCH(bo_k_step, e->d.c.G, stream, e->d, policy_dev, value_dev, policy_kind, nn_in_dev));
+    }
     return BO_OK;
 }
 
@@ -438,7 +492,7 @@ extern "C" int bo_search_result(bo_engine *e, int32_t *res_n, int32_t *res_idx, 
                                 int32_t *best_move, int32_t *total_visits, void *stream) {
     if (!e) return fail(BO_E_ARG, "null engine");
     const size_t G = (size_t)e->d.c.G;
-    if (e->fast) RT(RT_LAUNCH(bo_k_fast_result, e->d.c.G, stream, e->d));
+    if (e->fast) RT(RT_LAUNCH(bo_k_fw_result, e->d.c.G, stream, e->d, e->f));
     else RT(RT_LAUNCH(bo_k_result, e->d.c.G, stream, e->d));
     RT(rt_d2h(e->h_res, e->d_res_blk, G * (4 + 2 * (size_t)BO_RES_CAP) * 4, stream));  // the whole result block in one copy
     RT(rt_sync(stream));
@@ -456,6 +510,7 @@ extern "C" int bo_play(bo_engine *e, const int32_t *action, void *stream) {
     if (!e || !action) return fail(BO_E_ARG, "null argument");
     RT(rt_h2d(e->d_action, action, (size_t)e->d.c.G * 4, stream));
     RT(RT_LAUNCH(bo_k_play, e->d.c.G, stream, e->d, (const int *)e->d_action));
+    if (e->fast) RT(RT_LAUNCH(bo_k_fw_reroot, e->d.c.G, stream, e->d, e->f, e->fast_reuse));  // tree reuse: the played child becomes the root
     return BO_OK;
 }
 
@@ -695,6 +750,41 @@ extern "C" int bo_debug_tree(bo_engine *e, int slot, bo_node *out, int32_t cap, 
     int nn = 0;
     RT(rt_d2h(&nn, e->d.n_nodes + slot, 4, stream));
     RT(rt_sync(stream));
+    if (e->fast) {  // child-block arena (bo_fastw.h): nodes in breadth-first order, children in record order
+        const FastW &f = e->f;
+        int cur = 0, top = 0;
+        RT(rt_d2h(&cur, f.cur + slot, 4, stream)); RT(rt_d2h(&top, f.top + slot, 4, stream));
+        RT(rt_sync(stream));
+        std::vector<WRec> A((size_t)top * BO_FW_C);
+        std::vector<bo_mv> M((size_t)top * BO_FW_C);
+        RT(rt_d2h(A.data(), f.arena[cur] + (size_t)slot * f.NB * BO_FW_C, A.size() * sizeof(WRec), stream));
+        RT(rt_d2h(M.data(), f.amove[cur] + (size_t)slot * f.NB * BO_FW_C, M.size() * sizeof(bo_mv), stream));
+        RT(rt_sync(stream));
+        std::vector<bo_node> nodes;
+        std::vector<int> rec;  // record id of each node
+        auto push = [&](int r, int parent) {
+            bo_node nd;
+            nd.parent = parent; nd.n_visits = A[r].n; nd.first_child = 0; nd.n_children = 0; nd.q_value = A[r].w; nd.prior = A[r].prior;
+            nd.move = r == 0 ? 0 : M[r];
+            nd.terminal = A[r].link == FW_MATE ? 1 : A[r].link == FW_DRAW ? 2 : A[r].link >= 0 ? 0 : -1;
+            nodes.push_back(nd); rec.push_back(r);
+        };
+        push(0, -1);
+        for (size_t i = 0; i < nodes.size(); i++) {
+            const int link = A[rec[i]].link;
+            if (link < 0) continue;
+            const int first = link & BO_FW_LINK_MASK, nb = ((link >> 24) & 7) + 1;
+            if ((size_t)(first + nb) * BO_FW_C > A.size()) return fail(BO_E_HIP, "corrupt child-block link");
+            nodes[i].first_child = (int)nodes.size();
+            for (int k = 0; k < nb * BO_FW_C; k++)
+                if (A[(size_t)first * BO_FW_C + k].n >= 0) { push(first * BO_FW_C + k, (int)i); nodes[i].n_children++; }
+        }
+        *n_nodes = (int)nodes.size();
+        if (!out) return BO_OK;
+        if ((int)nodes.size() > cap) return fail(BO_E_ARG, "tree buffer too small");
+        memcpy(out, nodes.data(), nodes.size() * sizeof(bo_node));
+        return BO_OK;
+    }
     *n_nodes = nn;
     if (!out) return BO_OK;
     if (nn > cap) return fail(BO_E_ARG, "tree buffer too small");
@@ -711,6 +801,39 @@ extern "C" int bo_debug_tree(bo_engine *e, int slot, bo_node *out, int32_t cap, 
     for (size_t i = 0; i < N; i++) {
         out[i].parent = pa[i]; out[i].n_visits = nv[i]; out[i].first_child = fc[i]; out[i].n_children = nc[i];
         out[i].q_value = q[i]; out[i].prior = pr[i]; out[i].move = mv[i]; out[i].terminal = tm[i];
+    }
+    return BO_OK;
+}
+
+extern "C" int bo_fast_options(bo_engine *e, int32_t tree_reuse) {
+    if (!e) return fail(BO_E_ARG, "null engine");
+    if (!e->fast) return fail(BO_E_CONFIG, "bo_fast_options: fast-mode engines only");
+    e->fast_reuse = tree_reuse ? 1 : 0;
+    return BO_OK;
+}
+
+extern "C" int bo_fast_stats(bo_engine *e, uint64_t *blocks_read, uint64_t *path_nodes, int32_t *arena_blocks, int32_t time_select, double *select_ms,
+                             int64_t *select_launches, void *stream) {
+    if (!e) return fail(BO_E_ARG, "null engine");
+    if (!e->fast) return fail(BO_E_CONFIG, "bo_fast_stats: fast-mode engines only");
+    const size_t G = (size_t)e->d.c.G;
+    if (blocks_read) RT(rt_d2h(blocks_read, e->f.stat_blocks, G * 8, stream));
+    if (path_nodes) RT(rt_d2h(path_nodes, e->f.stat_path_nodes, G * 8, stream));
+    if (arena_blocks) RT(rt_d2h(arena_blocks, e->f.top, G * 4, stream));
+    RT(rt_sync(stream));
+#if !defined(BO_WAVE_EMU)
+    if (e->sel_pending) {
+        float ms = 0.0f;
+        RT((int)hipEventSynchronize(e->sel_ev1));
+        RT((int)hipEventElapsedTime(&ms, e->sel_ev0, e->sel_ev1));
+        e->sel_ms += ms; e->sel_launches++; e->sel_pending = 0;
+    }
+#endif
+    if (select_ms) *select_ms = e->sel_ms;
+    if (select_launches) *select_launches = e->sel_launches;
+    if (time_select >= 0) {
+        if (time_select && !e->sel_profile) { e->sel_ms = 0.0; e->sel_launches = 0; }
+        e->sel_profile = time_select ? 1 : 0;
     }
     return BO_OK;
 }

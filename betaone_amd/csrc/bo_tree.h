@@ -80,6 +80,7 @@ struct Eng {
     // search results
     int *res_n, *res_idx, *res_best_idx, *res_best_mv, *res_total;
     float *res_val;
+    int *played_now;                  // [G] or NULL: bo_k_play notes the move it played (0: refused) -- read by the fast mode's re-rooting
     unsigned long long *prof;         // [G][10] cycles: apply, select, first-visit (movegen+draw rules), terminal backups, encode, flush, total; steps,
                                       // loop iterations, first visits.  profile = N > 1 counts only game-steps longer than N cycles
 };
@@ -150,8 +151,26 @@ struct ChainBuf {
     unsigned long long hash[BO_CHAIN_CAP];
     int ref[BO_CHAIN_CAP];  // node index (>= 0) or -1 - ply of the game history
 };
-BO_DEV DPos chain_entry(const Eng &e, int g, int ref) {
-    return ref >= 0 ? e.npos[NOFF(e, g) + ref] : e.gpos[(size_t)g * e.c.PLY_CAP + (-1 - ref)];
+// ref >= 0: index into the caller's array of tree positions; ref < 0: ply -1 - ref of the game's position stack
+BO_DEV DPos chain_entry(const Eng &e, int g, const DPos *tree_pos, int ref) {
+    return ref >= 0 ? tree_pos[ref] : e.gpos[(size_t)g * e.c.PLY_CAP + (-1 - ref)];
+}
+// the game-history part of a chain (entries ply-1 .. J, J = last irreversible ply): found and read by all lanes at once
+BO_DEV int chain_collect_history(const Eng &e, int g, ChainBuf &cb, int cnt) {
+    const DPos *gp = e.gpos + (size_t)g * e.c.PLY_CAP;
+    const int lane = bo_lane(), ply = e.ply[g];
+    int J = 0;  // largest j in [1, ply] whose position was reached by an irreversible move, else 0
+    for (int base = ply; base > 0; base -= 64) {
+        const int j = base - lane;
+        const bool irr = j > 0 && (gp[j].flags & F_IRREV);
+        const unsigned long long m = bo_ballot(irr);
+        if (m) { J = base - __builtin_ctzll(m); break; }
+    }
+    const int nh = ply - J;  // entries ply-1 .. J
+    for (int i = lane; i < nh; i += 64) {
+        if (cnt + i < BO_CHAIN_CAP) { const int j = ply - 1 - i; cb.hash[cnt + i] = gp[j].khash; cb.ref[cnt + i] = -1 - j; }
+    }
+    return cnt + nh;
 }
 // Collects (transposition hash, reference) of every chain entry into LDS and returns their number.  The in-tree part
 // follows parent links (a few levels); the game-history part -- up to ~100 plies in drawn-out endgames, the tail
@@ -168,37 +187,26 @@ BO_DEV int chain_collect(const Eng &e, int g, int leaf, ChainBuf &cb) {
         if (lane == 0 && cnt < BO_CHAIN_CAP) { cb.hash[cnt] = e.npos[no + x].khash; cb.ref[cnt] = x; }
         cnt++;
     }
-    if (!stop) {
-        const DPos *gp = e.gpos + (size_t)g * e.c.PLY_CAP;
-        const int ply = e.ply[g];
-        int J = 0;  // largest j in [1, ply] whose position was reached by an irreversible move, else 0
-        for (int base = ply; base > 0; base -= 64) {
-            const int j = base - lane;
-            const bool irr = j > 0 && (gp[j].flags & F_IRREV);
-            const unsigned long long m = bo_ballot(irr);
-            if (m) { J = base - __builtin_ctzll(m); break; }
-        }
-        const int nh = ply - J;  // entries ply-1 .. J
-        for (int i = lane; i < nh; i += 64) {
-            if (cnt + i < BO_CHAIN_CAP) { const int j = ply - 1 - i; cb.hash[cnt + i] = gp[j].khash; cb.ref[cnt + i] = -1 - j; }
-        }
-        cnt += nh;
-    }
+    if (!stop) cnt = chain_collect_history(e, g, cb, cnt);
     bo_sync();
     return cnt;
 }
 
-// Board.outcome(claim_draw=True) of node `leaf` whose legal moves are mv[0..n): 0 ongoing, 1 mate, 2 draw
-BO_DEV int terminal_eval(const Eng &e, int g, int leaf, const DPos &P, const bo_mv *mv, int n, bool in_check, bo_mv *scratch, ChainBuf &cb) {
+// Board.outcome(claim_draw=True) of a position P whose legal moves are mv[0..n): 0 ongoing, 1 mate, 2 draw.  `collect()`
+// fills cb with the positions python-chess would revisit (the chain back to the last irreversible move) and returns their
+// number; it is only called when the cheap rules have not decided; tree_pos = base of the refs >= 0 it stores.
+template <class CollectFn>
+BO_DEV int terminal_eval_with(const Eng &e, int g, const DPos *tree_pos, const DPos &P, const bo_mv *mv, int n, bool in_check, bo_mv *scratch,
+                              ChainBuf &cb, CollectFn collect) {
     if (n == 0 && in_check) return 1;
     if (insufficient_material(P)) return 2;
     if (n == 0) return 2;
     if (P.halfmove >= 150) return 2;
-    const int npred = chain_collect(e, g, leaf, cb);
+    const int npred = collect();
     const int nn = npred < BO_CHAIN_CAP ? npred : BO_CHAIN_CAP;
     int same = 0;
     for (int i = bo_lane(); i < nn; i += 64)
-        if (cb.hash[i] == P.khash && key_equal(chain_entry(e, g, cb.ref[i]), P)) same++;
+        if (cb.hash[i] == P.khash && key_equal(chain_entry(e, g, tree_pos, cb.ref[i]), P)) same++;
     const int self = 1 + bo_wave_sum(same);
     if (self >= 5) return 2;
     if (P.halfmove >= 100) return 2;
@@ -224,12 +232,17 @@ BO_DEV int terminal_eval(const Eng &e, int g, int leaf, const DPos &P, const bo_
             if (act) c = make_move(P, m);
             int cc = 0;
             for (int i = 0; i < nn; i++)
-                if (act && cb.hash[i] == c.khash && key_equal(chain_entry(e, g, cb.ref[i]), c)) cc++;
+                if (act && cb.hash[i] == c.khash && key_equal(chain_entry(e, g, tree_pos, cb.ref[i]), c)) cc++;
             if (bo_ballot(act && cc >= 2)) hit = true;
         }
         if (hit) return 2;
     }
     return 0;
+}
+
+// the same for node `leaf` of the reference-semantics tree (chain through the parent links)
+BO_DEV int terminal_eval(const Eng &e, int g, int leaf, const DPos &P, const bo_mv *mv, int n, bool in_check, bo_mv *scratch, ChainBuf &cb) {
+    return terminal_eval_with(e, g, e.npos + NOFF(e, g), P, mv, n, in_check, scratch, cb, [&]() { return chain_collect(e, g, leaf, cb); });
 }
 
 // tracker.repetitions(board) = max(0, count - 1)   (utils.py:91-99)
@@ -983,12 +996,14 @@ BO_KERNEL void bo_k_play(Eng e, const int *action) {
         ok = ok || bo_ballot(j < n && mv[j] == m) != 0;
         best_ok = best_ok || bo_ballot(j < n && mv[j] == best) != 0;
     }
+    if (e.played_now && lane == 0) e.played_now[g] = 0;
     if (!ok) {  // self_play.py:142-167
         if (best != m && best_ok) m = best;
         else { if (lane == 0) { e.status[g] |= ST_ILLEGAL_ACTION; e.phase[g] = PH_IDLE; } return; }
     }
     if (ply + 1 >= e.c.PLY_CAP || tn >= e.c.TRK_CAP) { if (lane == 0) e.status[g] |= ST_PLY_OVERFLOW; return; }
     if (lane == 0) {
+        if (e.played_now) e.played_now[g] = m;
         const DPos c = make_move(P, m);
         gp[ply + 1] = c;
         e.played[(size_t)g * e.c.PLY_CAP + ply] = m;

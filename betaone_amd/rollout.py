@@ -91,7 +91,9 @@ class Rollout:
         # fast=True: csrc/bo_fast.h (virtual loss, L leaves per game per step) -- NOT the reference's search semantics
         self.fast, self.L = bool(fast), self.eng.L
         self.nn_in = torch.zeros((self.G * self.L, E.INPUT_CHANNELS, 8, 8), dtype=torch.float32, device=self.device)
-        self.expected_evals = 1 + math.ceil(self.S / (self.L if self.fast else self.B))
+        # evaluations per search before the first poll: reference semantics = root + one per batch; fast mode = one per L
+        # simulations (a root kept from the previous search needs no evaluation of its own; a fresh one costs one more round)
+        self.expected_evals = math.ceil(self.S / self.L) if self.fast else 1 + math.ceil(self.S / self.B)
         self.games: List[Optional[GameState]] = [None] * self.G
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
         self._graph = None
@@ -336,8 +338,9 @@ class Rollout:
         want_next = self._active & ((self._plies + go) < self.max_game_moves)     # the next call's `want`
         self.host_seconds += time.perf_counter() - t0
         # one native call: sample the moves, play them, begin the next searches (root info, Dirichlet noise, root planes)
+        # (fast mode mixes the noise into a kept root's priors when the search begins, so its draws cannot be deferred)
         out, begun = eng.selfplay_turn(go, move_number, self.temperature, self._out, want_next.astype(np.int32), self.nn_in.data_ptr(), stream,
-                                       defer_noise=True)
+                                       defer_noise=not self.fast)
         t0 = time.perf_counter()
         actions = out["action"]
         if begun is None:  # rare: a pi not sparse enough for the native sampler -- nothing was played
@@ -350,7 +353,7 @@ class Rollout:
                 eng.rng_set_state(int(g), rs.get_state())
             eng.play(actions, stream)
         else:
-            self._begun, self._begun_want, self._noise_pending = begun, want_next.copy(), True
+            self._begun, self._begun_want, self._noise_pending = begun, want_next.copy(), not self.fast
         k = max(1, int(out["n"].max()))
         self._hist[self._step] = (out["n"].copy(), out["idx"][:, :k].copy(), out["val"][:, :k].copy())
         self._step += 1

@@ -193,6 +193,18 @@ typedef struct {
     int32_t terminal;  /* -1 never visited as leaf, 0 no, 1 mate, 2 draw */
 } bo_node;
 int bo_debug_tree(bo_engine *e, int slot, bo_node *out, int32_t cap, int32_t *n_nodes, void *stream);
+/* FAST mode (cfg.mode = 1; NOT the reference's semantics): tree_reuse != 0 (default) keeps the
+ * played child's subtree as the next search's tree -- the reference rebuilds the tree every move (mcts.py:176). */
+int bo_fast_options(bo_engine *e, int32_t tree_reuse);
+/* FAST mode, per game [G]: 512-byte child blocks read by PUCT descents so far (x 512 = bytes the select path moved), path
+ * nodes written by virtual loss + backup (x 16 B; with 12 B x children_scanned + 8 B x levels of bo_engine_status these are
+ * the algorithmic bytes of SURVEY.md section 8d), blocks in use in the game's arena. */
+int bo_fast_stats(bo_engine *e, uint64_t *blocks_read, uint64_t *path_nodes, int32_t *arena_blocks, int32_t time_select, double *select_ms,
+                  int64_t *select_launches, void *stream);
+/* time_select: 1 / 0 switches timing of the select + backup kernel (bo_k_fw_select) with HIP events on its launch stream
+ * on / off for the following EAGER bo_step calls (not while the stream is being captured), -1 leaves it as it is;
+ * select_ms / select_launches return the time and the number of launches accumulated since it was switched on.  Any out
+ * pointer may be NULL.  Synchronises. */
 /* per game [G]: status bits, NN evaluations, flushes, terminal simulations, tree levels descended,
  * children scanned by the PUCT select (the last two give the select kernel's algorithmic bytes). */
 int bo_engine_status(bo_engine *e, int32_t *status, int32_t *evals, int32_t *flushes, int32_t *term_sims,

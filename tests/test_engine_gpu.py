@@ -332,26 +332,51 @@ def test_full_size_config_parity_with_real_net(backend):
 
 
 def test_fast_mode_kernels_on_gpu_match_numpy_restatement(backend):
-    """FAST search mode (csrc/bo_fast.h) on the product library: same trees as tests/fast_reference.py, bit for bit."""
+    """FAST search mode (csrc/bo_fastw.h: child-block arenas, virtual loss) on the product library: same trees as
+    tests/fast_reference.py, bit for bit."""
     import test_fast_mode_emu as T
     from betaone_amd import engine as E
-    from fast_reference import fast_search
-    from oracle import oracle as O
+    from fast_reference import canonical_from_engine
 
-    for fen, moves, sims, L in T.CASES[:3]:
+    for fen, moves, sims, L in T.CASES:
         fn = T.softmax_eval(7)
         eng, noise, _ = T.run_engine_search("hip", fen, moves, sims, L, fn, seed=3)
-        got = eng.debug_tree(0)
-        b = O.Board(fen)
-        trk = O.PyTracker(); trk.add_board(b)
-        for u in moves:
-            b.push(u); trk.add_board(b)
-        pos = b.positions()
-        ref = fast_search(b, pos[max(0, len(pos) - 8):-1], trk, fn, noise[0], sims, L)
-        assert len(got) == len(ref)
-        for g, r in zip(got, ref):
-            assert g["n"] == r.n and np.float32(g["q"]).view(np.uint32) == np.float32(r.w).view(np.uint32)
-            assert np.float32(g["prior"]).view(np.uint32) == np.float32(r.prior).view(np.uint32)
+        ref = T.reference_for(fen, moves, fn, sims, L)
+        ref.search(noise[0])
+        assert canonical_from_engine(eng.debug_tree(0), E.move_to_uci) == ref.canonical(), fen
+        st = eng.status()
+        assert int(st["evals"][0]) == ref.n_evals and int(st["term_sims"][0]) == ref.n_term_sims
+
+
+def test_fast_mode_tree_reuse_on_gpu_matches_numpy_restatement(backend):
+    """Tree reuse between moves on the product library: after every search the played child's subtree is compacted into the
+    game's other arena and becomes the next tree; six plies, trees compared with the restatement after every search and
+    after every re-rooting."""
+    import test_fast_mode_emu as T
+    from betaone_amd import engine as E
+    from fast_reference import canonical_from_engine
+    from oracle import oracle as O
+
+    fen, moves, sims, L = O.STARTING_FEN, "e2e4 c7c5 g1f3".split(), 256, 16
+    fn = T.softmax_eval(9)
+    eng = E.Engine(1, num_simulations=sims, dirichlet_alpha=0.1, fast=True, leaves_per_step=L, max_plies=256)
+    eng.reset([0], [fen], [" ".join(moves)])
+    ref = T.reference_for(fen, moves, fn, sims, L)
+    rng, bufs, carried = np.random.RandomState(2), None, 0
+    for ply in range(6):
+        nl, term, _ = eng.root_info()
+        assert term[0] == 0
+        noise = np.zeros((1, E.MAX_LEGAL))
+        noise[0, :nl[0]] = rng.dirichlet([0.1] * int(nl[0]))
+        carried = max(carried, eng.debug_tree(0)[0]["n"])
+        _, bufs = T.drive_search("hip", eng, 1, L, fn, noise, bufs)
+        ref.search(noise[0])
+        assert canonical_from_engine(eng.debug_tree(0), E.move_to_uci) == ref.canonical(), ply
+        best = E.move_to_uci(int(eng.result()["best_move"][0]))
+        eng.play(np.array([-2], dtype=np.int32))
+        ref.play(best)
+        assert canonical_from_engine(eng.debug_tree(0), E.move_to_uci) == ref.canonical(), ("re-rooted", ply)
+    assert carried > 1
 
 
 def test_fast_mode_rollout_on_gpu(backend):

@@ -1,5 +1,5 @@
-"""CPU tests of the FAST search mode kernels (csrc/bo_fast.h) under the wave emulator, against the NumPy
-restatement tests/fast_reference.py and against structural invariants."""
+"""CPU tests of the FAST search mode kernels (csrc/bo_fastw.h: child-block arenas, virtual loss, tree reuse) under the wave
+emulator, against the NumPy restatement tests/fast_reference.py and against structural invariants."""
 import numpy as np
 import pytest
 
@@ -7,7 +7,7 @@ import engine_cases as EC
 from betaone_amd import engine as E
 from engine_harness import Buf, emu_call
 from fake_model import fake_logits_values
-from fast_reference import fast_search
+from fast_reference import FastSearcher, canonical_from_engine
 from oracle import oracle as O
 
 
@@ -53,36 +53,88 @@ CASES = [
     ("k7/8/1K6/8/8/8/8/7R w - - 0 1", [], 120, 8),                         # mates in the tree
     (O.STARTING_FEN, "g1f3 g8f6 f3g1 f6g8 g1f3 g8f6".split(), 100, 4),     # claimable repetitions in the tree
     ("8/8/4k3/8/8/3K4/8/6R1 w - - 97 80", [], 60, 8),                      # 50-move claims in the tree
+    ("R6R/3Q4/1Q4Q1/4Q3/2Q4Q/Q4Q2/pp1Q4/kBNN1KB1 w - - 0 1", [], 48, 8),   # 218 legal moves: a root run of 7 child blocks
 ]
+
+
+def reference_for(fen, moves, fn, sims, L, **kw):
+    b = O.Board(fen)
+    trk = O.PyTracker(); trk.add_board(b)
+    for u in moves:
+        b.push(u); trk.add_board(b)
+    return FastSearcher(b, trk, fn, sims, L, **kw)
+
+
+def drive_search(backend, eng, G, L, eval_fn, noise, bufs=None):
+    """One search in every slot of `eng` with an external evaluator (all rows are evaluated; stale rows are ignored)."""
+    nn_in, pol, val = bufs or (Buf(backend, (G * L, 120, 8, 8)), Buf(backend, (G * L, E.NUM_ACTIONS)), Buf(backend, (G * L,)))
+    eng.search_begin([1] * G, noise, nn_in.ptr)
+    kind, steps = E.POLICY_NONE, 0
+    while True:
+        eng.step(pol.ptr, val.ptr, kind, nn_in.ptr)
+        steps += 1
+        running, _, _ = eng.poll()
+        if not running:
+            break
+        p, v = eval_fn(nn_in.numpy())
+        pol.set(p); val.set(v)
+        kind = E.POLICY_PROBS
+        assert steps < 10000
+    eng.check_status()
+    return steps, (nn_in, pol, val)
 
 
 @pytest.mark.parametrize("fen,moves,sims,L", CASES)
 def test_fast_kernels_match_numpy_restatement(fen, moves, sims, L):
     fn = softmax_eval(7)
     eng, noise, _ = run_engine_search("emu", fen, moves, sims, L, fn, seed=3)
-    got = eng.debug_tree(0)
-    b = O.Board(fen)
-    trk = O.PyTracker(); trk.add_board(b)
-    for u in moves:
-        b.push(u); trk.add_board(b)
-    pos = b.positions()
-    ref = fast_search(b, pos[max(0, len(pos) - 8):-1], trk, fn, noise[0], sims, L)
-    assert len(got) == len(ref)
-    for i, (g, r) in enumerate(zip(got, ref)):
-        assert g["n"] == r.n, i
-        assert np.float32(g["q"]).view(np.uint32) == np.float32(r.w).view(np.uint32), (i, g["q"], r.w)
-        assert np.float32(g["prior"]).view(np.uint32) == np.float32(r.prior).view(np.uint32), i
-        assert g["parent"] == r.parent and g["n_children"] == r.nc
-        if i:
-            assert E.move_to_uci(g["move"]) == r.move
+    ref = reference_for(fen, moves, fn, sims, L)
+    ref.search(noise[0])
+    assert canonical_from_engine(eng.debug_tree(0), E.move_to_uci) == ref.canonical()
     res = eng.result()
-    root = ref[0]
-    visits = [ref[root.first + i].n for i in range(root.nc)]
+    visits = [v for _m, v in ref.visits()]
     n = int(res["n"][0])
     assert n == sum(v > 0 for v in visits) and int(res["total"][0]) == sum(visits) == sims
     best = int(np.argmax(visits))
-    assert E.move_to_uci(int(res["best_move"][0])) == ref[root.first + best].move
+    assert E.move_to_uci(int(res["best_move"][0])) == ref.visits()[best][0]
     assert abs(float(res["val"][0, :n].sum()) - 1.0) < 1e-6
+    st = eng.status()
+    assert int(st["evals"][0]) == ref.n_evals and int(st["term_sims"][0]) == ref.n_term_sims
+
+
+@pytest.mark.parametrize("reuse", [True, False])
+def test_fast_tree_reuse_between_moves_matches_restatement(reuse):
+    """Four consecutive searches of one game; after each the most visited move is played and the played child's subtree
+    is the next search's tree (bo_k_fw_reroot: breadth-first compaction into the game's other arena) -- or, with reuse
+    switched off, a fresh root."""
+    fen, moves, sims, L = O.STARTING_FEN, "d2d4 d7d5 c2c4".split(), 96, 8
+    fn = softmax_eval(5)
+    kw = dict(num_simulations=sims, dirichlet_alpha=0.1, fast=True, leaves_per_step=L, max_plies=256)
+    eng = emu_call(E.Engine, 1, **kw)
+    eng.fast_options(tree_reuse=reuse)
+    eng.reset([0], [fen], [" ".join(moves)])
+    ref = reference_for(fen, moves, fn, sims, L, reuse=reuse)
+    rng, bufs, kept = np.random.RandomState(11), None, []
+    for ply in range(4):
+        nl, term, _ = eng.root_info()
+        assert term[0] == 0
+        noise = np.zeros((1, E.MAX_LEGAL))
+        noise[0, :nl[0]] = rng.dirichlet([0.1] * int(nl[0]))
+        kept.append(eng.debug_tree(0)[0]["n"])                      # visits the new root starts with
+        _, bufs = drive_search("emu", eng, 1, L, fn, noise, bufs)
+        ref.search(noise[0])
+        got = canonical_from_engine(eng.debug_tree(0), E.move_to_uci)
+        assert got == ref.canonical(), ply
+        res = eng.result()
+        assert int(res["total"][0]) == sum(v for _m, v in ref.visits()) >= sims
+        best = E.move_to_uci(int(res["best_move"][0]))
+        eng.play(np.array([-2], dtype=np.int32))                    # play res_best_mv; the engine re-roots
+        ref.play(best)
+        after = canonical_from_engine(eng.debug_tree(0), E.move_to_uci)
+        assert after == ref.canonical(), ("after re-rooting", ply)   # the kept subtree, bit for bit (w, priors, states)
+    assert (max(kept[1:]) > 1) == reuse                              # reuse really carried visits over
+    fs = eng.fast_stats()
+    assert fs["blocks_read"][0] > 0 and 1 <= fs["arena_blocks"][0] < eng.cfg.num_simulations * 8
 
 
 def test_fast_mode_invariants_many_games():
