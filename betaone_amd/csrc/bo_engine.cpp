@@ -211,8 +211,8 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
     const size_t G = (size_t)c.G, N = G * (size_t)c.NCAP;
     Eng &d = e->d;
     int rc = 0;
-    float *sq = nullptr; int *wl = nullptr;
-    rc |= e->alloc(&sq, (size_t)c.S + 2); rc |= e->alloc(&wl, (size_t)c.B + 1);
+    float *sq = nullptr, *rcp = nullptr; int *wl = nullptr;
+    rc |= e->alloc(&sq, (size_t)c.S + 2); rc |= e->alloc(&wl, (size_t)c.B + 1); rc |= e->alloc(&rcp, (size_t)c.S + 3);
     int **iscal[] = {&d.sims_done, &d.n_nodes, &d.rows, &d.n_runs, &d.n_ul, &d.req_nlegal, &d.status,
                      &d.trk_n, &d.n_hist, &d.ctx_mode, &d.root_nch, &d.stat_evals,
                      &d.stat_flushes, &d.stat_term_sims, &d.stat_levels, &d.stat_children_scanned, &e->d_go, &e->d_action};
@@ -275,6 +275,10 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
     for (int n = 0; n < c.S + 2; n++) hs[n] = (float)sqrt((double)n + 1e-8);  // mcts.py:93
     std::vector<int> hw((size_t)c.B + 1);
     for (int k = 0; k <= c.B; k++) hw[k] = (int)(cfg->widen_coeff * sqrt((double)k));  // mcts.py:55-57 with n_visits+1 == k
+    std::vector<float> hr((size_t)c.S + 3, 0.0f);
+    for (int n = 1; n < c.S + 3; n++) hr[n] = (float)(1.0 / (double)n);  // RN(1/n): rounding the double quotient again is innocuous (53 >= 2*24+2)
+    rt_h2d(rcp, hr.data(), hr.size() * sizeof(float), nullptr);
+    d.rcp_lut = rcp;
     rt_h2d(sq, hs.data(), hs.size() * sizeof(float), nullptr);
     rt_h2d(wl, hw.data(), hw.size() * sizeof(int), nullptr);
     d.sqrt_lut = sq; d.widen_lut = wl;

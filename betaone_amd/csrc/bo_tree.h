@@ -52,6 +52,7 @@ struct EngCfg {
 struct Eng {
     EngCfg c;
     const float *sqrt_lut;  // [S+2]  f32(math.sqrt(n + 1e-8))
+    const float *rcp_lut;   // [S+3]  RN(1 / n) (entry 0 unused): the divisor table of bo_div_count
     const int *widen_lut;   // [B+1]  int(WIDEN*sqrt(k)) for k rows (0 -> "all legal moves")
     // per game scalars
     int *phase, *sims_done, *n_nodes, *rows, *n_runs, *n_ul, *req_node, *req_nlegal, *status;
@@ -374,8 +375,18 @@ BO_DEV int select_leaf(const Eng &e, int g, int *flags, int *path, int *depth_ou
 // registers, and as long as it reproduces the same path the loop continues.  Returns the number of simulations
 // applied (>= 1); the caller re-selects from memory afterwards.  Bit-identical to backup_run + select_leaf.
 #define BO_BURST_LEVELS 4
-#define BO_BURST_WIN 256  // sqrt-table entries staged in LDS per level and refill (4 levels x 256 floats = 4 KB of the probs buffer)
-BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, int sims_left, float *lds_lut) {
+// x / fn for fn = (float)n, n a small positive integer (a visit count), y = RN(1 / fn) from the host-built table: quotient
+// estimate, exact remainder (fma), one correction (fma) -- the correctly rounded quotient (Markstein's division; it holds
+// whenever the quotient is a normal number: checked against true division on 1.6e9 operand pairs, n <= 4100), in 3
+// operations instead of the ~10 of the general sequence.  Tiny and non-finite quotients take the general division.
+BO_DEV float bo_div_count(float x, float fn, float y) {
+    const float q0 = x * y;
+    const float r = __builtin_fmaf(-fn, q0, x);
+    const float q1 = __builtin_fmaf(r, y, q0);
+    const float a = q0 < 0.0f ? -q0 : q0;
+    return (a >= 1e-30f && a <= 1e30f) ? q1 : x / fn;
+}
+BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, int sims_left, float *lds, bool *staged) {
     const size_t no = NOFF(e, g);
     const int lane = bo_lane(), grp = lane >> 4, j = lane & 15;
     int nv[BO_BURST_LEVELS + 1];  // uniform copies of the path nodes' visit counts
@@ -401,42 +412,39 @@ BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, 
     const int cterm = (have && last && e.n_children[no + my_fc + j] == 0) ? (int)e.term[no + my_fc + j] : -1;
     float v_cur = v;
     int done = 0;
-    // sqrt(parent visits) of this lane's level: every level's count grows by one per simulation, so iteration i of the
-    // burst reads table entry pv0 + i of its level.  A window of BO_BURST_WIN entries per level is staged in LDS by all
-    // lanes at once (one memory round trip per 256 simulations; as a global load per iteration -- even requested one
-    // iteration ahead -- the L2 latency of ~700 cycles bounded every simulated visit: 1 M cycles for an 800-visit burst).
-    int win_base = 0;  // iteration index of lds_lut[grp][0]
-    {
-        const int idx_max = e.c.S + 1;
-        for (int t = lane; t < BO_BURST_LEVELS * BO_BURST_WIN; t += 64) {
-            const int k = t / BO_BURST_WIN, i = t % BO_BURST_WIN;
-            const int p = (k == 0 ? nv[0] : nv[k - 1]) + 1 + i;
-            lds_lut[t] = e.sqrt_lut[p <= idx_max ? p : idx_max];
-        }
+    // Per simulated visit the loop needs sqrt(parent visits) of every level and the reciprocal of the visited child's new
+    // count.  Both tables (S + 2 and S + 3 floats) are staged in LDS once per launch by all lanes (one memory round trip);
+    // as global loads inside the loop their L2 latency (~700 cycles) bounded every visit.  Searches too long for the 18 KB
+    // buffer read the tables from memory.
+    const int S = e.c.S;
+    const bool fits = 2 * S + 5 <= BO_NUM_ACTIONS;
+    if (fits && !*staged) {
         bo_sync();
+        for (int t = lane; t < 2 * S + 5; t += 64) lds[t] = t < S + 2 ? e.sqrt_lut[t] : e.rcp_lut[t - (S + 2)];
+        bo_sync();
+        *staged = true;
     }
+#define BO_SQ(i) (fits ? lds[(i) <= S + 1 ? (i) : S + 1] : e.sqrt_lut[(i) <= S + 1 ? (i) : S + 1])
+#define BO_RC(i) (fits ? lds[S + 2 + ((i) <= S + 2 ? (i) : S + 2)] : e.rcp_lut[(i) <= S + 2 ? (i) : S + 2])
+    int pvl = nv[0];  // parent-side visit count of this lane's level (mcts.py:89): the root's for levels 0 and 1
+#pragma unroll
+    for (int k = 1; k < BO_BURST_LEVELS; k++)
+        if (grp == k) pvl = nv[k - 1];
+    const float t1 = e.c.cpuct * cp;
+    float y1 = BO_RC(1 + cn);  // RN(1 / (1 + cn)): the divisor of this child's exploration term
+    const uint64_t last_bits = d > 0 ? (0xFFFFull << (16 * (d - 1))) : 0ull;
     int it = 0;
     for (;;) {
-        if (it - win_base >= BO_BURST_WIN) {  // wave-uniform: refill the windows
-            win_base = it;
-            const int idx_max = e.c.S + 1;
-            bo_sync();
-            for (int t = lane; t < BO_BURST_LEVELS * BO_BURST_WIN; t += 64) {
-                const int k = t / BO_BURST_WIN, i = t % BO_BURST_WIN;
-                const int p = (k == 0 ? nv[0] : nv[k - 1]) + 1 + i;  // nv[] already counts the simulations applied so far
-                lds_lut[t] = e.sqrt_lut[p <= idx_max ? p : idx_max];
-            }
-            bo_sync();
-        }
-        const float sp = lds_lut[grp * BO_BURST_WIN + (it - win_base)];
         it++;
+        const float sp = BO_SQ(pvl + it);
         // ---- apply one terminal simulation (MCTSNode.update along the path, mcts.py:120-144) ----
         if (have && j == my_chosen) {
             const float val = ((d - (grp + 1)) & 1) ? -v_cur : v_cur;  // the leaf sees v, its parent -v, ...
             cn += 1;
             const float dd = val - cq;
-            const float ee = dd / (float)cn;
+            const float ee = bo_div_count(dd, (float)cn, y1);  // == dd / (float)cn, correctly rounded
             cq = cq + ee;
+            y1 = BO_RC(1 + cn);
         }
 #pragma unroll
         for (int k = 0; k <= BO_BURST_LEVELS; k++) nv[k] += k <= d ? 1 : 0;
@@ -447,38 +455,44 @@ BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, 
         // ---- re-evaluate the descent from the registers (select_child at every level of the path) ----
         float score = -__builtin_inff();
         if (have) {
-            const float t1 = e.c.cpuct * cp;
             const float t2 = t1 * sp;
             float qv = 0.0f, u = t2;
-            if (cn > 0) { qv = cq; u = t2 / (float)(1 + cn); }
+            if (cn > 0) { qv = cq; u = bo_div_count(t2, (float)(1 + cn), y1); }
             score = qv + u;
             if (!(score == score)) score = -__builtin_inff();
         }
-        int bi = j;  // argmax (first index on ties) over the 16 lanes of the level: four DPP exchanges
+        // Does every level still choose the child it chose?  One cross-lane read of the chosen child's score per lane and a
+        // ballot (the full argmax costs four DPP rounds on two values; it is only needed when the LAST level moves on).
+        const float cs = bo_shfl_f(score, (lane & 48) | (my_chosen & 15));
+        const bool beat = have && (score > cs || (score == cs && j < my_chosen));
+        const bool dead = grp < d && j == 0 && !(cs > -__builtin_inff());  // the chosen child's own score is NaN
+        const uint64_t mb = bo_ballot(beat), md = bo_ballot(dead);
+        if (md != 0 || (mb & ~last_bits) != 0) break;  // an upper level turns elsewhere: the next descent needs the general loop
+        if ((mb & last_bits) != 0) {  // the last level moves to a sibling: fine if that one is a known terminal leaf too
+            int bi = j;
+            float bs = score;
 #define BO_BURST_STEP(kind)                                                                          \
-        {                                                                                            \
-            const float os = __builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, score), kind)); \
-            const int oi = BO_ROW_XCHG(bi, kind);                                                    \
-            if (os > score || (os == score && oi < bi)) { score = os; bi = oi; }                     \
-        }
-        BO_BURST_STEP(0) BO_BURST_STEP(1) BO_BURST_STEP(2) BO_BURST_STEP(3)
+            {                                                                                        \
+                const float os = __builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, bs), kind)); \
+                const int oi = BO_ROW_XCHG(bi, kind);                                                \
+                if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }                          \
+            }
+            BO_BURST_STEP(0) BO_BURST_STEP(1) BO_BURST_STEP(2) BO_BURST_STEP(3)
 #undef BO_BURST_STEP
-        // upper levels must reproduce the path; the last level may move to another known terminal leaf
-        const bool upper_ok = !(grp < d) || last || (bi == my_chosen && score > -__builtin_inff());
-        int bterm = (j == (bi & 15)) ? cterm : -2;  // term of the child this group selected: row maximum of the one candidate
-        { int o = BO_ROW_XCHG(bterm, 0); bterm = o > bterm ? o : bterm; }
-        { int o = BO_ROW_XCHG(bterm, 1); bterm = o > bterm ? o : bterm; }
-        { int o = BO_ROW_XCHG(bterm, 2); bterm = o > bterm ? o : bterm; }
-        { int o = BO_ROW_XCHG(bterm, 3); bterm = o > bterm ? o : bterm; }
-        const bool last_ok = !(have || (grp < d && j == 0)) || !last || (bterm > 0 && score > -__builtin_inff());
-        if (bo_ballot(!(upper_ok && last_ok)) != 0) break;  // the next descent needs the general loop
-        if (d > 0) {
+            int bterm = (j == (bi & 15)) ? cterm : -2;  // term of the child this group selected: row maximum of the one candidate
+            { int o = BO_ROW_XCHG(bterm, 0); bterm = o > bterm ? o : bterm; }
+            { int o = BO_ROW_XCHG(bterm, 1); bterm = o > bterm ? o : bterm; }
+            { int o = BO_ROW_XCHG(bterm, 2); bterm = o > bterm ? o : bterm; }
+            { int o = BO_ROW_XCHG(bterm, 3); bterm = o > bterm ? o : bterm; }
             const int src = 16 * (d - 1);  // lane 0 of the last level's group holds its argmax
             const int nb = bo_readlane(bi, src), nt = bo_readlane(bterm, src);
+            if (!(nt > 0)) break;
             if (last) my_chosen = nb;
             v_cur = nt == 1 ? 1.0f : 0.0f;
         }
     }
+#undef BO_SQ
+#undef BO_RC
     // ---- write the path back ----
     if (have) { e.n_visits[no + my_fc + j] = cn; e.q[no + my_fc + j] = cq; }
     if (lane == 0) e.n_visits[no] = nv[0];
@@ -744,6 +758,7 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
     }
     BO_PROF(0)
     int phase = PH_RUN;
+    bool burst_tables_staged = false;  // sh.probs is free from here on: terminal_burst keeps its two tables there
     for (;;) {
         if (sims >= e.c.S) {  // mcts.py:256-257
             if (rows > 0) { flush_pending(e, g, n_runs, n_ul, &n_nodes, sh.path, &flags); rows = n_runs = n_ul = 0; }
@@ -775,7 +790,7 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
             int applied = 1;
             bool small = depth <= BO_BURST_LEVELS;
             for (int k = 0; k < depth && small; k++) small = e.n_children[no + sh.path[k]] <= 16;
-            if (small) applied = terminal_burst(e, g, sh.path, depth, tv, e.c.S - sims, sh.probs);
+            if (small) applied = terminal_burst(e, g, sh.path, depth, tv, e.c.S - sims, sh.probs, &burst_tables_staged);
             else backup_run(e, g, leaf, tv, 1, sh.path, &flags);  // deep or wide path: one simulation the general way
             sims += applied;
             if (lane == 0) e.stat_term_sims[g] += applied;
