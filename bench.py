@@ -22,8 +22,10 @@ reported as the labelled extra `opening_phase`.
 process, started before this process touches a GPU) and relays rank 0's JSON line.
 
 Also measured live, per the contract:
-  roofline      PUCT-select kernel on the wide synthetic workload of SURVEY.md section 8d (HIP events on the
-                kernel's stream; algorithmic bytes = measured levels x 392 B)
+  roofline      the dominant kernel of the timed workload: the evaluate stage's residual-tower kernel (MFMA-bound, HIP events
+                on its stream); with --fast the select + backup kernel on the trees the run grew (HBM, engine byte counters)
+  roofline_select_wide_synthetic
+                PUCT-select on the wide synthetic workload of SURVEY.md section 8d (algorithmic bytes = measured levels x 392 B)
   roofline_step the in-loop tree-step kernel (latency-bound, cache-resident; reported for honesty)
   cpu_baseline  the CPU oracle (oracle/, a C port of the reference) + the same net under torch-CPU: one game per core on
                 the box's host cores (the reference's mp.Pool, main.py:168), bounded sample; per-core and x cores
@@ -498,16 +500,19 @@ def main():
         with open(args.dump_games if world == 1 else f"{args.dump_games}.rank{rank}", "w") as f:
             json.dump(dump, f)
     if rank == 0 and not args.no_roofline:
+        # `roofline` = the DOMINANT kernel of the timed workload.  Reference semantics: the evaluate stage's tower kernel
+        # (~80 % of a ply, MFMA-bound).  Fast mode: its select + backup kernel on the trees this run grew (what SURVEY.md
+        # section 8f asks to price).  The north star's select target on the section-8d synthetic wide workload
+        # (bo_k_select_wide: the same child-block layout and arithmetic, 262144 static trees) is reported beside it.
         wide = select_roofline(args, device)
-        if fast_roof is not None:  # fast mode: the product's own select + backup kernel is the roofline kernel
+        rn = nn_roofline(net, G, device) if (not args.fast and args.net_dtype == "fp32") else None
+        if fast_roof is not None:
             out["roofline"] = fast_roof
-            out["roofline_wide_synthetic"] = wide
+        elif rn:
+            out["roofline"] = rn
         else:
             out["roofline"] = wide
-        if not args.fast and args.net_dtype == "fp32":
-            rn = nn_roofline(net, G, device)
-            if rn:
-                out["roofline_nn"] = rn
+        out["roofline_select_wide_synthetic"] = wide
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # "on rank 0 at N=1 only"
         out["cpu_baseline"] = cpu_baseline(args)
     if dist is not None:

@@ -239,7 +239,7 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
     rc |= e->alloc(&d.req_moves, G * BO_MAX_MOVES); rc |= e->alloc(&d.root_moves, G * BO_MAX_MOVES);
     rc |= e->alloc(&d.root_child_rank, G * 2 * BO_CH_CAP); rc |= e->alloc(&d.noise, G * BO_MAX_MOVES);
     rc |= e->alloc(&d.played, G * c.PLY_CAP);
-    rc |= e->alloc(&d.prof, G * 10);
+    rc |= e->alloc(&d.prof, G * BO_PROF_SLOTS);
     d.played_now = nullptr;
     if (fast) {
         FastW &f = e->f;
@@ -860,11 +860,11 @@ extern "C" int bo_debug_profile(bo_engine *e, int enable, uint64_t *cycles_out, 
     if (!e) return fail(BO_E_ARG, "null engine");
     const size_t G = (size_t)e->d.c.G;
     if (cycles_out) {
-        RT(rt_d2h(cycles_out, e->d.prof, G * 10 * sizeof(uint64_t), stream));
+        RT(rt_d2h(cycles_out, e->d.prof, G * BO_PROF_SLOTS * sizeof(uint64_t), stream));
         RT(rt_sync(stream));
     }
     if (enable >= 0) {
-        if (enable && !e->d.c.profile) RT(rt_memset(e->d.prof, 0, G * 10 * sizeof(uint64_t), stream));
+        if (enable && !e->d.c.profile) RT(rt_memset(e->d.prof, 0, G * BO_PROF_SLOTS * sizeof(uint64_t), stream));
         e->d.c.profile = enable;  // 1: every game-step; N > 1: only game-steps longer than N cycles
     }
     return BO_OK;

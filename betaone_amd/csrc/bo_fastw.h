@@ -227,10 +227,27 @@ BO_KERNEL void bo_k_fw_select(Eng e, FastW f, const float *value, int kind) {
                         }
                     }
                 }
-                for (int m = 1; m < 64; m <<= 1) {  // first maximum in child order
-                    const float os = bo_shfl_xor_f(best, m), ow = bo_shfl_xor_f(bw, m);
-                    const int oi = bo_shfl_xor(bi, m), on = bo_shfl_xor(bn, m), ol = bo_shfl_xor(bl, m);
-                    if (os > best || (os == best && oi < bi)) { best = os; bi = oi; bn = on; bw = ow; bl = ol; }
+                // first maximum in child order: (score, index) through four DPP row rounds and two cross-row exchanges; the
+                // winner's statistics then come from its lane (index & 63) by v_readlane
+#define BO_FW_ARGMAX(os_expr, oi_expr)                                                      \
+                {                                                                           \
+                    const float os = (os_expr);                                             \
+                    const int oi = (oi_expr);                                               \
+                    if (os > best || (os == best && oi < bi)) { best = os; bi = oi; }       \
+                }
+                BO_FW_ARGMAX(__builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, best), 0)), BO_ROW_XCHG(bi, 0))
+                BO_FW_ARGMAX(__builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, best), 1)), BO_ROW_XCHG(bi, 1))
+                BO_FW_ARGMAX(__builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, best), 2)), BO_ROW_XCHG(bi, 2))
+                BO_FW_ARGMAX(__builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, best), 3)), BO_ROW_XCHG(bi, 3))
+                BO_FW_ARGMAX(bo_shfl_xor_f(best, 16), bo_shfl_xor(bi, 16))
+                BO_FW_ARGMAX(bo_shfl_xor_f(best, 32), bo_shfl_xor(bi, 32))
+#undef BO_FW_ARGMAX
+                bi = bo_uniform(bi);
+                if (bi < nblk * BO_FW_C) {
+                    const int src = bi & 63;
+                    bn = bo_readlane(bn, src);
+                    bw = __builtin_bit_cast(float, bo_readlane(__builtin_bit_cast(int, bw), src));
+                    bl = bo_readlane(bl, src);
                 }
                 if (bi >= nblk * BO_FW_C) {  // every score was NaN: take the first child (it exists: a run is never empty)
                     const WRec c = A[(size_t)first * BO_FW_C];

@@ -31,6 +31,7 @@
 #define BO_PATH_CAP 1024 // max tree depth
 #define BO_RES_CAP 256
 #define BO_PLANES 120
+#define BO_PROF_SLOTS 16  // bo_debug_profile: u64 counters per game
 #define BO_ROW (BO_PLANES * 64)
 
 enum { PH_IDLE = 0, PH_RUN = 1, PH_DONE = 2 };
@@ -82,7 +83,7 @@ struct Eng {
     int *res_n, *res_idx, *res_best_idx, *res_best_mv, *res_total;
     float *res_val;
     int *played_now;                  // [G] or NULL: bo_k_play notes the move it played (0: refused) -- read by the fast mode's re-rooting
-    unsigned long long *prof;         // [G][10] cycles: apply, select, first-visit (movegen+draw rules), terminal backups, encode, flush, total; steps,
+    unsigned long long *prof;         // [G][BO_PROF_SLOTS] cycles: apply, select, first-visit (movegen+draw rules), terminal backups, encode, flush, total; steps,
                                       // loop iterations, first visits.  profile = N > 1 counts only game-steps longer than N cycles
 };
 
@@ -384,6 +385,7 @@ BO_DEV float bo_div_count(float x, float fn, float y) {
     const float r = __builtin_fmaf(-fn, q0, x);
     const float q1 = __builtin_fmaf(r, y, q0);
     const float a = q0 < 0.0f ? -q0 : q0;
+    if (x == 0.0f) return q0;  // +-0 / n = +-0 (the common case: a child whose mean already equals the value backed up)
     return (a >= 1e-30f && a <= 1e30f) ? q1 : x / fn;
 }
 BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, int sims_left, float *lds, bool *staged) {
@@ -744,7 +746,7 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
 
     const bool prof = e.c.profile != 0;
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int n_iter = 0, n_first = 0;
+    int n_iter = 0, n_first = 0, n_burst = 0, n_burst_sims = 0, n_general = 0;
     unsigned long long tk = prof ? bo_clock() : 0ull;
     const unsigned long long t_start = tk;
 #define BO_PROF(slot)                                                    \
@@ -790,8 +792,10 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
             int applied = 1;
             bool small = depth <= BO_BURST_LEVELS;
             for (int k = 0; k < depth && small; k++) small = e.n_children[no + sh.path[k]] <= 16;
-            if (small) applied = terminal_burst(e, g, sh.path, depth, tv, e.c.S - sims, sh.probs, &burst_tables_staged);
-            else backup_run(e, g, leaf, tv, 1, sh.path, &flags);  // deep or wide path: one simulation the general way
+            BO_PROF(6)
+            if (small) { applied = terminal_burst(e, g, sh.path, depth, tv, e.c.S - sims, sh.probs, &burst_tables_staged); n_burst++; n_burst_sims += applied; }
+            else { backup_run(e, g, leaf, tv, 1, sh.path, &flags); n_general++; }  // deep or wide path: one simulation the general way
+            BO_PROF(7)
             sims += applied;
             if (lane == 0) e.stat_term_sims[g] += applied;
             BO_PROF(3)
@@ -820,7 +824,9 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
     if (prof && lane == 0) {
         const unsigned long long total = bo_clock() - t_start;
         if (e.c.profile == 1 || total > (unsigned long long)e.c.profile) {
-            unsigned long long *pp = e.prof + (size_t)g * 10;
+            unsigned long long *pp = e.prof + (size_t)g * BO_PROF_SLOTS;
+            pp[10] += (unsigned long long)n_burst; pp[11] += (unsigned long long)n_burst_sims; pp[12] += (unsigned long long)n_general;
+            pp[13] += pc[6]; pp[14] += pc[7];
             for (int i = 0; i < 6; i++) pp[i] += pc[i];
             pp[6] += total;
             pp[7] += 1;

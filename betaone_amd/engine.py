@@ -375,7 +375,7 @@ class Engine:
             raise EngineError(f"game slot {g}: {self.describe_status(int(st[g]))}")
 
     def profile(self, enable: int = -1, read: bool = True, stream: int = 0):
-        out = np.zeros((self.G, 10), dtype=np.uint64) if read else None
+        out = np.zeros((self.G, 16), dtype=np.uint64) if read else None
         self._check(self.lib.bo_debug_profile(self.h, enable, out.ctypes.data_as(C.POINTER(C.c_uint64)) if read else None, stream))
         return out
 

@@ -31,6 +31,7 @@ for step in "$@"; do
     fast)    run bench_fast 500 python bench.py --fast --leaves 16 --preroll 48 --steps 6 --warmup 1 --opening-steps 0 --no-cpu-baseline ;;
     fast16)  run bench_fast_f16 500 python bench.py --fast --leaves 16 --net-dtype fp16 --preroll 48 --steps 6 --warmup 1 --opening-steps 0 --no-cpu-baseline --wide-trees 32768 ;;
     fast4k)  run bench_fast_4096 700 python bench.py --fast --games 4096 --leaves 4 --net-dtype fp16 --preroll 24 --steps 3 --warmup 1 --opening-steps 0 --no-cpu-baseline --wide-trees 32768 ;;
+    fast32k) run bench_fast_32k 900 python bench.py --fast --games 32768 --leaves 1 --sims 64 --net 4x64 --net-dtype fp16 --preroll 6 --steps 2 --warmup 1 --opening-steps 0 --no-cpu-baseline --wide-trees 32768 ;;
     fasttests) run gpu_fasttests 600 python -m pytest tests/test_engine_gpu.py -m gpu -q -k "fast_mode" ;;
     uci)     run uci_latency 300 python tests/uci_latency.py ;;
     nccl1)   run bench_nccl1 300 env RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 python bench.py --force-dist --exchange-every 4 --steps 60 --no-cpu-baseline --no-roofline ;;

@@ -31,6 +31,8 @@ if thr > 1:
     for i, nm in enumerate(names[:7]):
         print(f"  {nm:16s} {tot[i] / max(n, 1):10.0f} cycles per slow step")
     print(f"  loop iterations per slow step {tot[8] / max(n, 1):.1f}, first visits {tot[9] / max(n, 1):.1f}")
+    print(f"  terminal iterations per slow step: burst calls {tot[10] / max(n, 1):.1f} applying {tot[11] / max(n, 1):.1f} simulations, "
+          f"general-path simulations {tot[12] / max(n, 1):.1f}; cycles before the burst (path check) {tot[13] / max(n, 1):.0f}, inside burst / general backup {tot[14] / max(n, 1):.0f}")
     sys.exit(0)
 per_step = p[:, :7] / np.maximum(p[:, 7:8], 1)
 print("cycles per step per game (100 MHz s_memtime ticks? shader clock): mean over games / max over games")
