@@ -17,7 +17,10 @@
 #include <hip/hip_runtime.h>
 #define BO_DEV __device__ __forceinline__
 #define BO_DEV_NOINLINE __device__ __noinline__
-#define BO_KERNEL extern "C" __global__
+// every BO_KERNEL is launched as ONE wavefront per workgroup (bo_rt.h: RT_LAUNCH): telling the compiler so gives a kernel the
+// whole 512-entry vector register file instead of the 128 registers a 1024-thread workgroup could use (bo_k_step spilled 83
+// vector and 212 scalar registers to scratch memory without it)
+#define BO_KERNEL extern "C" __global__ __launch_bounds__(64)
 #define BO_SHARED __shared__
 #define BO_CONST_TABLE __device__ const
 
