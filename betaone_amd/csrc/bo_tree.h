@@ -376,17 +376,20 @@ BO_DEV int select_leaf(const Eng &e, int g, int *flags, int *path, int *depth_ou
 // registers, and as long as it reproduces the same path the loop continues.  Returns the number of simulations
 // applied (>= 1); the caller re-selects from memory afterwards.  Bit-identical to backup_run + select_leaf.
 #define BO_BURST_LEVELS 4
+#define BO_BURST_FITS(S) (2 * (S) + 5 <= BO_NUM_ACTIONS)  // both tables in the step kernel's 18 KB probability buffer (S <= 2333)
 // x / fn for fn = (float)n, n a small positive integer (a visit count), y = RN(1 / fn) from the host-built table: quotient
 // estimate, exact remainder (fma), one correction (fma) -- the correctly rounded quotient (Markstein's division; it holds
 // whenever the quotient is a normal number: checked against true division on 1.6e9 operand pairs, n <= 4100), in 3
 // operations instead of the ~10 of the general sequence.  Tiny and non-finite quotients take the general division.
+BO_DEV_NOINLINE float bo_div_general(float x, float fn) { return x / fn; }  // out of line: the compiler must branch around it
 BO_DEV float bo_div_count(float x, float fn, float y) {
     const float q0 = x * y;
     const float r = __builtin_fmaf(-fn, q0, x);
-    const float q1 = __builtin_fmaf(r, y, q0);
+    float q = __builtin_fmaf(r, y, q0);
     const float a = q0 < 0.0f ? -q0 : q0;
-    if (x == 0.0f) return q0;  // +-0 / n = +-0 (the common case: a child whose mean already equals the value backed up)
-    return (a >= 1e-30f && a <= 1e30f) ? q1 : x / fn;
+    if (x == 0.0f) q = q0;  // +-0 / n = +-0 (the common case: a child whose mean already equals the value backed up)
+    else if (!(a >= 1e-30f && a <= 1e30f)) q = bo_div_general(x, fn);  // (never taken in a search: |quotient| in [1e-30, 1e30])
+    return q;
 }
 BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, int sims_left, float *lds, bool *staged) {
     const size_t no = NOFF(e, g);
@@ -416,18 +419,17 @@ BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, 
     int done = 0;
     // Per simulated visit the loop needs sqrt(parent visits) of every level and the reciprocal of the visited child's new
     // count.  Both tables (S + 2 and S + 3 floats) are staged in LDS once per launch by all lanes (one memory round trip);
-    // as global loads inside the loop their L2 latency (~700 cycles) bounded every visit.  Searches too long for the 18 KB
-    // buffer read the tables from memory.
+    // as global loads inside the loop their L2 latency (~700 cycles) bounded every visit.  (The caller takes the general
+    // path for searches whose tables do not fit the 18 KB buffer: BO_BURST_FITS.)
     const int S = e.c.S;
-    const bool fits = 2 * S + 5 <= BO_NUM_ACTIONS;
-    if (fits && !*staged) {
+    if (!*staged) {
         bo_sync();
         for (int t = lane; t < 2 * S + 5; t += 64) lds[t] = t < S + 2 ? e.sqrt_lut[t] : e.rcp_lut[t - (S + 2)];
         bo_sync();
         *staged = true;
     }
-#define BO_SQ(i) (fits ? lds[(i) <= S + 1 ? (i) : S + 1] : e.sqrt_lut[(i) <= S + 1 ? (i) : S + 1])
-#define BO_RC(i) (fits ? lds[S + 2 + ((i) <= S + 2 ? (i) : S + 2)] : e.rcp_lut[(i) <= S + 2 ? (i) : S + 2])
+#define BO_SQ(i) lds[(i) <= S + 1 ? (i) : S + 1]
+#define BO_RC(i) lds[S + 2 + ((i) <= S + 2 ? (i) : S + 2)]
     int pvl = nv[0];  // parent-side visit count of this lane's level (mcts.py:89): the root's for levels 0 and 1
 #pragma unroll
     for (int k = 1; k < BO_BURST_LEVELS; k++)
@@ -790,7 +792,7 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
         if (t > 0) {  // mcts.py:235-238: terminal leaves absorb the simulation, no NN row
             const float tv = t == 1 ? 1.0f : 0.0f;
             int applied = 1;
-            bool small = depth <= BO_BURST_LEVELS;
+            bool small = depth <= BO_BURST_LEVELS && BO_BURST_FITS(e.c.S);
             for (int k = 0; k < depth && small; k++) small = e.n_children[no + sh.path[k]] <= 16;
             BO_PROF(6)
             if (small) { applied = terminal_burst(e, g, sh.path, depth, tv, e.c.S - sims, sh.probs, &burst_tables_staged); n_burst++; n_burst_sims += applied; }
