@@ -763,6 +763,13 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
     BO_PROF(0)
     int phase = PH_RUN;
     bool burst_tables_staged = false;  // sh.probs is free from here on: terminal_burst keeps its two tables there
+    // Terminal simulations need no evaluation, so a game that runs into hundreds of them (a mating move, a claimable draw:
+    // up to the whole search) would keep its wavefront busy for ~1000 cycles each while every other game of the launch has
+    // long asked for its next evaluation -- the launch, and with it the whole ply, waited for that one game.  A launch
+    // therefore absorbs at most MCTS_BATCH_SIZE of them per game and then YIELDS: the game asks for nothing (its NN row is
+    // evaluated and ignored) and carries on in the next launch.  Results are unchanged (the same operations in the same
+    // order), and the search needs no more launches than one that spends those simulations on a batch of 96 rows would.
+    int term_budget = e.c.B;
     for (;;) {
         if (sims >= e.c.S) {  // mcts.py:256-257
             if (rows > 0) { flush_pending(e, g, n_runs, n_ul, &n_nodes, sh.path, &flags); rows = n_runs = n_ul = 0; }
@@ -795,12 +802,15 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
             bool small = depth <= BO_BURST_LEVELS && BO_BURST_FITS(e.c.S);
             for (int k = 0; k < depth && small; k++) small = e.n_children[no + sh.path[k]] <= 16;
             BO_PROF(6)
-            if (small) { applied = terminal_burst(e, g, sh.path, depth, tv, e.c.S - sims, sh.probs, &burst_tables_staged); n_burst++; n_burst_sims += applied; }
+            const int may = e.c.S - sims < term_budget ? e.c.S - sims : term_budget;
+            if (small) { applied = terminal_burst(e, g, sh.path, depth, tv, may, sh.probs, &burst_tables_staged); n_burst++; n_burst_sims += applied; }
             else { backup_run(e, g, leaf, tv, 1, sh.path, &flags); n_general++; }  // deep or wide path: one simulation the general way
             BO_PROF(7)
             sims += applied;
+            term_budget -= applied;
             if (lane == 0) e.stat_term_sims[g] += applied;
             BO_PROF(3)
+            if (term_budget <= 0 && sims < e.c.S) break;  // yield: req stays -1, phase stays RUN
             continue;
         }
         if (e.eval_slot[no + leaf] < 0) {  // needs the net: emit planes 98..119 into row g and pause
