@@ -58,6 +58,8 @@ struct bo_engine {
     int *h_go = nullptr;                      // pinned [G]
     std::vector<int> h_nl, h_term;
     bool nl_valid = false;  // h_nl holds the current roots' legal-move counts (set by bo_selfplay_begin)
+    void *setup_dev = nullptr, *setup_host = nullptr;  // staging of bo_games_reset_ex (grow-only)
+    size_t setup_cap = 0;
     std::vector<unsigned char> noise_pending;  // roots begun by bo_selfplay_turn(defer_noise) whose Dirichlet draw is still due
     template <class T> int alloc(T **p, size_t n) {
         void *v = nullptr;
@@ -299,6 +301,8 @@ extern "C" void bo_engine_destroy(bo_engine *e) {
     rt_set_device(e->device);
     for (void *p : e->allocs) rt_free(p);
     rt_host_free(e->h_res); rt_host_free(e->h_info); rt_host_free(e->h_noise); rt_host_free(e->h_go);
+    if (e->setup_dev) rt_free(e->setup_dev);
+    if (e->setup_host) rt_host_free(e->setup_host);
 #if !defined(BO_WAVE_EMU)
     if (e->sel_ev0) { (void)hipEventDestroy(e->sel_ev0); (void)hipEventDestroy(e->sel_ev1); }
 #endif
@@ -346,31 +350,48 @@ extern "C" int bo_games_reset_ex(bo_engine *e, int n, const int32_t *slots, cons
             }
         }
     }
+    // One packed upload through the engine's persistent staging buffers (grow-only device + pinned host memory): refilling
+    // a finished game's slot happens about once per ply in steady-state self-play, and nine hipMalloc / hipFree pairs per
+    // call cost more than the set-up kernel itself.
+    std::vector<int> sl(slots, slots + n);
+    size_t off = 0;
+    auto place = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 15) & ~(size_t)15; return o; };
+    const size_t o_slots = place(sl.size() * 4), o_start = place(start.size() * sizeof(DPos)), o_mv = place(flat.size() * sizeof(bo_mv)),
+                 o_nm = place(nm.size() * 4);
+    size_t o_nh = 0, o_hh = 0, o_tt = 0, o_tc = 0, o_nt = 0;
+    if (n_hist) {
+        o_nh = place(nh.size() * 4); o_hh = place(hh.size() * sizeof(DPos)); o_tt = place(tt.size() * sizeof(DPos));
+        o_tc = place(tc.size() * 4); o_nt = place(nt.size() * 4);
+    }
+    int rc = 0;
+    if (off > e->setup_cap) {
+        if (e->setup_dev) rt_free(e->setup_dev);
+        if (e->setup_host) rt_host_free(e->setup_host);
+        e->setup_dev = nullptr; e->setup_host = nullptr;
+        e->setup_cap = 2 * off + 4096;
+        rc = rt_malloc(&e->setup_dev, e->setup_cap) | rt_host_alloc(&e->setup_host, e->setup_cap);
+        if (rc) e->setup_cap = 0;
+    }
     SetupArgs a;
     memset(&a, 0, sizeof(a));
-    int *d_slots, *d_nm, *d_nh = nullptr, *d_nt = nullptr, *d_tc = nullptr;
-    DPos *d_start, *d_hh = nullptr, *d_tt = nullptr;
-    bo_mv *d_mv;
-    std::vector<void *> tmp;
-    auto up = [&](auto **dp, const auto &vec) -> int {
-        void *p = nullptr;
-        int rc = rt_malloc(&p, vec.size() * sizeof(vec[0]));
-        if (rc) return rc;
-        tmp.push_back(p);
-        *dp = (typename std::remove_reference<decltype(**dp)>::type *)p;
-        return rt_h2d(p, vec.data(), vec.size() * sizeof(vec[0]), stream);
-    };
-    std::vector<int> sl(slots, slots + n);
-    int rc = up(&d_slots, sl) | up(&d_start, start) | up(&d_mv, flat) | up(&d_nm, nm);
-    if (n_hist) rc |= up(&d_nh, nh) | up(&d_hh, hh) | up(&d_tt, tt) | up(&d_tc, tc) | up(&d_nt, nt);
     if (!rc) {
-        a.slots = d_slots; a.start = d_start; a.moves = d_mv; a.n_moves = d_nm; a.max_moves = (int)max_moves;
-        a.hist = d_hh; a.n_hist = d_nh; a.trk = d_tt; a.trk_cnt = d_tc; a.n_trk = d_nt; a.max_trk = (int)max_trk;
-        rc = RT_LAUNCH(bo_k_setup, n, stream, e->d, a);
-        if (!rc && e->fast) rc = RT_LAUNCH(bo_k_fw_reset, n, stream, e->d, e->f, (const int *)d_slots);
+        char *h = (char *)e->setup_host, *dv = (char *)e->setup_dev;
+        memcpy(h + o_slots, sl.data(), sl.size() * 4); memcpy(h + o_start, start.data(), start.size() * sizeof(DPos));
+        memcpy(h + o_mv, flat.data(), flat.size() * sizeof(bo_mv)); memcpy(h + o_nm, nm.data(), nm.size() * 4);
+        a.slots = (const int *)(dv + o_slots); a.start = (const DPos *)(dv + o_start); a.moves = (const bo_mv *)(dv + o_mv);
+        a.n_moves = (const int *)(dv + o_nm); a.max_moves = (int)max_moves; a.max_trk = (int)max_trk;
+        if (n_hist) {
+            memcpy(h + o_nh, nh.data(), nh.size() * 4); memcpy(h + o_hh, hh.data(), hh.size() * sizeof(DPos));
+            memcpy(h + o_tt, tt.data(), tt.size() * sizeof(DPos)); memcpy(h + o_tc, tc.data(), tc.size() * 4);
+            memcpy(h + o_nt, nt.data(), nt.size() * 4);
+            a.n_hist = (const int *)(dv + o_nh); a.hist = (const DPos *)(dv + o_hh); a.trk = (const DPos *)(dv + o_tt);
+            a.trk_cnt = (const int *)(dv + o_tc); a.n_trk = (const int *)(dv + o_nt);
+        }
+        rc = rt_h2d(dv, h, off, stream);
+        if (!rc) rc = RT_LAUNCH(bo_k_setup, n, stream, e->d, a);
+        if (!rc && e->fast) rc = RT_LAUNCH(bo_k_fw_reset, n, stream, e->d, e->f, a.slots);
     }
-    int rc2 = rt_sync(stream);
-    for (void *p : tmp) rt_free(p);
+    int rc2 = rt_sync(stream);  // the staging buffers are free again when this returns
     if (rc || rc2) return fail(BO_E_HIP, std::string("bo_games_reset: ") + rt_errstr(rc ? rc : rc2));
     return BO_OK;
 }
@@ -709,16 +730,20 @@ extern "C" int bo_game_export(bo_engine *e, int slot, bo_position *positions, in
                               void *stream) {
     if (!e || slot < 0 || slot >= e->d.c.G || !n_plies) return fail(BO_E_ARG, "bad arguments");
     const EngCfg &c = e->d.c;
+    // ply count and (up to cap) positions / moves in one round trip: the caller's cap is normally exact (it counted the plies)
+    const int want = cap < c.PLY_CAP ? (cap > 0 ? cap : 0) : c.PLY_CAP;
     int ply = 0;
+    std::vector<DPos> gp((size_t)want);
+    std::vector<bo_mv> mv((size_t)want);
     RT(rt_d2h(&ply, e->d.ply + slot, 4, stream));
+    if (want > 0 && (positions || moves)) {
+        RT(rt_d2h(gp.data(), e->d.gpos + (size_t)slot * c.PLY_CAP, gp.size() * sizeof(DPos), stream));
+        RT(rt_d2h(mv.data(), e->d.played + (size_t)slot * c.PLY_CAP, mv.size() * sizeof(bo_mv), stream));
+    }
     RT(rt_sync(stream));
     *n_plies = ply;
+    if (!positions && !moves) return BO_OK;
     if (ply + 1 > cap) return fail(BO_E_ARG, "export buffer too small");
-    std::vector<DPos> gp((size_t)ply + 1);
-    std::vector<bo_mv> mv((size_t)ply + 1);
-    RT(rt_d2h(gp.data(), e->d.gpos + (size_t)slot * c.PLY_CAP, gp.size() * sizeof(DPos), stream));
-    RT(rt_d2h(mv.data(), e->d.played + (size_t)slot * c.PLY_CAP, mv.size() * sizeof(bo_mv), stream));
-    RT(rt_sync(stream));
     for (int i = 0; i <= ply; i++) {
         if (positions) to_abi(gp[i], &positions[i]);
         if (moves && i < ply) moves[i] = mv[i];

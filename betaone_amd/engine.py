@@ -159,6 +159,28 @@ def _p(a: np.ndarray, typ=_I32P):
     return a.ctypes.data_as(typ)
 
 
+class PositionList:
+    """positions[0..n) of an exported game: indexable like a list of BoPosition, backed by ONE ctypes array (`raw`)."""
+
+    def __init__(self, raw, n: int):
+        self.raw, self.n = raw, n
+
+    def __len__(self) -> int:
+        return self.n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self.raw[k] for k in range(*i.indices(self.n))]
+        if i < 0:
+            i += self.n
+        if not 0 <= i < self.n:
+            raise IndexError(i)
+        return self.raw[i]
+
+    def __iter__(self):
+        return (self.raw[k] for k in range(self.n))
+
+
 class Engine:
     """G game slots on one GPU.  All pointer arguments are raw addresses (tensor.data_ptr())."""
 
@@ -325,7 +347,7 @@ class Engine:
         mv = np.zeros(cap, dtype=np.int32)
         n = C.c_int32()
         self._check(self.lib.bo_game_export(self.h, slot, pos, _p(mv), cap, C.byref(n), stream))
-        return [pos[i] for i in range(n.value + 1)], [int(m) for m in mv[:n.value]]
+        return PositionList(pos, n.value + 1), mv[:n.value].tolist()
 
     def encode_game(self, slot: int, first: int, n: int, out_ptr: int, stream: int = 0):
         self._check(self.lib.bo_game_encode(self.h, slot, first, n, out_ptr, stream))

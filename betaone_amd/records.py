@@ -36,14 +36,18 @@ def pack_game(fin) -> bytes:
     if getattr(fin, "first_ply", 0):
         raise ValueError("pack_game: a game continued from a move prefix has no pi for its first plies")
     n = len(fin.pis)
-    ptr = np.zeros(n + 1, dtype=np.int32)
-    for i, (idx, _) in enumerate(fin.pis):
-        ptr[i + 1] = ptr[i] + len(idx)
-    idx = np.concatenate([np.asarray(i, dtype=np.int32) for i, _ in fin.pis]) if n else np.zeros(0, np.int32)
-    val = np.concatenate([np.asarray(v, dtype=np.float32) for _, v in fin.pis]) if n else np.zeros(0, np.float32)
+    if hasattr(fin.pis, "flat"):  # rollout.SparsePis: already arrays
+        ptr, idx, val = fin.pis.flat()
+    else:
+        ptr = np.zeros(n + 1, dtype=np.int32)
+        for i, (ix, _) in enumerate(fin.pis):
+            ptr[i + 1] = ptr[i] + len(ix)
+        idx = np.concatenate([np.asarray(i, dtype=np.int32) for i, _ in fin.pis]) if n else np.zeros(0, np.int32)
+        val = np.concatenate([np.asarray(v, dtype=np.float32) for _, v in fin.pis]) if n else np.zeros(0, np.float32)
     head = np.array([MAGIC, fin.game_id, n, fin.terminal, 0, len(idx)], dtype=np.int32)
     head[4:5].view(np.float32)[0] = fin.outcome
-    pos = b"".join(bytes(p) for p in fin.positions[:n + 1])
+    raw = getattr(fin.positions, "raw", None)  # engine.PositionList: one ctypes array, no per-position objects
+    pos = bytes(raw)[:(n + 1) * POS_BYTES] if raw is not None else b"".join(bytes(p) for p in fin.positions[:n + 1])
     return b"".join([head.tobytes(), pos, np.asarray(fin.moves[:n], dtype=np.int32).tobytes(), ptr.tobytes(),
                      idx.tobytes(), val.tobytes()])
 

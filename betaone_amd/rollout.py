@@ -44,6 +44,34 @@ class GameState:
         return self.start_fullmove + (self.plies + (0 if self.start_white else 1)) // 2
 
 
+class SparsePis:
+    """The sparse pi of every searched ply of one game, as a sequence of (action indices, float32 probabilities) backed by
+    three arrays (entries per ply n[T], idx[T,K], val[T,K]) -- a finished game is handed over without a Python loop over
+    its plies (the reference's search leaves at most two non-zero entries per pi)."""
+
+    def __init__(self, n: np.ndarray, idx: np.ndarray, val: np.ndarray):
+        self.n, self.idx, self.val = n, idx, val
+
+    def __len__(self) -> int:
+        return len(self.n)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return SparsePis(self.n[i], self.idx[i], self.val[i])
+        k = int(self.n[i])
+        return self.idx[i, :k], self.val[i, :k]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self.n)))
+
+    def flat(self):
+        """(ptr[T+1], idx[total], val[total]): the CSR form the record wire format stores."""
+        mask = np.arange(self.idx.shape[1])[None, :] < self.n[:, None]
+        ptr = np.zeros(len(self.n) + 1, dtype=np.int32)
+        np.cumsum(self.n, out=ptr[1:])
+        return ptr, self.idx[mask].astype(np.int32, copy=False), self.val[mask].astype(np.float32, copy=False)
+
+
 @dataclass
 class FinishedGame:
     game_id: int
@@ -121,8 +149,14 @@ class Rollout:
         self._start_full = np.ones(G, dtype=np.int64)
         self._start_black = np.zeros(G, dtype=np.int64)
         self._start_step = np.zeros(G, dtype=np.int64)
+        self._first_ply = np.zeros(G, dtype=np.int64)
         self._step = 0
         self._hist = {}             # step -> (n[G], idx[G,K], val[G,K]) sparse pi of every game at that step
+        # reference semantics: pi has <= 2 entries, kept per slot and ply in dense arrays that grow with the longest game
+        self._pk = 0 if self.fast else 2
+        self._pi_n = np.zeros((G, 256), np.int32)
+        self._pi_idx = np.zeros((G, 256, max(1, self._pk)), np.int32)
+        self._pi_val = np.zeros((G, 256, max(1, self._pk)), np.float32)
         self._out = dict(n=np.zeros(G, np.int32), idx=np.zeros((G, E.RES_CAP), np.int32), val=np.zeros((G, E.RES_CAP), np.float32),
                          best_idx=np.zeros(G, np.int32), action=np.zeros(G, np.int32))
 
@@ -186,7 +220,7 @@ class Rollout:
             self._active[s] = True
             if self._begun_want is not None:
                 self._begun_want[s] = False  # a search begun for the slot's previous occupant does not count
-            self._plies[s] = self.games[s].plies
+            self._plies[s] = self._first_ply[s] = self.games[s].plies
             self._start_full[s], self._start_black[s] = full, 0 if white else 1
             self._start_step[s] = self._step
             if self.rng_mode == "native":
@@ -356,6 +390,19 @@ class Rollout:
             self._begun, self._begun_want, self._noise_pending = begun, want_next.copy(), not self.fast
         k = max(1, int(out["n"].max()))
         self._hist[self._step] = (out["n"].copy(), out["idx"][:, :k].copy(), out["val"][:, :k].copy())
+        if self._pk and k <= self._pk:  # this ply's pi of every searched game into its slot's row (one scatter)
+            rows = np.nonzero(go)[0]
+            cols = (self._plies[rows] - self._first_ply[rows]).astype(np.int64)
+            if len(cols) and cols.max() >= self._pi_n.shape[1]:
+                grow = max(2 * self._pi_n.shape[1], int(cols.max()) + 1)
+                self._pi_n = np.concatenate([self._pi_n, np.zeros((G, grow - self._pi_n.shape[1]), np.int32)], axis=1)
+                self._pi_idx = np.concatenate([self._pi_idx, np.zeros((G, grow - self._pi_idx.shape[1], self._pk), np.int32)], axis=1)
+                self._pi_val = np.concatenate([self._pi_val, np.zeros((G, grow - self._pi_val.shape[1], self._pk), np.float32)], axis=1)
+            self._pi_n[rows, cols] = out["n"][rows]
+            self._pi_idx[rows, cols] = out["idx"][rows, :self._pk]
+            self._pi_val[rows, cols] = out["val"][rows, :self._pk]
+        elif self._pk:
+            self._pk = 0  # a denser pi than the reference's search produces: fall back to the per-step history
         self._step += 1
         self._plies += go  # GameState.plies of the native mode is brought up to date when the game is finished
         lo = int(self._start_step[self._active].min()) if self._active.any() else self._step
@@ -373,7 +420,10 @@ class Rollout:
         positions, moves = self.eng.export_game(g, self._stream(), n_plies=gs.plies)
         outcome = 1.0 if terminal == 1 else 0.0
         pis = gs.pis
-        if self.rng_mode == "native":  # gather this game's sparse pis from the per-step arrays
+        if self.rng_mode == "native" and self._pk:  # this game's sparse pis: three slices of its slot's rows
+            t = max(0, len(moves) - gs.first_ply)
+            pis = SparsePis(self._pi_n[g, :t].copy(), self._pi_idx[g, :t].copy(), self._pi_val[g, :t].copy())
+        elif self.rng_mode == "native":  # (fast mode: pi over many moves) gather from the per-step arrays
             pis = []
             for st in range(int(self._start_step[g]), self._step):
                 n, idx, val = self._hist[st]
