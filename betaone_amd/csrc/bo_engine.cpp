@@ -368,7 +368,7 @@ extern "C" int bo_games_reset_ex(bo_engine *e, int n, const int32_t *slots, cons
         if (e->setup_dev) rt_free(e->setup_dev);
         if (e->setup_host) rt_host_free(e->setup_host);
         e->setup_dev = nullptr; e->setup_host = nullptr;
-        e->setup_cap = 2 * off + 4096;
+        e->setup_cap = 2 * off + (256u << 10);  // roomy from the start: regrowing means hipFree, i.e. a device synchronisation
         rc = rt_malloc(&e->setup_dev, e->setup_cap) | rt_host_alloc(&e->setup_host, e->setup_cap);
         if (rc) e->setup_cap = 0;
     }

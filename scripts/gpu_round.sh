@@ -21,6 +21,8 @@ for step in "$@"; do
     testsall) run gpu_tests 1000 python -m pytest tests -m gpu -q ;;
     newtests) run gpu_newtests 900 python -m pytest tests/test_baseline_configs_gpu.py tests/test_dropin_gpu.py -m gpu -q -s ;;
     bench)   run bench_default 600 python bench.py ;;
+    bench200) run bench_200a 300 python bench.py --steps 200 --no-cpu-baseline --no-roofline ;
+              run bench_200b 300 python bench.py --steps 200 --no-cpu-baseline --no-roofline ;;
     softmax) run bench_softmax_engine 300 python bench.py --softmax engine --no-cpu-baseline --no-roofline ;;
     opening) run bench_opening 300 python bench.py --preroll 0 --no-cpu-baseline --no-roofline ;;
     dist2)   run bench_dist2_gloo 400 python bench.py --gpus 2 --share-gpu --dist-backend gloo --games 128 --steps 40 --exchange-every 4 --no-cpu-baseline --no-roofline ;;
