@@ -21,6 +21,7 @@ for step in "$@"; do
     testsall) run gpu_tests 1000 python -m pytest tests -m gpu -q ;;
     newtests) run gpu_newtests 900 python -m pytest tests/test_baseline_configs_gpu.py tests/test_dropin_gpu.py -m gpu -q -s ;;
     bench)   run bench_default 600 python bench.py ;;
+    bench3)  run bench_a 300 python bench.py --no-cpu-baseline --no-roofline ; run bench_b 300 python bench.py --no-cpu-baseline --no-roofline ; run bench_c 300 python bench.py --no-cpu-baseline --no-roofline ;;
     bench200) run bench_200a 300 python bench.py --steps 200 --no-cpu-baseline --no-roofline ;
               run bench_200b 300 python bench.py --steps 200 --no-cpu-baseline --no-roofline ;;
     softmax) run bench_softmax_engine 300 python bench.py --softmax engine --no-cpu-baseline --no-roofline ;;
