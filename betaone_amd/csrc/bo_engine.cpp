@@ -713,7 +713,16 @@ extern "C" int bo_selfplay_turn(bo_engine *e, const int32_t *active, const int32
                                 int32_t defer_noise, int32_t *completed, void *stream) {
     if (!e || !want_next || !nn_in_dev || !completed) return fail(BO_E_ARG, "null argument");
     *completed = 0;
-    int rc = bo_selfplay_sample(e, active, move_number, threshold, t_initial, t_final, res_n, res_idx, res_val, best_idx, action_out, stream);
+    const bool poll_first = (defer_noise & 2) != 0;
+    defer_noise &= 1;
+    int rc;
+    if (poll_first) {  // are all searches finished?  Asked here, so that a ply costs ONE host round trip, not two
+        int running = 0;
+        rc = bo_search_poll(e, &running, nullptr, nullptr, stream);
+        if (rc) return rc;
+        if (running > 0) { *completed = -1; return BO_OK; }
+    }
+    rc = bo_selfplay_sample(e, active, move_number, threshold, t_initial, t_final, res_n, res_idx, res_val, best_idx, action_out, stream);
     if (rc) return rc;
     for (int g = 0; g < e->d.c.G; g++)
         if (action_out[g] == -3) return BO_OK;  // a pi too dense for the native sampler: the caller samples it, then plays and begins

@@ -321,16 +321,20 @@ class Engine:
     def selfplay_noise(self, stream: int = 0):
         self._check(self.lib.bo_selfplay_noise(self.h, stream))
 
-    def selfplay_turn(self, active, move_number, temperature, out, want_next, nn_in_ptr: int, stream: int = 0, defer_noise: bool = False):
+    def selfplay_turn(self, active, move_number, temperature, out, want_next, nn_in_ptr: int, stream: int = 0, defer_noise: bool = False,
+                      poll_first: bool = False):
         """selfplay_sample + play + selfplay_begin(want_next) in one call.  Returns (out, (n_legal, terminal, go) or None):
-        None when a game needs the dense NumPy sampler (action -3) -- nothing was played then."""
+        None when a game needs the dense NumPy sampler (action -3) -- nothing was played then.  poll_first: check that all
+        searches are finished first; returns (None, None) if one is still running (issue another step and call again)."""
         a, m, w = _i32(active), _i32(move_number), _i32(want_next)
         th, ti, tf = temperature
         nl, tm, go = (np.zeros(self.G, dtype=np.int32) for _ in range(3))
         done = C.c_int32(0)
         self._check(self.lib.bo_selfplay_turn(self.h, _p(a), _p(m), int(th), float(ti), float(tf), _p(out["n"]), _p(out["idx"]),
                                               _p(out["val"], _F32P), _p(out["best_idx"]), _p(out["action"]), _p(w), nn_in_ptr, _p(nl), _p(tm),
-                                              _p(go), 1 if defer_noise else 0, C.byref(done), stream))
+                                              _p(go), (1 if defer_noise else 0) | (2 if poll_first else 0), C.byref(done), stream))
+        if done.value < 0:
+            return None, None
         return out, ((nl, tm, go) if done.value else None)
 
     def selfplay_begin(self, want, nn_in_ptr: int, stream: int = 0):

@@ -386,10 +386,16 @@ class FusedPolicyValueNet(nn.Module):
         return x
 
     @torch.no_grad()
-    def forward(self, x):
+    def forward_probs(self, x):
+        """(softmax(logits, dim=1) in float32, value): the policy softmax of mcts.py:185,287 issued where it costs least."""
+        return self.forward(x, probs=True)
+
+    @torch.no_grad()
+    def forward(self, x, probs: bool = False):
         if self.conv == "tower_f16":
             p, v = self._tower_f16_forward(x)
-            return self.policy_fc_h(p), torch.tanh(self.value_fc2_h(F.relu(self.value_fc1_h(v))))
+            logits = self.policy_fc_h(p)
+            return (torch.softmax(logits.float(), dim=1) if probs else logits), torch.tanh(self.value_fc2_h(F.relu(self.value_fc1_h(v))))
         if self.conv == "tower_wg":  # tower + head convolutions in one kernel, then 2 GEMMs and the value tail
             p, v = self._tower_forward(x, heads=True)
             # the value head (2 small kernels) runs beside the policy GEMM: a fork/join of streams, also inside a captured graph
@@ -402,6 +408,8 @@ class FusedPolicyValueNet(nn.Module):
                 h = torch._addmm_activation(self.value_fc1.bias, v, self.value_fc1.weight.t())  # relu(fc1)
                 value = self._value_tail(h)
             logits = self.policy_fc(p)
+            if probs:  # before the join: the softmax runs beside the value head instead of behind the streams' rendezvous
+                logits = torch.softmax(logits.float(), dim=1)
             cur.wait_stream(side)
             return logits, value
         if self.conv in ("mfma", "tower", "mfma_small"):
@@ -409,7 +417,8 @@ class FusedPolicyValueNet(nn.Module):
             h = self._epi(F.conv2d(x, self.w_head, None), self.b_head)
             p = h[:, :self.n_policy_ch].flatten(1)
             v = h[:, self.n_policy_ch:].flatten(1)
-            return self.policy_fc(p), torch.tanh(self.value_fc2(F.relu(self.value_fc1(v))))
+            logits = self.policy_fc(p)
+            return (torch.softmax(logits.float(), dim=1) if probs else logits), torch.tanh(self.value_fc2(F.relu(self.value_fc1(v))))
         x = self._epi(F.conv2d(x, self.w_in, None, padding=1), self.b_in)
         for w1, b1, w2, b2, se in self.blocks:
             y = self._epi(F.conv2d(x, w1, None, padding=1), b1)
@@ -418,4 +427,5 @@ class FusedPolicyValueNet(nn.Module):
         h = self._epi(F.conv2d(x, self.w_head, None), self.b_head)
         p = h[:, :self.n_policy_ch].flatten(1)
         v = h[:, self.n_policy_ch:].flatten(1)
-        return self.policy_fc(p), torch.tanh(self.value_fc2(F.relu(self.value_fc1(v))))
+        logits = self.policy_fc(p)
+        return (torch.softmax(logits.float(), dim=1) if probs else logits), torch.tanh(self.value_fc2(F.relu(self.value_fc1(v))))

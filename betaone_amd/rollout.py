@@ -165,14 +165,19 @@ class Rollout:
         return torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
 
     def _forward(self):
+        want_probs = self.policy_kind == E.POLICY_PROBS
+        fused = getattr(self.model, "forward_probs", None) if (want_probs and not self.autocast) else None
         with torch.no_grad():
-            if self.autocast:
+            if fused is not None:  # the evaluate stage places the softmax itself (beside its value head)
+                logits, value = fused(self.nn_in)
+                want_probs = False
+            elif self.autocast:
                 with torch.autocast(self.device.type):
                     logits, value = self.model(self.nn_in)
             else:
                 logits, value = self.model(self.nn_in)
         logits = logits.float()
-        if self.policy_kind == E.POLICY_PROBS:
+        if want_probs:
             logits = torch.softmax(logits, dim=1)
         return logits.contiguous(), value.float().contiguous()
 
@@ -311,7 +316,7 @@ class Rollout:
             self._fgraph, self._f_logits, self._f_value = g, logits, value
         self._fgraph.replay()
 
-    def _run_search_steps(self):
+    def _run_search_steps(self, poll: bool = True):
         burst = self.expected_evals
         if self._noise_pending:  # root evaluation: forward | host draws the noise meanwhile | upload | apply
             self._noise_pending = False
@@ -323,6 +328,8 @@ class Rollout:
         while True:
             for _ in range(burst):
                 self._eval_and_step()
+            if not poll:  # the caller asks the engine itself (bo_selfplay_turn, poll_first)
+                return
             running, _, _ = self.eng.poll(self._stream(), want_mask=False)
             if running == 0:
                 break
@@ -365,7 +372,7 @@ class Rollout:
                 go = go | go2
         if not go.any():
             return 0
-        self._run_search_steps()
+        self._run_search_steps(poll=False)
         self.n_sims += int(np.count_nonzero(go)) * self.S
         t0 = time.perf_counter()
         move_number = self._start_full + (self._plies + self._start_black) // 2   # board.fullmove_number, self_play.py:104
@@ -373,8 +380,12 @@ class Rollout:
         self.host_seconds += time.perf_counter() - t0
         # one native call: sample the moves, play them, begin the next searches (root info, Dirichlet noise, root planes)
         # (fast mode mixes the noise into a kept root's priors when the search begins, so its draws cannot be deferred)
-        out, begun = eng.selfplay_turn(go, move_number, self.temperature, self._out, want_next.astype(np.int32), self.nn_in.data_ptr(), stream,
-                                       defer_noise=not self.fast)
+        while True:  # one native call per ply: "all searches finished?" + sample + play + begin the next searches
+            out, begun = eng.selfplay_turn(go, move_number, self.temperature, self._out, want_next.astype(np.int32), self.nn_in.data_ptr(), stream,
+                                           defer_noise=not self.fast, poll_first=True)
+            if out is not None:
+                break
+            self._eval_and_step()  # a search needed one more evaluation than expected
         t0 = time.perf_counter()
         actions = out["action"]
         if begun is None:  # rare: a pi not sparse enough for the native sampler -- nothing was played

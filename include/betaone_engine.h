@@ -168,7 +168,9 @@ int bo_selfplay_turn(bo_engine *e, const int32_t *active, const int32_t *move_nu
                      double t_final, int32_t *res_n, int32_t *res_idx, float *res_val, int32_t *best_idx, int32_t *action_out,
                      const int32_t *want_next, float *nn_in_dev, int32_t *n_legal_out, int32_t *terminal_out, int32_t *go_out,
                      int32_t defer_noise, int32_t *completed, void *stream);
-/* defer_noise = 1: the Dirichlet draws of the new roots (mcts.py:190-201) and their upload are left to bo_selfplay_noise,
+/* defer_noise is a bit set.  Bit 1 (value 2): first ask whether every search has finished (bo_search_poll); if one is still
+ * running nothing is done and *completed = -1 -- the caller issues another evaluate + step and calls again.
+ * Bit 0, defer_noise = 1: the Dirichlet draws of the new roots (mcts.py:190-201) and their upload are left to bo_selfplay_noise,
  * to be called after the root evaluations' network forward has been enqueued on `stream` (the host work overlaps it) and
  * before the bo_step that consumes those evaluations.  Per game the RNG stream order is the same either way. */
 int bo_selfplay_noise(bo_engine *e, void *stream);
