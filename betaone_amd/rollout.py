@@ -141,6 +141,7 @@ class Rollout:
         self.policy_kind = E.POLICY_LOGITS if policy_kind == "logits" else E.POLICY_PROBS
         G = self.G
         self._fgraph = None
+        self._side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None  # finished games' hand-over beside the search
         self._noise_pending = False
         self._begun = None          # (n_legal, terminal, go) of searches already begun by the previous selfplay_turn
         self._begun_want = None
@@ -352,27 +353,24 @@ class Rollout:
                 nl, term, go = np.where(extra, nl2, nl), np.where(extra, t2, term), go | go2
         else:
             nl, term, go = eng.selfplay_begin(want.astype(np.int32), self.nn_in.data_ptr(), stream)
+        # Games that are over: their slots sit this ply out.  Exporting them, the caller's callback and setting up the next
+        # games happen WHILE the GPU searches the other games' moves -- on a side stream: a finished slot's arrays are not
+        # touched by the search (bo_k_step skips idle slots) -- and the new games' first searches are begun with everyone
+        # else's next one by bo_selfplay_turn below.  (One idle slot-ply per game, ~0.3 % of the capacity, instead of an
+        # idle GPU during ~0.3 ms of host work in every ply in which a game ends.)
         done = [int(g) for g in limit_done] + [int(g) for g in np.nonzero(want & (term != 0))[0]]
-        if done:
-            new_slots, ids, seeds, fens = [], [], [], []
-            for g in done:
-                fin = self._finish(g, int(term[g]))
-                if on_finished is not None:
-                    on_finished(fin)
-                self.games[g] = None
-                self._active[g] = False
-                nxt = refill(g) if refill is not None else None
-                if nxt is not None:
-                    new_slots.append(g); ids.append(nxt[0]); seeds.append(nxt[1]); fens.append(nxt[2])
-            if new_slots:
-                self.start_games(new_slots, ids, seeds, fens)
-                w2 = np.zeros(G, dtype=np.int32)
-                w2[new_slots] = 1
-                _nl2, _t2, go2 = eng.selfplay_begin(w2, self.nn_in.data_ptr(), stream)
-                go = go | go2
+        for g in done:
+            self._active[g] = False
         if not go.any():
+            self._finish_and_refill(done, term, on_finished, refill)
             return 0
         self._run_search_steps(poll=False)
+        if done:
+            if self._side is not None:
+                with torch.cuda.stream(self._side):  # torch's current stream in here: exports, encodes and set-up run beside the search
+                    self._finish_and_refill(done, term, on_finished, refill)
+            else:
+                self._finish_and_refill(done, term, on_finished, refill)
         self.n_sims += int(np.count_nonzero(go)) * self.S
         t0 = time.perf_counter()
         move_number = self._start_full + (self._plies + self._start_black) // 2   # board.fullmove_number, self_play.py:104
@@ -423,6 +421,20 @@ class Rollout:
         n_moves = int(np.count_nonzero(go))
         self.n_plies += n_moves
         return n_moves
+
+    def _finish_and_refill(self, done, term, on_finished, refill) -> None:
+        new_slots, ids, seeds, fens = [], [], [], []
+        for g in done:
+            fin = self._finish(g, int(term[g]))
+            if on_finished is not None:
+                on_finished(fin)
+            self.games[g] = None
+            self._active[g] = False
+            nxt = refill(g) if refill is not None else None
+            if nxt is not None:
+                new_slots.append(g); ids.append(nxt[0]); seeds.append(nxt[1]); fens.append(nxt[2])
+        if new_slots:
+            self.start_games(new_slots, ids, seeds, fens)  # (bo_games_reset synchronises its stream before it returns)
 
     def _finish(self, g: int, terminal: int) -> FinishedGame:
         gs = self.games[g]

@@ -130,3 +130,29 @@ def test_record_wire_format_roundtrip():
     assert games[0]["positions"][2].bb[0] == 0xFF02 and games[0]["positions"][1].turn == 0
     assert games[0]["pis"][0][0].tolist() == [5, 900] and games[0]["pis"][0][1].tolist() == [0.25, 0.75]
     assert len(blob) // 2 < 400     # ~100 B per ply instead of 49 KB per ply
+
+
+def test_launch_ranks_starts_one_process_per_rank(tmp_path):
+    """`bench.py --gpus N` / `selfplay_main --gpus N` start their ranks through selfplay_main.launch_ranks (a
+    torch.distributed.run child on 127.0.0.1): every rank sees RANK / LOCAL_RANK / WORLD_SIZE and can rendezvous."""
+    sys.path[:0] = [ROOT]
+    from betaone_amd.selfplay_main import launch_ranks
+
+    script = tmp_path / "child.py"
+    script.write_text(
+        "import os, sys\n"
+        "import torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "r, w = dist.get_rank(), dist.get_world_size()\n"
+        "assert r == int(os.environ['RANK']) == int(os.environ['LOCAL_RANK']) and w == int(os.environ['WORLD_SIZE']) == 3\n"
+        "import torch\n"
+        "t = torch.tensor([r + 1.0]); dist.all_reduce(t)\n"
+        "open(os.path.join(sys.argv[1], f'rank{r}.txt'), 'w').write(str(t.item()))\n"
+        "dist.destroy_process_group()\n")
+    rc = launch_ranks(3, [str(script), str(tmp_path)])
+    assert rc == 0
+    assert [open(tmp_path / f"rank{r}.txt").read() for r in range(3)] == ["6.0"] * 3
+    # a failing rank is reported through the exit code
+    bad = tmp_path / "bad.py"
+    bad.write_text("import sys; sys.exit(3)\n")
+    assert launch_ranks(2, [str(bad)]) != 0
