@@ -54,10 +54,21 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
     bo_f32x4 a0[4], a1[4], a2[4], a3[4];  // A fragments of four consecutive K-steps: [position quad]
     bo_f32x4 va[4], vb[4];                // B operands of two consecutive K-steps: [position quad]
     float skip[4][4];                     // block input at this lane's (channels, tile): the skip connection
+    // Weight fragments come through a buffer descriptor: the per-thread part of the address (wave, lane) is ONE constant
+    // VGPR, the per-step part (layer offset, K-step) is scalar arithmetic, the position quad is the instruction's immediate
+    // offset -- no vector ALU work per load (as 64-bit global pointers every K-step cost three VALU address operations,
+    // which on this kernel come straight out of the MFMA issue time).
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bo_f32x4 *>(wts), 0, 0x7fffffff, 0x00020000);
+    const int wvoff = ((wave * 4) * 64 + lane) * 16;
+    auto ldw = [&](int w_off4, int step, int pq) -> bo_f32x4 {
+        typedef int bo_i32x4_t __attribute__((ext_vector_type(4)));
+        const int soff = __builtin_amdgcn_readfirstlane((w_off4 + step * (OB * 4 * 64)) * 16);
+        const bo_i32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff + pq * 64 * 16, soff, 0);
+        return __builtin_bit_cast(bo_f32x4, v);
+    };
     auto load_w = [&](bo_f32x4(&a)[4], int w_off4, int step) {
-        const bo_f32x4 *wb = wts + w_off4 + (size_t)step * (OB * 4 * 64) + (wave * 4) * 64 + lane;
 #pragma unroll
-        for (int pq = 0; pq < 4; pq++) a[pq] = wb[pq * 64];
+        for (int pq = 0; pq < 4; pq++) a[pq] = ldw(w_off4, step, pq);
     };
     // chunk c of a layer = input channels 16c..16c+15; at C = 128 the even chunks are transformed by waves 0-3 and the
     // odd ones by waves 4-7 (one of each per SIMD), at C = 64 by all four waves
@@ -100,11 +111,10 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
 #define BO_WG_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
     auto kstep = [&](const bo_f32x4(&a)[4], const bo_f32x4(&v)[4], bo_f32x4(&an)[4], bo_f32x4(&vn)[4], int buf, int sl_next, int w_off4n,
                      int step_w) {
-        const bo_f32x4 *wb = wts + w_off4n + (size_t)step_w * (OB * 4 * 64) + (wave * 4) * 64 + lane;
         const bo_f32x4 *src = &V[buf][(4 * (sl_next < 0 ? 0 : sl_next) + kq) * 64 + n];
 #pragma unroll
         for (int pq = 0; pq < 4; pq++) {
-            if (LAB != 1 && LAB != 6) an[pq] = wb[pq * 64];
+            if (LAB != 1 && LAB != 6) an[pq] = ldw(w_off4n, step_w, pq);
             if (sl_next >= 0) vn[pq] = src[pq * 16];
 #pragma unroll
             for (int e = 0; e < 4; e++) acc[4 * pq + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[pq][e], v[pq][e], acc[4 * pq + e], 0, 0, 0);
