@@ -76,29 +76,28 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
     auto transform = [&](const float *img, int c) {  // V[c&1][channel][.][tile] = B^T d B for one (channel, tile) per lane
         const int icl = 4 * (wave & 3) + kq;
         const float *p = img + (16 * c + icl) * IMG + patch;
-        float d[16], w[16], v[16];
+        // 32 additions as 16 packed ones (v_pk_add_f32 with per-lane operand selection and negation): vector ALU work does
+        // not overlap this SIMD's MFMAs, every instruction here comes out of the other wave's matrix time.
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 dl[4], dh[4], wl[4], wh[4];  // (x0, x1) and (x2, x3) of each patch row
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const float2 lo = *reinterpret_cast<const float2 *>(p + 10 * i), hi = *reinterpret_cast<const float2 *>(p + 10 * i + 2);
-            d[4 * i] = lo.x; d[4 * i + 1] = lo.y; d[4 * i + 2] = hi.x; d[4 * i + 3] = hi.y;
+            dl[i] = *reinterpret_cast<const f2 *>(p + 10 * i);
+            dh[i] = *reinterpret_cast<const f2 *>(p + 10 * i + 2);
         }
+        wl[0] = dl[0] - dl[2]; wh[0] = dh[0] - dh[2];   // B^T d: rows (0-2, 1+2, 2-1, 1-3), both column pairs at once
+        wl[1] = dl[1] + dl[2]; wh[1] = dh[1] + dh[2];
+        wl[2] = dl[2] - dl[1]; wh[2] = dh[2] - dh[1];
+        wl[3] = dl[1] - dl[3]; wh[3] = dh[1] - dh[3];
+        f2 *dst = reinterpret_cast<f2 *>(&V[c & 1][icl * 64 + n]);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            w[j] = d[j] - d[8 + j];
-            w[4 + j] = d[4 + j] + d[8 + j];
-            w[8 + j] = d[8 + j] - d[4 + j];
-            w[12 + j] = d[4 + j] - d[12 + j];
+        for (int i = 0; i < 4; i++) {  // (.) B per row: (w0 - w2, w1 + w2) and (w2 - w1, w1 - w3), one instruction each
+            f2 v01, v23;
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(v01) : "v"(wl[i]), "v"(wh[i]));
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(v23) : "v"(wl[i]), "v"(wh[i]));
+            dst[i * 32] = v01;      // V[.][channel][position quad i][tile]: 16 bytes per (quad, tile), 16 tiles per quad
+            dst[i * 32 + 1] = v23;
         }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            v[4 * i] = w[4 * i] - w[4 * i + 2];
-            v[4 * i + 1] = w[4 * i + 1] + w[4 * i + 2];
-            v[4 * i + 2] = w[4 * i + 2] - w[4 * i + 1];
-            v[4 * i + 3] = w[4 * i + 1] - w[4 * i + 3];
-        }
-        bo_f32x4 *dst = &V[c & 1][icl * 64 + n];
-#pragma unroll
-        for (int pq = 0; pq < 4; pq++) dst[pq * 16] = bo_f32x4{v[4 * pq], v[4 * pq + 1], v[4 * pq + 2], v[4 * pq + 3]};
     };
     auto read_b = [&](bo_f32x4(&v)[4], int buf, int sl) {  // B operands of local step sl (channels 4*sl + kq of the chunk)
         const bo_f32x4 *src = &V[buf][(4 * sl + kq) * 64 + n];
@@ -166,19 +165,27 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
             }
 
             // ---- output transform Y = A^T M A per row r: M[i][j] = acc[4i+j][r] ----
+            // (two output channels per instruction: the accumulator registers of rows r, r+1 are adjacent -> v_pk_add_f32;
+            //  the same operations in the same order per element as the scalar form)
             float o[4][4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float t0[4], t1[4];
+            for (int p2 = 0; p2 < 2; p2++) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                f2 t0[4], t1[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    t0[j] = acc[j][r] + acc[4 + j][r] + acc[8 + j][r];
-                    t1[j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+                    const f2 a0 = {acc[j][2 * p2], acc[j][2 * p2 + 1]}, a1 = {acc[4 + j][2 * p2], acc[4 + j][2 * p2 + 1]};
+                    const f2 a2 = {acc[8 + j][2 * p2], acc[8 + j][2 * p2 + 1]}, a3 = {acc[12 + j][2 * p2], acc[12 + j][2 * p2 + 1]};
+                    t0[j] = a0 + a1 + a2;
+                    t1[j] = a1 - a2 - a3;
                 }
-                o[r][0] = t0[0] + t0[1] + t0[2] + bv[r];
-                o[r][1] = t0[1] - t0[2] - t0[3] + bv[r];
-                o[r][2] = t1[0] + t1[1] + t1[2] + bv[r];
-                o[r][3] = t1[1] - t1[2] - t1[3] + bv[r];
+                const f2 bp = {bv[2 * p2], bv[2 * p2 + 1]};
+                const f2 o0 = t0[0] + t0[1] + t0[2] + bp, o1 = t0[1] - t0[2] - t0[3] + bp;
+                const f2 o2 = t1[0] + t1[1] + t1[2] + bp, o3 = t1[1] - t1[2] - t1[3] + bp;
+                o[2 * p2][0] = o0[0]; o[2 * p2 + 1][0] = o0[1];
+                o[2 * p2][1] = o1[0]; o[2 * p2 + 1][1] = o1[1];
+                o[2 * p2][2] = o2[0]; o[2 * p2 + 1][2] = o2[1];
+                o[2 * p2][3] = o3[0]; o[2 * p2 + 1][3] = o3[1];
             }
             if (LAB == 4 || LAB == 6) {
                 if (o[0][0] == 123.456f) Q[tid] = o[1][1] + o[2][2] + o[3][3];
