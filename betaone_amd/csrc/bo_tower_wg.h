@@ -28,6 +28,7 @@
 #pragma once
 #if !defined(BO_WAVE_EMU)
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "bo_tower.h"
 
 // LAB (scripts/conv_lab.hip only): 0 = the kernel; 1 = no weight loads; 2 = no input transform; 4 = no epilogue (wrong
@@ -108,15 +109,22 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
     // quad two steps ahead and the B operand read of the same quad of the next step; the sched_group_barriers put each
     // into the shadow of a different MFMA (the scheduler's own order issues loads right before their use).
 #define BO_WG_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+    // first = the layer's first K-step: its MFMAs take a zero C operand (an inline constant) instead of accumulators that 64
+    // v_mov instructions per wave and layer would have had to clear
     auto kstep = [&](const bo_f32x4(&a)[4], const bo_f32x4(&v)[4], bo_f32x4(&an)[4], bo_f32x4(&vn)[4], int buf, int sl_next, int w_off4n,
-                     int step_w) {
+                     int step_w, auto first) {
         const bo_f32x4 *src = &V[buf][(4 * (sl_next < 0 ? 0 : sl_next) + kq) * 64 + n];
 #pragma unroll
         for (int pq = 0; pq < 4; pq++) {
             if (LAB != 1 && LAB != 6) an[pq] = ldw(w_off4n, step_w, pq);
             if (sl_next >= 0) vn[pq] = src[pq * 16];
 #pragma unroll
-            for (int e = 0; e < 4; e++) acc[4 * pq + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[pq][e], v[pq][e], acc[4 * pq + e], 0, 0, 0);
+            for (int e = 0; e < 4; e++) {
+                if constexpr (decltype(first)::value)
+                    acc[4 * pq + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[pq][e], v[pq][e], bo_f32x4{0, 0, 0, 0}, 0, 0, 0);
+                else
+                    acc[4 * pq + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[pq][e], v[pq][e], acc[4 * pq + e], 0, 0, 0);
+            }
             BO_WG_SGB(0x008, 1); BO_WG_SGB(0x020, 1); BO_WG_SGB(0x008, 1); BO_WG_SGB(0x100, 1); BO_WG_SGB(0x008, 2);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -145,24 +153,24 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
             float bv[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) bv[r] = params[L.bias_off + oc0 + r];
-#pragma unroll
-            for (int pos = 0; pos < 16; pos++) acc[pos] = bo_f32x4{0, 0, 0, 0};
             if (LAB != 2 && LAB != 6 && my_chunk(0)) transform(img, 0);
             __syncthreads();
             // One chunk = 4 K-steps = one turn of the weight-set rotation: step s multiplies with set s%4 while the weights
             // of step s+3 (possibly the first steps of the next layer) are loaded into set (s+3)%4.
             const int nk = L.t4, nchunks = nk >> 2;
-            for (int c = 0; c < nchunks; c++) {
+            auto chunk = [&](int c, auto first) {
                 const int s = 4 * c, buf = c & 1, t4 = s + 4, t5 = s + 5, t6 = s + 6;
                 if (LAB != 2 && LAB != 6 && c + 1 < nchunks && my_chunk(c + 1)) transform(img, c + 1);
                 read_b(va, buf, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                kstep(a0, va, a3, vb, buf, 1, L.w_off4, s + 3);
-                kstep(a1, vb, a0, va, buf, 2, t4 < nk ? L.w_off4 : Ln.w_off4, t4 < nk ? t4 : t4 - nk);
-                kstep(a2, va, a1, vb, buf, 3, t5 < nk ? L.w_off4 : Ln.w_off4, t5 < nk ? t5 : t5 - nk);
-                kstep(a3, vb, a2, va, buf, -1, t6 < nk ? L.w_off4 : Ln.w_off4, t6 < nk ? t6 : t6 - nk);
+                kstep(a0, va, a3, vb, buf, 1, L.w_off4, s + 3, first);
+                kstep(a1, vb, a0, va, buf, 2, t4 < nk ? L.w_off4 : Ln.w_off4, t4 < nk ? t4 : t4 - nk, std::false_type{});
+                kstep(a2, va, a1, vb, buf, 3, t5 < nk ? L.w_off4 : Ln.w_off4, t5 < nk ? t5 : t5 - nk, std::false_type{});
+                kstep(a3, vb, a2, va, buf, -1, t6 < nk ? L.w_off4 : Ln.w_off4, t6 < nk ? t6 : t6 - nk, std::false_type{});
                 if (LAB != 5 && LAB != 6 && c + 1 < nchunks) __syncthreads();  // V[buf] is free for chunk c+2, V[buf^1] is complete
-            }
+            };
+            chunk(0, std::true_type{});
+            for (int c = 1; c < nchunks; c++) chunk(c, std::false_type{});
 
             // ---- output transform Y = A^T M A per row r: M[i][j] = acc[4i+j][r] ----
             // (two output channels per instruction: the accumulator registers of rows r, r+1 are adjacent -> v_pk_add_f32;
