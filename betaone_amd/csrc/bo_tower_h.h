@@ -49,10 +49,19 @@ bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
     bo_h8 bq[2][4];            // B operands of two consecutive K-steps
     bo_h4 skip[MT][4][4];      // block input at this lane's (positions, channels), packed like the LDS writes
     const _Float16 *xl = X + (size_t)cell0 * PH + 8 * kg;  // + board*IMGH + half*40*PH + tap/channel offset
+    // weight fragments through a buffer descriptor: per-thread offset in one VGPR, layer / K-step offset in scalar registers,
+    // no vector address arithmetic per load (see bo_tower_wg.h)
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bo_h8 *>(wts), 0, 0x7fffffff, 0x00020000);
+    const int wvoff = ((wave * MT) * 64 + lane) * 16;
     auto load_a = [&](int j, int w_off8, int step) {
         if (LAB == 1 || LAB >= 5) return;
+        typedef int bo_i32x4_t __attribute__((ext_vector_type(4)));
+        const int soff = __builtin_amdgcn_readfirstlane((w_off8 + step * (C / 32) * 64) * 16);
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) a[j][mt] = wts[(size_t)w_off8 + ((size_t)step * (C / 32) + wave * MT + mt) * 64 + lane];
+        for (int mt = 0; mt < MT; mt++) {
+            const bo_i32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff + mt * 64 * 16, soff, 0);
+            a[j][mt] = __builtin_bit_cast(bo_h8, v);
+        }
     };
     auto read_b = [&](bo_h8(&b)[4], int off) {  // off: (tap offset in cells) * PH + 16 * channel group
         if (LAB == 2 || LAB >= 5) return;
