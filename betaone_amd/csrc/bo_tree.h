@@ -178,16 +178,31 @@ BO_DEV int chain_collect_history(const Eng &e, int g, ChainBuf &cb, int cnt) {
 // follows parent links (a few levels); the game-history part -- up to ~100 plies in drawn-out endgames, the tail
 // of the step kernel when it was walked one dependent 80-byte load at a time -- is found and read by all lanes at
 // once: ballot for the last irreversible ply, then one hash per lane.
-BO_DEV int chain_collect(const Eng &e, int g, int leaf, ChainBuf &cb) {
+// `path[0..d]` = the nodes root..leaf of the descent that has just ended in the leaf (select_leaf leaves it in LDS): ancestor
+// path[k] belongs to the chain while no move between it and the leaf was irreversible.  All lanes read the path nodes'
+// flags and hashes at once -- one memory round trip per 64 levels; following the parent links from the leaf took two
+// dependent loads per level (a third of a first visit's time).
+BO_DEV int chain_collect(const Eng &e, int g, const int *path, int d, ChainBuf &cb) {
     const size_t no = NOFF(e, g);
     const int lane = bo_lane();
-    int cnt = 0, x = leaf;
+    int cnt = 0;
     bool stop = false;
-    while (x > 0) {
-        if (e.npos[no + x].flags & F_IRREV) { stop = true; break; }
-        x = e.parent[no + x];
-        if (lane == 0 && cnt < BO_CHAIN_CAP) { cb.hash[cnt] = e.npos[no + x].khash; cb.ref[cnt] = x; }
-        cnt++;
+    for (int base = d; base >= 0 && !stop; base -= 64) {
+        const int j = base - lane;  // this lane's path index, from the leaf (j = d) towards the root (j = 0)
+        const bool in = j >= 0;
+        const int node = in ? path[j] : 0;
+        const uint32_t fl = in ? e.npos[no + node].flags : 0u;
+        const uint32_t kh = in ? e.npos[no + node].khash : 0u;
+        const uint64_t irr = bo_ballot(in && j >= 1 && (fl & F_IRREV));  // the root's own flag belongs to the game history
+        const uint64_t below = BIT(lane) - 1;
+        const bool take = in && j < d && (irr & below) == 0;  // an ancestor, and every node after it was reached reversibly
+        const uint64_t tk = bo_ballot(take);
+        if (take) {
+            const int o = cnt + bo_popc64(tk & below);
+            if (o < BO_CHAIN_CAP) { cb.hash[o] = kh; cb.ref[o] = node; }
+        }
+        cnt += bo_popc64(tk);
+        stop = irr != 0;
     }
     if (!stop) cnt = chain_collect_history(e, g, cb, cnt);
     bo_sync();
@@ -242,9 +257,10 @@ BO_DEV int terminal_eval_with(const Eng &e, int g, const DPos *tree_pos, const D
     return 0;
 }
 
-// the same for node `leaf` of the reference-semantics tree (chain through the parent links)
-BO_DEV int terminal_eval(const Eng &e, int g, int leaf, const DPos &P, const bo_mv *mv, int n, bool in_check, bo_mv *scratch, ChainBuf &cb) {
-    return terminal_eval_with(e, g, e.npos + NOFF(e, g), P, mv, n, in_check, scratch, cb, [&]() { return chain_collect(e, g, leaf, cb); });
+// the same for the leaf path[d] of the reference-semantics tree
+BO_DEV int terminal_eval(const Eng &e, int g, const int *path, int d, const DPos &P, const bo_mv *mv, int n, bool in_check, bo_mv *scratch,
+                         ChainBuf &cb) {
+    return terminal_eval_with(e, g, e.npos + NOFF(e, g), P, mv, n, in_check, scratch, cb, [&]() { return chain_collect(e, g, path, d, cb); });
 }
 
 // tracker.repetitions(board) = max(0, count - 1)   (utils.py:91-99)
@@ -504,24 +520,35 @@ BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, 
     return done;
 }
 
-// MCTSNode.update_recursive applied `cnt` times with the same leaf value (mcts.py:120-144)
-BO_DEV void backup_run(const Eng &e, int g, int leaf, float v, int cnt, int *path, int *flags) {
+// MCTSNode.update_recursive applied `cnt` times with the same leaf value (mcts.py:120-144).  known_depth >= 0: known[0 ..
+// known_depth] is the descent root..leaf that select_leaf has just left in LDS (no walk up the parent links: one dependent
+// load per level saved); else the path is collected into `scratch`.  The incremental mean divides by the visit count with
+// bo_div_count (3 operations, exact) -- up to 96 divisions in a row per path node.
+BO_DEV void backup_run(const Eng &e, int g, int leaf, float v, int cnt, int *scratch, int *flags, const int *known = nullptr,
+                       int known_depth = -1) {
     const size_t no = NOFF(e, g);
     int d = 0;
-    for (int x = leaf; x >= 0 && d < BO_PATH_CAP; x = e.parent[no + x]) {
-        if (bo_lane() == 0) path[d] = x;
-        d++;
+    if (known_depth >= 0) {
+        d = known_depth + 1;
+    } else {
+        for (int x = leaf; x >= 0 && d < BO_PATH_CAP; x = e.parent[no + x]) {
+            if (bo_lane() == 0) scratch[d] = x;
+            d++;
+        }
+        bo_sync();
     }
-    bo_sync();
-    for (int i = bo_lane(); i < d; i += 64) {
-        const int nd = path[i];
+    const int rmax = e.c.S + 2;
+    for (int i = bo_lane(); i < d; i += 64) {  // i = distance from the leaf
+        const int nd = known_depth >= 0 ? known[known_depth - i] : scratch[i];
         const float val = (i & 1) ? -v : v;
         int n = e.n_visits[no + nd];
         float qv = e.q[no + nd];
+#pragma unroll 8
         for (int c = 0; c < cnt; c++) {
             n += 1;
+            const float y = e.rcp_lut[n <= rmax ? n : rmax];
             const float dd = val - qv;
-            const float ee = dd / (float)n;
+            const float ee = n <= rmax ? bo_div_count(dd, (float)n, y) : dd / (float)n;
             qv = qv + ee;
         }
         e.n_visits[no + nd] = n;
@@ -544,7 +571,8 @@ BO_DEV void init_node(const Eng &e, size_t no, int idx, int par, float prior, bo
 }
 
 // _evaluate_batch's per-row expand + backup for all pending rows (mcts.py:291-295)
-BO_DEV void flush_pending(const Eng &e, int g, int n_runs, int n_ul, int *n_nodes_io, int *path, int *flags) {
+BO_DEV void flush_pending(const Eng &e, int g, int n_runs, int n_ul, int *n_nodes_io, int *path, int *flags, int cur_leaf = -1,
+                          const int *cur_path = nullptr, int cur_depth = -1) {
     const size_t no = NOFF(e, g);
     const int lane = bo_lane();
     const int *rl = e.run_leaf + (size_t)g * e.c.B, *rc = e.run_cnt + (size_t)g * e.c.B;
@@ -571,7 +599,8 @@ BO_DEV void flush_pending(const Eng &e, int g, int n_runs, int n_ul, int *n_node
     for (int r = 0; r < n_runs; r++) {
         const int leaf = rl[r];
         const int slot = e.eval_slot[no + leaf];
-        backup_run(e, g, leaf, e.ul_value[(size_t)g * e.c.UL_MAX + slot], rc[r], path, flags);
+        const bool known = leaf == cur_leaf && cur_depth >= 0;  // (the usual case: the batch's only leaf is the one just selected)
+        backup_run(e, g, leaf, e.ul_value[(size_t)g * e.c.UL_MAX + slot], rc[r], path, flags, known ? cur_path : nullptr, known ? cur_depth : -1);
     }
     *n_nodes_io = n_nodes;
     if (lane == 0) e.stat_flushes[g] += 1;
@@ -609,6 +638,7 @@ struct StepShared {
     bo_mv moves2[BO_MAX_MOVES];
     float pv[BO_MAX_MOVES];
     int path[BO_PATH_CAP];
+    int path2[BO_PATH_CAP];  // scratch of parent-link walks (path keeps the last descent)
     float probs[BO_NUM_ACTIONS];
     int rank_of[2 * BO_CH_CAP];
     ChainBuf chain;
@@ -770,15 +800,17 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
     // evaluated and ignored) and carries on in the next launch.  Results are unchanged (the same operations in the same
     // order), and the search needs no more launches than one that spends those simulations on a batch of 96 rows would.
     int term_budget = e.c.B;
+    int path_leaf = -1, path_depth = -1;  // the leaf whose descent sh.path holds (none yet in this launch)
     for (;;) {
         if (sims >= e.c.S) {  // mcts.py:256-257
-            if (rows > 0) { flush_pending(e, g, n_runs, n_ul, &n_nodes, sh.path, &flags); rows = n_runs = n_ul = 0; }
+            if (rows > 0) { flush_pending(e, g, n_runs, n_ul, &n_nodes, sh.path2, &flags, path_leaf, sh.path, path_depth); rows = n_runs = n_ul = 0; }
             BO_PROF(5)
             phase = PH_DONE;
             break;
         }
         int depth;
         const int leaf = select_leaf(e, g, &flags, sh.path, &depth, lut);
+        path_leaf = leaf; path_depth = depth;  // sh.path[0..depth] = root..leaf until something else uses the buffer
         n_iter++;
         BO_PROF(1)
         int t = e.term[no + leaf];
@@ -787,7 +819,7 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
             const DPos P = e.npos[no + leaf];
             bool chk;
             const int n = bo_movegen(P, sh.moves, &chk);
-            t = terminal_eval(e, g, leaf, P, sh.moves, n, chk, sh.moves2, sh.chain);
+            t = terminal_eval(e, g, sh.path, depth, P, sh.moves, n, chk, sh.moves2, sh.chain);
             if (lane == 0) e.term[no + leaf] = (signed char)t;
             if (t == 0) {  // it will be evaluated now: keep its ordered legal moves for apply_leaf
                 for (int j = lane; j < n; j += 64) e.req_moves[(size_t)g * BO_MAX_MOVES + j] = sh.moves[j];
@@ -804,7 +836,7 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
             BO_PROF(6)
             const int may = e.c.S - sims < term_budget ? e.c.S - sims : term_budget;
             if (small) { applied = terminal_burst(e, g, sh.path, depth, tv, may, sh.probs, &burst_tables_staged); n_burst++; n_burst_sims += applied; }
-            else { backup_run(e, g, leaf, tv, 1, sh.path, &flags); n_general++; }  // deep or wide path: one simulation the general way
+            else { backup_run(e, g, leaf, tv, 1, sh.path2, &flags, sh.path, depth); n_general++; }  // deep or wide path: one simulation the general way
             BO_PROF(7)
             sims += applied;
             term_budget -= applied;
@@ -829,7 +861,7 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
         rows += cnt;
         sims += cnt;
         bo_sync();
-        if (rows >= e.c.B) { flush_pending(e, g, n_runs, n_ul, &n_nodes, sh.path, &flags); rows = n_runs = n_ul = 0; }
+        if (rows >= e.c.B) { flush_pending(e, g, n_runs, n_ul, &n_nodes, sh.path2, &flags, path_leaf, sh.path, path_depth); rows = n_runs = n_ul = 0; }
         BO_PROF(5)
     }
 #undef BO_PROF
@@ -873,7 +905,9 @@ BO_DEV void root_prepare(const Eng &e, int g, StepShared &sh) {
     bo_sync();
     bool chk;
     const int n = bo_movegen(P, sh.moves, &chk);
-    const int t = terminal_eval(e, g, 0, P, sh.moves, n, chk, sh.moves2, sh.chain);
+    if (lane == 0) sh.path[0] = 0;
+    bo_sync();
+    const int t = terminal_eval(e, g, sh.path, 0, P, sh.moves, n, chk, sh.moves2, sh.chain);
     for (int j = lane; j < n; j += 64) {
         e.root_moves[(size_t)g * BO_MAX_MOVES + j] = sh.moves[j];
         e.req_moves[(size_t)g * BO_MAX_MOVES + j] = sh.moves[j];
