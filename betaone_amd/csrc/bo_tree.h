@@ -522,8 +522,7 @@ BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, 
 
 // MCTSNode.update_recursive applied `cnt` times with the same leaf value (mcts.py:120-144).  known_depth >= 0: known[0 ..
 // known_depth] is the descent root..leaf that select_leaf has just left in LDS (no walk up the parent links: one dependent
-// load per level saved); else the path is collected into `scratch`.  The incremental mean divides by the visit count with
-// bo_div_count (3 operations, exact) -- up to 96 divisions in a row per path node.
+// load per level saved); else the path is collected into `scratch`.
 BO_DEV void backup_run(const Eng &e, int g, int leaf, float v, int cnt, int *scratch, int *flags, const int *known = nullptr,
                        int known_depth = -1) {
     const size_t no = NOFF(e, g);
@@ -537,18 +536,15 @@ BO_DEV void backup_run(const Eng &e, int g, int leaf, float v, int cnt, int *scr
         }
         bo_sync();
     }
-    const int rmax = e.c.S + 2;
     for (int i = bo_lane(); i < d; i += 64) {  // i = distance from the leaf
         const int nd = known_depth >= 0 ? known[known_depth - i] : scratch[i];
         const float val = (i & 1) ? -v : v;
         int n = e.n_visits[no + nd];
         float qv = e.q[no + nd];
-#pragma unroll 8
-        for (int c = 0; c < cnt; c++) {
+        for (int c = 0; c < cnt; c++) {  // (the table division of the burst does not pay here: its reciprocal would be a load per step)
             n += 1;
-            const float y = e.rcp_lut[n <= rmax ? n : rmax];
             const float dd = val - qv;
-            const float ee = n <= rmax ? bo_div_count(dd, (float)n, y) : dd / (float)n;
+            const float ee = dd / (float)n;
             qv = qv + ee;
         }
         e.n_visits[no + nd] = n;
