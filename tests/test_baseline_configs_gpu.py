@@ -412,3 +412,56 @@ def test_orchestrator_iteration_on_gpu_writes_reference_pickles_and_resumes(env,
         assert len(new) == len(old)
         assert all(torch.equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] for a, b in zip(new, old))
     assert M.run_iteration(model, 5, n_games=24, n_slots=8, log=logs.append) == {}
+
+
+def test_bench_starts_its_own_ranks_and_exchanges_records(env, tmp_path):
+    """`python bench.py --gpus 2` (no torchrun): the parent starts two ranks before touching a GPU and relays rank 0's JSON
+    line; both ranks play their own games (ids by rank), finished games travel through the pipelined exchange.  Two ranks
+    share this box's one GPU here (gloo), as a rehearsal of the one-rank-per-GPU RCCL run."""
+    import json
+    import subprocess
+
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--dist-backend", "gloo", "--games", "16",
+           "--sims", "60", "--net", "4x64", "--steps", "6", "--warmup", "1", "--preroll", "12", "--max-game-moves", "10",
+           "--exchange-every", "2", "--no-cpu-baseline", "--no-roofline"]
+    p = subprocess.run(cmd, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric')]
+    assert len(lines) == 1, p.stdout[-2000:]           # exactly one JSON line: rank 0's
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0
+    ex = d["record_exchange"]
+    assert ex["records_received_rank0"] == d["games_finished_since_start"] > 0   # every rank's finished games arrived at rank 0
+    assert ex["payload_gathers"] >= 1 and ex["size_gathers"] >= ex["payload_gathers"]
+
+
+def test_record_exchange_through_rccl_on_one_rank(env):
+    """records.PeriodicGameExchange on the RCCL backend (world size 1 on this box): staging buffers, side stream and the
+    completion events of the asynchronous path; every record comes back, no tick blocks."""
+    import torch
+    import torch.distributed as dist
+    from betaone_amd import engine as E, records
+    from betaone_amd.rollout import FinishedGame, SparsePis
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        ex = records.PeriodicGameExchange(torch.device("cuda:0"), every=2)
+        pos = [E.BoPosition() for _ in range(4)]
+        got, sent = [], 0
+        for step in range(9):
+            fins = []
+            if step % 3 == 0:
+                pis = SparsePis(np.array([1, 2, 1], np.int32), np.array([[5, 0], [7, 9], [3, 0]], np.int32),
+                                np.array([[1.0, 0.0], [0.25, 0.75], [1.0, 0.0]], np.float32))
+                fins.append(FinishedGame(game_id=100 + step, slot=0, moves=[796, 3364, 100], positions=pos, pis=pis, outcome=0.0, terminal=2))
+                sent += 1
+            got.extend(ex.push(fins))
+            torch.cuda.synchronize()
+        got.extend(ex.flush())
+        assert sorted(g["game_id"] for g in got) == [100, 103, 106] and sent == 3
+        assert got[0]["pis"][1][0].tolist() == [7, 9] and got[0]["pis"][1][1].tolist() == [0.25, 0.75]
+        assert ex.blocked_ticks == 0 and ex.n_size_gathers == 5 and 1 <= ex.n_payload_gathers <= 4
+    finally:
+        dist.destroy_process_group()
