@@ -991,6 +991,23 @@ extern "C" int bo_nn_se_residual(float *x_dev, const float *bias_dev, const floa
 #endif
 }
 
+// small-batch form: the result replaces `residual_inout_dev`, x is only read (bo_nn_fused.h: bo_k_se_residual_small)
+extern "C" int bo_nn_se_residual_small(const float *x_dev, const float *bias_dev, const float *w1_dev, const float *w2_dev,
+                                       float *residual_inout_dev, int batch, int channels, int hidden, void *stream) {
+#if defined(BO_WAVE_EMU)
+    (void)x_dev; (void)bias_dev; (void)w1_dev; (void)w2_dev; (void)residual_inout_dev; (void)batch; (void)channels; (void)hidden; (void)stream;
+    return fail(BO_E_CONFIG, "bo_nn_se_residual_small is a gfx950-only kernel");
+#else
+    if (!x_dev || !bias_dev || !w1_dev || !w2_dev || !residual_inout_dev || batch < 1 || batch > 65535) return fail(BO_E_ARG, "bad arguments");
+    if (channels < 16 || channels > BO_SE_MAX_C || (channels & 15) || hidden < 1 || hidden > 16)
+        return fail(BO_E_CONFIG, "small SE block: channels a multiple of 16 <= 256, hidden <= 16");
+    hipLaunchKernelGGL(bo_k_se_residual_small, dim3((unsigned)(channels / 16), (unsigned)batch), dim3(256), 0, (hipStream_t)stream, x_dev, bias_dev,
+                       w1_dev, w2_dev, residual_inout_dev, channels, hidden);
+    RT((int)hipGetLastError());
+    return BO_OK;
+#endif
+}
+
 // ---- direct 3x3 convolution on the fp32 matrix cores (bo_conv.h); independent of an engine instance ---------------
 extern "C" int bo_nn_conv3x3(const float *x_dev, const float *wpacked_dev, const float *bias_dev, const float *residual_dev,
                              float *y_dev, int batch, int c_in, int c_out, int mode, void *stream) {

@@ -101,6 +101,71 @@ bo_k_se_residual(float *__restrict__ x, const float *__restrict__ bias, const fl
     }
 }
 
+// Small-batch form of the SE epilogue (uci.py analyses ONE position: bo_k_se_residual would run as a single workgroup whose
+// 64 dependent load iterations per thread are the latency of the whole layer, 30 us).  Here a board's layer is cut into C/16
+// workgroups of 16 channels.  Every workgroup pools ALL channels itself (thread = channel, its 64 squares as 16 float4 loads
+// issued at once; 64 KB from L2, cheaper than a rendezvous between workgroups), computes the hidden layer, then gates, adds
+// the skip connection and applies ReLU for its own 16 channels.  x is only read; the result goes into `res` IN PLACE
+// (res[i] = relu((x[i] + bias[c]) * gate[c] + res[i])): a workgroup reads and writes only its own elements of it.
+extern "C" __global__ void __launch_bounds__(256)
+bo_k_se_residual_small(const float *__restrict__ x, const float *__restrict__ bias, const float *__restrict__ w1 /*[H][C]*/,
+                       const float *__restrict__ w2 /*[C][H]*/, float *__restrict__ res, int C, int H) {
+    __shared__ float mean[BO_SE_MAX_C], hid[BO_SE_MAX_H], gate16[16], part[256];
+    const int cg = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const float *xb = x + (size_t)b * C * 64;
+    float *rb = res + (size_t)b * C * 64;
+    const int sl = t & 15, per = (C + 15) >> 4;
+    float w1r[BO_SE_MAX_C / 16];  // FC1: 16 threads per hidden unit, each a slice of the channels; requested before the pooling
+#pragma unroll
+    for (int i = 0; i < BO_SE_MAX_C / 16; i++) {
+        const int h = t >> 4, c = sl * per + i;
+        w1r[i] = (h < H && i < per && c < C) ? w1[h * C + c] : 0.0f;
+    }
+    if (t < C) {  // AdaptiveAvgPool2d(1) of channel t (conv output + bias)
+        const float4 *p = reinterpret_cast<const float4 *>(xb + (size_t)t * 64);
+        float4 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = p[i];
+        const float bc = bias[t];
+        float a = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) a += (v[i].x + bc) + (v[i].y + bc) + (v[i].z + bc) + (v[i].w + bc);
+        mean[t] = a * (1.0f / 64.0f);
+    }
+    __syncthreads();
+    {   // Linear(C, C/r, bias=False) + ReLU   (H <= 16)
+        const int h = t >> 4;
+        float a = 0.0f;
+#pragma unroll
+        for (int i = 0; i < BO_SE_MAX_C / 16; i++)
+            if (i < per && sl * per + i < C) a += w1r[i] * mean[sl * per + i];
+        part[t] = a;
+        __syncthreads();
+        if (sl == 0 && h < H) {
+            float sum = 0.0f;
+            for (int i = 0; i < 16; i++) sum += part[(t & ~15) + i];
+            hid[h] = sum > 0.0f ? sum : 0.0f;
+        }
+        __syncthreads();
+    }
+    if (t < 16) {  // Linear(C/r, C, bias=False) + Sigmoid for this workgroup's channels
+        const int c = cg * 16 + t;
+        float a = 0.0f;
+        for (int j = 0; j < H; j++) a += w2[c * H + j] * hid[j];
+        gate16[t] = 1.0f / (1.0f + expf(-a));
+    }
+    __syncthreads();
+    {   // scale, skip connection, ReLU: 16 channels x 64 squares = one float4 per thread
+        const int c = cg * 16 + (t >> 4), q = t & 15;
+        const float4 v = reinterpret_cast<const float4 *>(xb + (size_t)c * 64)[q];
+        float4 r = reinterpret_cast<float4 *>(rb + (size_t)c * 64)[q];
+        const float bc = bias[c], g = gate16[t >> 4];
+        r.x = (v.x + bc) * g + r.x; r.y = (v.y + bc) * g + r.y; r.z = (v.z + bc) * g + r.z; r.w = (v.w + bc) * g + r.w;
+        r.x = r.x > 0.0f ? r.x : 0.0f; r.y = r.y > 0.0f ? r.y : 0.0f; r.z = r.z > 0.0f ? r.z : 0.0f; r.w = r.w > 0.0f ? r.w : 0.0f;
+        reinterpret_cast<float4 *>(rb + (size_t)c * 64)[q] = r;
+    }
+}
+
 // value tail: out[b] = tanh(w . h[b] + bias) (value_fc2 + tanh, /root/reference/network.py:116-118,197); one wave per board
 extern "C" __global__ void __launch_bounds__(256)
 bo_k_value_tail(const float *__restrict__ h, const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ out, int B, int H) {

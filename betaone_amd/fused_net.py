@@ -357,6 +357,12 @@ class FusedPolicyValueNet(nn.Module):
     def _se(self, x, bias, se, res):
         B, C = x.shape[0], x.shape[1]
         stream = torch.cuda.current_stream(x.device).cuda_stream
+        if self.conv == "mfma_small" and C % 16 == 0 and se[0].shape[0] <= 16:  # few boards: C/16 workgroups per board, result into `res`
+            rc = self.lib.bo_nn_se_residual_small(x.data_ptr(), bias.data_ptr(), se[0].data_ptr(), se[1].data_ptr(), res.data_ptr(), B, C,
+                                                  se[0].shape[0], stream)
+            if rc:
+                raise E.EngineError(self.lib.bo_last_error().decode())
+            return res
         rc = self.lib.bo_nn_se_residual(x.data_ptr(), bias.data_ptr(), se[0].data_ptr(), se[1].data_ptr(), res.data_ptr(), B, C,
                                         se[0].shape[0], stream)
         if rc:

@@ -249,6 +249,11 @@ int bo_nn_se_residual(float *x_dev, const float *bias_dev, const float *w1_dev, 
  * wpacked_dev: the [c_out][c_in][3][3] weights re-ordered as [tap 9][c_in/8][c_out][2][4] with element
  * (tap, t4, oc, k, e) = W[oc][8*t4 + 2*e + k][tap] (betaone_amd/fused_net.py:pack_conv_weight).
  * Supported (c_in, c_out): (120 | C, C) for C in {64, 128, 256}.  Asynchronous on `stream`. */
+/* Small-batch form of bo_nn_se_residual (uci.py's single-position searches): a board's layer in channels/16 workgroups;
+ * x_dev is only read, the result replaces residual_inout_dev: r = relu((x + bias[c]) * gate[b,c] + r).  channels a multiple
+ * of 16 (<= 256), hidden <= 16. */
+int bo_nn_se_residual_small(const float *x_dev, const float *bias_dev, const float *w1_dev, const float *w2_dev,
+                            float *residual_inout_dev, int batch, int channels, int hidden, void *stream);
 int bo_nn_conv3x3(const float *x_dev, const float *wpacked_dev, const float *bias_dev, const float *residual_dev,
                   float *y_dev, int batch, int c_in, int c_out, int mode, void *stream);
 
