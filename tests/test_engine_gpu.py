@@ -185,7 +185,8 @@ def test_mfma_conv3x3_matches_float64_convolution(backend, shape):
             y = conv3x3_mfma(lib, x, wp, bias, co, mode, residual=res if mode == 2 else None)
             torch.cuda.synchronize()
             err = (y.double() - refs[mode]).abs().max().item()
-            assert err < 2e-5 and err <= 4 * lib_err + 1e-6, (shape, B, mode, err, lib_err)
+            # (fp32 accumulation over 9 x C_in terms: a few 1e-6; MIOpen's own error depends on the algorithm its find step picks on the box)
+            assert err < 2e-5 and err <= 4 * lib_err + 1e-5, (shape, B, mode, err, lib_err)
     with pytest.raises(E.EngineError):
         conv3x3_mfma(lib, torch.zeros((1, 24, 8, 8)).cuda(), wp, bias, co)
 
