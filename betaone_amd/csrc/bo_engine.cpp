@@ -12,6 +12,7 @@
 #include "bo_tower.h"
 #include "bo_tower_wg.h"
 #include "bo_tower_h.h"
+#include "bo_heads.h"
 #include "bo_rt.h"
 #include "bo_hostrng.h"
 
@@ -1165,6 +1166,31 @@ extern "C" void bo_nn_tower_destroy(bo_tower *t) {
     (void)hipFree(t->wts); (void)hipFree(t->params); (void)hipFree(t->layers);
 #endif
     delete t;
+}
+
+// ---- policy FC + softmax + value head in one launch (bo_heads.h) -------------------------------------------------------
+extern "C" int bo_nn_heads(const float *p_dev, const float *v_dev, const float *wp_dev, const float *bp_dev, const float *w1_dev,
+                           const float *b1_dev, const float *w2_dev, const float *b2_dev, float *policy_out_dev, float *value_out_dev,
+                           float *scratch_dev, int batch, int softmax, void *stream) {
+#if defined(BO_WAVE_EMU)
+    (void)p_dev; (void)v_dev; (void)wp_dev; (void)bp_dev; (void)w1_dev; (void)b1_dev; (void)w2_dev; (void)b2_dev; (void)policy_out_dev;
+    (void)value_out_dev; (void)scratch_dev; (void)batch; (void)softmax; (void)stream;
+    return fail(BO_E_CONFIG, "bo_nn_heads is a gfx950-only kernel");
+#else
+    if (!p_dev || !v_dev || !wp_dev || !bp_dev || !w1_dev || !b1_dev || !w2_dev || !b2_dev || !policy_out_dev || !value_out_dev || !scratch_dev)
+        return fail(BO_E_ARG, "null argument");
+    if (batch < 1 || batch > BO_HEADS_MAX_B) return fail(BO_E_CONFIG, "bo_nn_heads: 1 <= batch <= 512 (every workgroup must be resident for its device-wide barrier)");
+    bo_heads_args a;
+    a.p = p_dev; a.v = v_dev; a.wp = wp_dev; a.bp = bp_dev; a.w1 = w1_dev; a.b1 = b1_dev; a.w2 = w2_dev; a.b2 = b2_dev;
+    a.policy_out = policy_out_dev; a.value_out = value_out_dev;
+    a.vpart = scratch_dev + 16;                                   // scratch: [16 floats = 4 barrier words + padding][batch * 16 partials]
+    a.bar = reinterpret_cast<unsigned *>(scratch_dev);
+    a.B = batch; a.softmax = softmax;
+    const unsigned grid = (unsigned)(((batch + 255) / 256) * (BO_HEADS_NA / 32) + ((batch + 31) / 32) * 16);
+    hipLaunchKernelGGL(bo_k_heads, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    RT((int)hipGetLastError());
+    return BO_OK;
+#endif
 }
 
 extern "C" int bo_nn_value_tail(const float *h_dev, const float *w_dev, const float *bias_dev, float *out_dev, int batch, int hidden, void *stream) {

