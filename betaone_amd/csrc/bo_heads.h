@@ -67,22 +67,34 @@ bo_k_heads(bo_heads_args a) {
 #pragma unroll
             for (int c = 0; c < 2; c++) acc[rt][c] = bo_f32x4{0, 0, 0, 0};
         const bo_f32x4 *p4 = reinterpret_cast<const bo_f32x4 *>(a.p), *w4 = reinterpret_cast<const bo_f32x4 *>(a.wp);
+        // the fragments of half the K range are requested before their first MFMA (24 float4 per lane, two memory round trips
+        // per tile; fetched per K-group the tile was a chain of eight dependent round trips).  Register budget: under 256 per
+        // lane, so that two workgroups share a CU -- the device-wide barrier needs every workgroup resident.
+        constexpr int PG = BO_HEADS_KP / 16 / 2;
 #pragma unroll
-        for (int t = 0; t < BO_HEADS_KP / 16; t++) {
-            bo_f32x4 fa[4], fb[2];
+        for (int half = 0; half < 2; half++) {
+            bo_f32x4 fa[PG][4], fb[PG][2];
 #pragma unroll
-            for (int rt = 0; rt < 4; rt++) {
-                const int row = r0 + 16 * rt + i;
-                fa[rt] = row < B ? p4[((size_t)row * BO_HEADS_KP + 16 * t + 4 * kq) >> 2] : bo_f32x4{0, 0, 0, 0};
+            for (int t = 0; t < PG; t++) {
+                const int kk = 16 * (PG * half + t) + 4 * kq;
+#pragma unroll
+                for (int rt = 0; rt < 4; rt++) {
+                    const int row = r0 + 16 * rt + i;
+                    fa[t][rt] = row < B ? p4[((size_t)row * BO_HEADS_KP + kk) >> 2] : bo_f32x4{0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int c = 0; c < 2; c++) fb[t][c] = w4[((size_t)(c0 + 16 * c + i) * BO_HEADS_KP + kk) >> 2];
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int c = 0; c < 2; c++) fb[c] = w4[((size_t)(c0 + 16 * c + i) * BO_HEADS_KP + 16 * t + 4 * kq) >> 2];
+            for (int t = 0; t < PG; t++)
 #pragma unroll
-            for (int e = 0; e < 4; e++)
+                for (int e = 0; e < 4; e++)
 #pragma unroll
-                for (int rt = 0; rt < 4; rt++)
+                    for (int rt = 0; rt < 4; rt++)
 #pragma unroll
-                    for (int c = 0; c < 2; c++) acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[rt][e], fb[c][e], acc[rt][c], 0, 0, 0);
+                        for (int c = 0; c < 2; c++) acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[t][rt][e], fb[t][c][e], acc[rt][c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int c = 0; c < 2; c++) {
@@ -101,10 +113,11 @@ bo_k_heads(bo_heads_args a) {
         const int vt = wg - n_policy, rbv = vt >> 4, ht = vt & 15, r0 = 32 * rbv, k0 = (BO_HEADS_KV / 4) * wave;
         bo_f32x4 acc[2] = {bo_f32x4{0, 0, 0, 0}, bo_f32x4{0, 0, 0, 0}};
         const bo_f32x4 *v4 = reinterpret_cast<const bo_f32x4 *>(a.v), *w4 = reinterpret_cast<const bo_f32x4 *>(a.w1);
-        for (int t0 = 0; t0 < BO_HEADS_KV / 4 / 16; t0 += 4) {  // 4 groups of 16 K per iteration: 12 loads in flight
-            bo_f32x4 fa[4][2], fb[4];
+        constexpr int VG = 8;  // groups of 16 K per round trip: 24 float4 per lane in flight, four round trips per wave
+        for (int t0 = 0; t0 < BO_HEADS_KV / 4 / 16; t0 += VG) {
+            bo_f32x4 fa[VG][2], fb[VG];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < VG; u++) {
                 const int kk = k0 + 16 * (t0 + u) + 4 * kq;
 #pragma unroll
                 for (int rt = 0; rt < 2; rt++) {
@@ -113,8 +126,9 @@ bo_k_heads(bo_heads_args a) {
                 }
                 fb[u] = w4[((size_t)(16 * ht + i) * BO_HEADS_KV + kk) >> 2];
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 4; u++)
+            for (int u = 0; u < VG; u++)
 #pragma unroll
                 for (int e = 0; e < 4; e++)
 #pragma unroll

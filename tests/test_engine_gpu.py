@@ -473,7 +473,9 @@ def test_fused_heads_kernel_matches_torch(backend):
     w1 = (torch.randn((256, 2048), generator=g) / 45.0).cuda(); b1 = torch.randn(256, generator=g).cuda()
     w2 = (torch.randn((1, 256), generator=g) / 16.0).cuda(); b2 = torch.randn(1, generator=g).cuda()
     scratch = torch.zeros(16 + 16 * 512, device="cuda")
-    for B in (1, 33, 256, 300, 512):
+    bmax = lib.bo_nn_heads_max_batch()
+    assert 256 <= bmax <= 512
+    for B in (1, 33, 256, 300, bmax):
         p = torch.rand((B, 128), generator=g).cuda(); v = torch.rand((B, 2048), generator=g).cuda()
         logits_ref = p.double() @ wp.double().t() + bp.double()
         value_ref = torch.tanh(torch.relu(v.double() @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double())
@@ -493,4 +495,4 @@ def test_fused_heads_kernel_matches_torch(backend):
         assert scratch[:4].view(torch.int32).tolist()[:3] == [0, 0, 0]   # barrier re-armed, no time-out flag
     out = torch.empty((1, 4672), device="cuda")
     assert lib.bo_nn_heads(p.data_ptr(), v.data_ptr(), wp.data_ptr(), bp.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
-                           out.data_ptr(), val.data_ptr(), scratch.data_ptr(), 513, 1, 0) != 0   # more boards than resident workgroups allow
+                           out.data_ptr(), val.data_ptr(), scratch.data_ptr(), bmax + 1, 1, 0) != 0   # more boards than resident workgroups allow
