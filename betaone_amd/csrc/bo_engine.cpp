@@ -1168,33 +1168,7 @@ extern "C" void bo_nn_tower_destroy(bo_tower *t) {
     delete t;
 }
 
-// ---- policy FC + softmax + value head in one launch (bo_heads.h) -------------------------------------------------------
-#if !defined(BO_WAVE_EMU)
-static unsigned heads_grid(int batch) { return (unsigned)(((batch + 255) / 256) * (BO_HEADS_NA / 32) + ((batch + 31) / 32) * 16); }
-// workgroups of bo_k_heads that can be resident at once on the current device (its device-wide barrier needs all of them)
-static int heads_resident_workgroups() {
-    int dev = 0, per_cu = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bo_k_heads, 256, 0) != hipSuccess) return 0;
-    return per_cu * prop.multiProcessorCount;
-}
-#endif
-extern "C" int bo_nn_heads_max_batch(void) {
-#if defined(BO_WAVE_EMU)
-    return 0;
-#else
-    static int cached = -1;
-    if (cached < 0) {
-        const int cap = heads_resident_workgroups();
-        int b = 0;
-        while (b + 32 <= BO_HEADS_MAX_B && (int)heads_grid(b + 32) <= cap) b += 32;
-        cached = b;
-    }
-    return cached;
-#endif
-}
-
+// ---- policy FC + softmax + value head behind the tower: two launches (bo_heads.h) ------------------------------------
 extern "C" int bo_nn_heads(const float *p_dev, const float *v_dev, const float *wp_dev, const float *bp_dev, const float *w1_dev,
                            const float *b1_dev, const float *w2_dev, const float *b2_dev, float *policy_out_dev, float *value_out_dev,
                            float *scratch_dev, int batch, int softmax, void *stream) {
@@ -1205,16 +1179,15 @@ extern "C" int bo_nn_heads(const float *p_dev, const float *v_dev, const float *
 #else
     if (!p_dev || !v_dev || !wp_dev || !bp_dev || !w1_dev || !b1_dev || !w2_dev || !b2_dev || !policy_out_dev || !value_out_dev || !scratch_dev)
         return fail(BO_E_ARG, "null argument");
-    if (batch < 1 || batch > bo_nn_heads_max_batch())
-        return fail(BO_E_CONFIG, "bo_nn_heads: batch exceeds bo_nn_heads_max_batch() (every workgroup must be resident for the device-wide barrier)");
+    if (batch < 1 || batch > 65536) return fail(BO_E_ARG, "bo_nn_heads: 1 <= batch <= 65536");
     bo_heads_args a;
     a.p = p_dev; a.v = v_dev; a.wp = wp_dev; a.bp = bp_dev; a.w1 = w1_dev; a.b1 = b1_dev; a.w2 = w2_dev; a.b2 = b2_dev;
     a.policy_out = policy_out_dev; a.value_out = value_out_dev;
-    a.vpart = scratch_dev + 16;                                   // scratch: [16 floats = 4 barrier words + padding][batch * 16 partials]
-    a.bar = reinterpret_cast<unsigned *>(scratch_dev);
+    a.vpart = scratch_dev;  // [16 K chunks][batch][256]
     a.B = batch; a.softmax = softmax;
-    const unsigned grid = heads_grid(batch);
-    hipLaunchKernelGGL(bo_k_heads, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    const unsigned tiles = (unsigned)(((batch + BO_HEADS_PROWS - 1) / BO_HEADS_PROWS) * (BO_HEADS_NA / 32) + ((batch + 63) / 64) * 4 * BO_HEADS_KS);
+    hipLaunchKernelGGL(bo_k_heads_tiles, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(bo_k_heads_rows, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, a);
     RT((int)hipGetLastError());
     return BO_OK;
 #endif

@@ -92,7 +92,6 @@ _SYMBOLS = {
                                     C.c_void_p]),
     "bo_nn_se_residual_small": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p]),
-    "bo_nn_heads_max_batch": (C.c_int, []),
     "bo_nn_heads": (C.c_int, [C.c_void_p] * 11 + [C.c_int, C.c_int, C.c_void_p]),
     "bo_nn_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p]),

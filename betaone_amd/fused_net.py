@@ -341,18 +341,12 @@ class FusedPolicyValueNet(nn.Module):
             raise E.EngineError(self.lib.bo_last_error().decode())
         return out
 
-    def _heads_max_batch(self):
-        m = self.__dict__.get("_heads_max")
-        if m is None:
-            m = self.__dict__["_heads_max"] = int(self.lib.bo_nn_heads_max_batch())
-        return m
-
     def _heads(self, p, v, probs):
         B = p.shape[0]
         dev = p.device
         scr = self.__dict__.get("_heads_scratch")
-        if scr is None or scr.device != dev or scr.numel() < 16 + 16 * B:
-            scr = self.__dict__["_heads_scratch"] = torch.zeros(16 + 16 * max(B, 512), dtype=torch.float32, device=dev)
+        if scr is None or scr.device != dev or scr.numel() < 4096 * B:  # value_fc1 partial sums
+            scr = self.__dict__["_heads_scratch"] = torch.empty(4096 * max(B, 256), dtype=torch.float32, device=dev)
         out = torch.empty((B, 4672), dtype=torch.float32, device=dev)
         value = torch.empty((B, 1), dtype=torch.float32, device=dev)
         rc = self.lib.bo_nn_heads(p.data_ptr(), v.data_ptr(), self.policy_fc.weight.data_ptr(), self.policy_fc.bias.data_ptr(),
@@ -429,7 +423,7 @@ class FusedPolicyValueNet(nn.Module):
             return (torch.softmax(logits.float(), dim=1) if probs else logits), torch.tanh(self.value_fc2_h(F.relu(self.value_fc1_h(v))))
         if self.conv == "tower_wg":  # tower + head convolutions in one kernel, then the heads
             p, v = self._tower_forward(x, heads=True)
-            if self.fused_heads and x.shape[0] <= self._heads_max_batch() and p.shape[1] == 128 and v.shape[1] == 2048:
+            if self.fused_heads and p.shape[1] == 128 and v.shape[1] == 2048:
                 return self._heads(p, v, probs)  # policy FC + softmax + value head: one launch (csrc/bo_heads.h)
             # the value head (2 small kernels) runs beside the policy GEMM: a fork/join of streams, also inside a captured graph
             cur = torch.cuda.current_stream(x.device)

@@ -42,7 +42,7 @@ for step in "$@"; do
     stepprof) run stepprof 400 python scripts/step_profile.py 640 100 1 ;
               run stepprof_slow 400 python scripts/step_profile.py 640 100 300000 ;;
     trace)   mkdir -p $out/${tag}_trace; run trace 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace -- python bench.py --steps 200 --opening-steps 0 --no-cpu-baseline --no-roofline ;
-             python scripts/kernel_percentiles.py $out/${tag}_trace > $out/${tag}_trace_percentiles.md 2>&1 ; rm -f $out/${tag}_trace/*/*_kernel_trace.csv.keep ; tail -n 30 $out/${tag}_trace_percentiles.md ;;
+             python scripts/kernel_percentiles.py $out/${tag}_trace > $out/${tag}_trace_percentiles.md 2>&1 ; rm -f $out/${tag}_trace/*/*_kernel_trace.csv.keep ; tail -n 40 $out/${tag}_trace_percentiles.md ;;
     pmcfast) mkdir -p $out/${tag}_pmcfast; run pmcfast 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex "bo_k_fw" --output-format csv -d $out/${tag}_pmcfast -- python bench.py --fast --games 4096 --leaves 4 --net-dtype fp16 --preroll 4 --steps 1 --warmup 1 --opening-steps 0 --no-cpu-baseline --no-graph --wide-trees 32768 ;
              python scripts/pmc_summary.py $out/${tag}_pmcfast > $out/${tag}_pmcfast.md 2>&1 ; cat $out/${tag}_pmcfast.md ;;
     dist2nccl) run bench_dist2 400 python bench.py --gpus 2 --share-gpu --dist-backend gloo --games 128 --steps 40 --no-cpu-baseline --no-roofline ;;

@@ -25,3 +25,24 @@ for name, v in sorted(dur.items(), key=lambda kv: -sum(x[1] for x in kv[1])):
     if len(a) == 0:
         continue
     print(f"| {name} | {len(a)} | {a.mean():.1f} | {np.percentile(a, 50):.1f} | {np.percentile(a, 90):.1f} | {np.percentile(a, 99):.1f} | {a.max():.1f} |")
+
+# ---- gaps between consecutive launches (idle device time between the end of one kernel and the start of the next), by pair.
+# Only meaningful for the single-stream part of the pipeline; overlapping launches (forked streams) show as negative and are skipped.
+allk = []
+for f in files:
+    for r in csv.DictReader(open(f)):
+        name = r.get("Kernel_Name") or r.get("Name") or ""
+        allk.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name[:48]))
+allk.sort()
+allk = allk[len(allk) // 2:]
+gaps = {}
+for (s0, e0, n0), (s1, e1, n1) in zip(allk, allk[1:]):
+    g = s1 - e0
+    if 0 <= g < 200000:  # > 0.2 ms: a host round trip, not a dependency gap
+        gaps.setdefault((n0, n1), []).append(g)
+print()
+print("| previous kernel -> next kernel | pairs | mean gap us | p50 | p90 |")
+print("|---|---|---|---|---|")
+for (n0, n1), v in sorted(gaps.items(), key=lambda kv: -sum(kv[1]))[:14]:
+    a = np.array(v, dtype=np.float64) / 1e3
+    print(f"| {n0} -> {n1} | {len(a)} | {a.mean():.1f} | {np.percentile(a, 50):.1f} | {np.percentile(a, 90):.1f} |")

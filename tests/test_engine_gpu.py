@@ -461,9 +461,8 @@ def test_long_runs_of_terminal_simulations_match_oracle(backend, case):
 
 
 def test_fused_heads_kernel_matches_torch(backend):
-    """csrc/bo_heads.h through the C ABI (bo_nn_heads): policy FC (+ softmax) and the value head in one launch against
-    torch's float64 result, for batches that are not multiples of its tiles, launched repeatedly (the device-wide barrier
-    re-arms itself) and through the evaluate stage's forward_probs."""
+    """csrc/bo_heads.h through the C ABI (bo_nn_heads): policy FC (+ softmax) and the value head against torch's float64
+    result, for batches that are not multiples of its tiles and above the 256 of the bench."""
     import torch
     from betaone_amd import engine as E
 
@@ -472,10 +471,8 @@ def test_fused_heads_kernel_matches_torch(backend):
     wp = (torch.randn((4672, 128), generator=g) / 11.0).cuda(); bp = torch.randn(4672, generator=g).cuda()
     w1 = (torch.randn((256, 2048), generator=g) / 45.0).cuda(); b1 = torch.randn(256, generator=g).cuda()
     w2 = (torch.randn((1, 256), generator=g) / 16.0).cuda(); b2 = torch.randn(1, generator=g).cuda()
-    scratch = torch.zeros(16 + 16 * 512, device="cuda")
-    bmax = lib.bo_nn_heads_max_batch()
-    assert 256 <= bmax <= 512
-    for B in (1, 33, 256, 300, bmax):
+    scratch = torch.empty(4096 * 1100, device="cuda")
+    for B in (1, 33, 64, 200, 256, 1100):
         p = torch.rand((B, 128), generator=g).cuda(); v = torch.rand((B, 2048), generator=g).cuda()
         logits_ref = p.double() @ wp.double().t() + bp.double()
         value_ref = torch.tanh(torch.relu(v.double() @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double())
@@ -492,7 +489,3 @@ def test_fused_heads_kernel_matches_torch(backend):
             assert (val.double() - value_ref).abs().max().item() < 5e-6, (B, softmax)
             if softmax:
                 assert (out.sum(dim=1) - 1.0).abs().max().item() < 1e-5
-        assert scratch[:4].view(torch.int32).tolist()[:3] == [0, 0, 0]   # barrier re-armed, no time-out flag
-    out = torch.empty((1, 4672), device="cuda")
-    assert lib.bo_nn_heads(p.data_ptr(), v.data_ptr(), wp.data_ptr(), bp.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
-                           out.data_ptr(), val.data_ptr(), scratch.data_ptr(), bmax + 1, 1, 0) != 0   # more boards than resident workgroups allow
