@@ -125,6 +125,7 @@ class Rollout:
         self.games: List[Optional[GameState]] = [None] * self.G
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
         self._graph = None
+        self._graphs_n = {}         # n -> (graph of n back-to-back evaluate->step iterations, its output tensors)
         self._logits = self._value = None
         self.n_forward = 0          # NN forwards issued
         self.n_sims = 0             # simulations completed (NUM_SIMULATIONS per finished search)
@@ -211,6 +212,35 @@ class Rollout:
             self._graph.replay()
         else:
             self._eval_and_step_eager()
+
+    MAX_GRAPH_ITERATIONS = 12
+
+    def _eval_and_step_n(self, n: int):
+        """n x (net forward -> tree step).  With graphs: ONE launch of a graph that holds the n iterations back to back (between
+        two graph launches the device idles ~8 us -- profiles/r02_trace_percentiles.md -- between two nodes of one graph < 1 us)."""
+        if n <= 1 or not self.use_graph:
+            for _ in range(n):
+                self._eval_and_step()
+            return
+        if n > self.MAX_GRAPH_ITERATIONS:  # (fast mode with few leaves per step: hundreds of evaluations per search)
+            while n > 0:
+                k = min(n, self.MAX_GRAPH_ITERATIONS)
+                self._eval_and_step_n(k)
+                n -= k
+            return
+        g = self._graphs_n.get(n)
+        if g is None:
+            if self._graph is None:
+                self._capture()  # warms the allocator / MIOpen up as well
+            cg, keep = torch.cuda.CUDAGraph(), []
+            with torch.cuda.graph(cg):
+                for _ in range(n):
+                    logits, value = self._forward()
+                    self.eng.step(logits.data_ptr(), value.data_ptr(), self.policy_kind, self.nn_in.data_ptr(), self._stream())
+                    keep.append((logits, value))
+            g = self._graphs_n[n] = (cg, keep)
+        self.n_forward += n
+        g[0].replay()
 
     # ---- game slots ---------------------------------------------------------------------------------
     def start_games(self, slots: Sequence[int], game_ids: Sequence[int], rngs: Sequence, fens: Optional[Sequence] = None,
@@ -327,8 +357,7 @@ class Rollout:
             self.eng.step(self._f_logits.data_ptr(), self._f_value.data_ptr(), self.policy_kind, self.nn_in.data_ptr(), self._stream())
             burst -= 1
         while True:
-            for _ in range(burst):
-                self._eval_and_step()
+            self._eval_and_step_n(burst)
             if not poll:  # the caller asks the engine itself (bo_selfplay_turn, poll_first)
                 return
             running, _, _ = self.eng.poll(self._stream(), want_mask=False)
@@ -482,5 +511,6 @@ class Rollout:
             self.start_games([g], [nxt[0]], [nxt[1]], [nxt[2]])  # its first search is begun by the next play_ply
 
     def close(self):
-        self._graph = None
+        self._graph = self._fgraph = None
+        self._graphs_n = {}
         self.eng.close()
