@@ -48,6 +48,9 @@ class SeamRecorder:
         self.ro, self.watch, self.seam, self.key = ro, list(watch), {}, planes_key
         self._step, self._fwd = ro._eval_and_step, ro._forward_only
         ro._eval_and_step, ro._forward_only = self.eval_and_step, self.forward_only
+        # a search's iterations one graph launch at a time, so that every evaluation's planes can be read back
+        # (test_iterations_in_one_graph_launch_play_the_same_games covers the n-iterations-per-launch form)
+        ro._eval_and_step_n = lambda n: [self.eval_and_step() for _ in range(n)]
 
     def _planes(self):
         return self.ro.nn_in[self.watch].cpu().numpy()
@@ -97,6 +100,38 @@ def _check_games_against_oracle(ro, rec, watch, sims, plies):
             assert sorted(np.nonzero(rpi)[0].tolist()) == sorted(idx.tolist())
             for i, v in zip(idx, val):
                 assert np.float32(rpi[i]).view(np.uint32) == np.float32(v).view(np.uint32)
+
+
+def test_iterations_in_one_graph_launch_play_the_same_games(env):
+    """Rollout._eval_and_step_n: a search's expected evaluations replayed as ONE graph of n iterations give bit-identical
+    games (moves, pis) to n launches of the one-iteration graph."""
+    import torch
+    import network
+    from betaone_amd.fused_net import FusedPolicyValueNet
+    from betaone_amd.rollout import Rollout
+
+    config = env
+    config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 8, 2, 128
+    G, SIMS, PLIES = 64, 400, 6
+    torch.manual_seed(0)
+    net = FusedPolicyValueNet(network.PolicyValueNet().to("cuda:0").eval(), conv="tower_wg").to("cuda:0")
+    games = []
+    for max_iter in (1, Rollout.MAX_GRAPH_ITERATIONS):
+        ro = Rollout(net, G, num_simulations=SIMS, mcts_batch_size=96, device="cuda:0", use_graph=True, rng_mode="native", policy_kind="probs")
+        ro.MAX_GRAPH_ITERATIONS = max_iter
+        if max_iter == 1:
+            ro._eval_and_step_n = lambda n, ro=ro: [ro._eval_and_step() for _ in range(n)]
+        ro.start_games(list(range(G)), list(range(G)), list(range(G)))
+        for _ in range(PLIES):
+            assert ro.play_ply() == G
+        ro.eng.check_status()
+        assert (len(ro._graphs_n) > 0) == (max_iter > 1)
+        games.append([ro._finish(g, 0) for g in range(G)])
+        ro.close()
+    for a, b in zip(*games):
+        assert a.moves == b.moves and len(a.pis) == len(b.pis) == PLIES
+        for (ia, va), (ib, vb) in zip(a.pis, b.pis):
+            assert ia.tolist() == ib.tolist() and va.view(np.uint32).tolist() == vb.view(np.uint32).tolist()
 
 
 def test_config2_shard_256_games_800_sims_10x128_graph_and_winograd_tower(env):
