@@ -48,8 +48,33 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
     const int ocell = patch + 11;             // top-left of its 2x2 output block
     const int oc0 = wave * 16 + 4 * kq;       // this lane's 4 output channels: oc0 + r
 
-    for (int i = tid; i < CP * IMG; i += NT) P[i] = 0.0f;
-    for (int i = tid; i < C * IMG; i += NT) Q[i] = 0.0f;
+    // the first board's input planes are requested before anything else: their latency hides behind the zero fill
+    constexpr int XQ = 128 * 16 / NT;
+    auto fetch_board = [&](bo_f32x4(&xin)[XQ], int b) {
+        const bo_f32x4 *xb = reinterpret_cast<const bo_f32x4 *>(x + (size_t)b * CIN0 * 64);
+#pragma unroll
+        for (int q = 0; q < XQ; q++) {
+            const int i = tid + q * NT;
+            xin[q] = i < CIN0 * 16 ? xb[i] : bo_f32x4{0, 0, 0, 0};
+        }
+    };
+    auto stage_board = [&](const bo_f32x4(&xin)[XQ]) {  // into P (channels 120..127 of the padded input conv stay zero)
+#pragma unroll
+        for (int q = 0; q < XQ; q++) {
+            const int i = tid + q * NT;
+            const int ic = i >> 4, q16 = i & 15, r = q16 >> 1, c0 = (q16 & 1) * 4;
+            float *dst = P + ic * IMG + (r + 1) * 10 + c0 + 1;
+            dst[0] = xin[q][0]; dst[1] = xin[q][1]; dst[2] = xin[q][2]; dst[3] = xin[q][3];
+        }
+    };
+    {
+        bo_f32x4 xin[XQ];
+        if ((int)blockIdx.x < B) fetch_board(xin, blockIdx.x);
+        for (int i = tid; i < CP * IMG / 4; i += NT) reinterpret_cast<bo_f32x4 *>(P)[i] = bo_f32x4{0, 0, 0, 0};
+        for (int i = tid; i < C * IMG / 4; i += NT) reinterpret_cast<bo_f32x4 *>(Q)[i] = bo_f32x4{0, 0, 0, 0};
+        __syncthreads();
+        if ((int)blockIdx.x < B) stage_board(xin);
+    }
 
     bo_f32x4 acc[16];
     bo_f32x4 a0[4], a1[4], a2[4], a3[4];  // A fragments of four consecutive K-steps: [position quad]
@@ -100,6 +125,12 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
             dst[i * 32 + 1] = v23;
         }
     };
+    // max(x, 0) as the one instruction it is (fmaxf() first canonicalises its operand: a second v_max_f32 per value)
+    auto relu = [](float x) {
+        float y;
+        asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+        return y;
+    };
     auto read_b = [&](bo_f32x4(&v)[4], int buf, int sl) {  // B operands of local step sl (channels 4*sl + kq of the chunk)
         const bo_f32x4 *src = &V[buf][(4 * sl + kq) * 64 + n];
 #pragma unroll
@@ -130,22 +161,19 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
         }
     };
 
-    load_w(a0, layers[0].w_off4, 0);
-    load_w(a1, layers[0].w_off4, 1);
-    load_w(a2, layers[0].w_off4, 2);
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        // ---- stage the 120 input planes of board b into P (channels 120..127 of the padded input conv are zero) ----
-        {
-            const bo_f32x4 *xb = reinterpret_cast<const bo_f32x4 *>(x + (size_t)b * CIN0 * 64);
-            __syncthreads();  // the zero fill / the previous board's readers of P are done
-            for (int i = tid; i < 128 * 16; i += NT) {
-                const bo_f32x4 t = i < CIN0 * 16 ? xb[i] : bo_f32x4{0, 0, 0, 0};
-                const int ic = i >> 4, q = i & 15, r = q >> 1, c0 = (q & 1) * 4;
-                float *dst = P + ic * IMG + (r + 1) * 10 + c0 + 1;
-                dst[0] = t[0]; dst[1] = t[1]; dst[2] = t[2]; dst[3] = t[3];
-            }
-            __syncthreads();
+        // ---- the 120 input planes of board b are in P (the first board's: staged above) ----
+        if (b != (int)blockIdx.x) {
+            bo_f32x4 xin[XQ];
+            fetch_board(xin, b);
+            __syncthreads();  // the previous board's readers of P are done
+            stage_board(xin);
+        } else {
+            load_w(a0, layers[0].w_off4, 0);  // (a later board finds them loaded by the previous board's last K-steps)
+            load_w(a1, layers[0].w_off4, 1);
+            load_w(a2, layers[0].w_off4, 2);
         }
+        __syncthreads();
         for (int l = 0; l < n_layers; l++) {
             const bo_tower_layer L = layers[l];
             const bo_tower_layer Ln = layers[l + 1 < n_layers ? l + 1 : 0];
@@ -179,17 +207,23 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
 #pragma unroll
             for (int p2 = 0; p2 < 2; p2++) {
                 typedef float f2 __attribute__((ext_vector_type(2)));
+                // x - y on both halves as ONE v_pk_add_f32 with negated second operand (the compiler emits two v_sub_f32)
+                auto psub = [](f2 x, f2 y) {
+                    f2 d;
+                    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(y));
+                    return d;
+                };
                 f2 t0[4], t1[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const f2 a0 = {acc[j][2 * p2], acc[j][2 * p2 + 1]}, a1 = {acc[4 + j][2 * p2], acc[4 + j][2 * p2 + 1]};
                     const f2 a2 = {acc[8 + j][2 * p2], acc[8 + j][2 * p2 + 1]}, a3 = {acc[12 + j][2 * p2], acc[12 + j][2 * p2 + 1]};
                     t0[j] = a0 + a1 + a2;
-                    t1[j] = a1 - a2 - a3;
+                    t1[j] = psub(psub(a1, a2), a3);
                 }
                 const f2 bp = {bv[2 * p2], bv[2 * p2 + 1]};
-                const f2 o0 = t0[0] + t0[1] + t0[2] + bp, o1 = t0[1] - t0[2] - t0[3] + bp;
-                const f2 o2 = t1[0] + t1[1] + t1[2] + bp, o3 = t1[1] - t1[2] - t1[3] + bp;
+                const f2 o0 = t0[0] + t0[1] + t0[2] + bp, o1 = psub(psub(t0[1], t0[2]), t0[3]) + bp;
+                const f2 o2 = t1[0] + t1[1] + t1[2] + bp, o3 = psub(psub(t1[1], t1[2]), t1[3]) + bp;
                 o[2 * p2][0] = o0[0]; o[2 * p2 + 1][0] = o0[1];
                 o[2 * p2][1] = o1[0]; o[2 * p2 + 1][1] = o1[1];
                 o[2 * p2][2] = o2[0]; o[2 * p2 + 1][2] = o2[1];
@@ -203,7 +237,7 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
                 for (int r = 0; r < 4; r++) {
                     float *c = out + (oc0 + r) * IMG + ocell;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) o[r][e] = fmaxf(o[r][e], 0.0f);
+                    for (int e = 0; e < 4; e++) o[r][e] = relu(o[r][e]);
                     c[0] = o[r][0]; c[1] = o[r][1]; c[10] = o[r][2]; c[11] = o[r][3];
                     if (L.kind == 0)
 #pragma unroll
@@ -256,7 +290,7 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         const float t = L.kind == 3 ? o[r][e] * gate[r] + skip[r][e] : o[r][e] + skip[r][e];
-                        skip[r][e] = fmaxf(t, 0.0f);
+                        skip[r][e] = relu(t);
                     }
                     c[0] = skip[r][0]; c[1] = skip[r][1]; c[10] = skip[r][2]; c[11] = skip[r][3];
                     if (L.last && y) {

@@ -45,6 +45,12 @@ for step in "$@"; do
              python scripts/kernel_percentiles.py $out/${tag}_trace > $out/${tag}_trace_percentiles.md 2>&1 ; rm -f $out/${tag}_trace/*/*_kernel_trace.csv.keep ; tail -n 40 $out/${tag}_trace_percentiles.md ;;
     pmcfast) mkdir -p $out/${tag}_pmcfast; run pmcfast 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex "bo_k_fw" --output-format csv -d $out/${tag}_pmcfast -- python bench.py --fast --games 4096 --leaves 4 --net-dtype fp16 --preroll 4 --steps 1 --warmup 1 --opening-steps 0 --no-cpu-baseline --no-graph --wide-trees 32768 ;
              python scripts/pmc_summary.py $out/${tag}_pmcfast > $out/${tag}_pmcfast.md 2>&1 ; cat $out/${tag}_pmcfast.md ;;
+    pmctower) for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
+                 p=$(echo $pass | cut -d" " -f1); mkdir -p $out/${tag}_pmctower_$p;
+                 run pmctower_$p 400 rocprofv3 --pmc $pass --kernel-trace --kernel-include-regex "bo_k_tower_wg|bo_k_heads" --output-format csv -d $out/${tag}_pmctower_$p -- python scripts/forward_profile.py tower_wg 256 ;
+                 for c in $pass; do python scripts/pmc_summary.py $out/${tag}_pmctower_$p $c >> $out/${tag}_pmctower.md 2>&1 ; done ;
+                 rm -rf $out/${tag}_pmctower_$p ;
+              done ; cat $out/${tag}_pmctower.md ;;
     dist2nccl) run bench_dist2 400 python bench.py --gpus 2 --share-gpu --dist-backend gloo --games 128 --steps 40 --no-cpu-baseline --no-roofline ;;
     ucitrace) mkdir -p $out/${tag}_ucitrace; run ucitrace 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_ucitrace -- python tests/uci_latency.py ;
              python scripts/kernel_percentiles.py $out/${tag}_ucitrace bo_k_ Cijk softmax conv elementwise > $out/${tag}_ucitrace_percentiles.md 2>&1 ; cat $out/${tag}_ucitrace_percentiles.md ;;
