@@ -38,6 +38,11 @@ __global__ void __launch_bounds__(C * 4)
 bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, const float *__restrict__ params,
               const bo_tower_layer *__restrict__ layers, int n_layers, float *__restrict__ y, int B, bo_tower_head head = bo_tower_head{}) {
     constexpr int IMG = 100, NT = C * 4, CP = 128, CIN0 = 120, OB = C / 16;
+    // C = 128: the K order of every layer is permuted so that a wave transforms only input channels that it produced itself
+    // as the previous layer's output (K-step 4c + sl = channels 16*(4*(c&1) + sl) + 4*(c>>1) + [0,4), the host packs the weights
+    // in that order): chunk 0 of the NEXT layer is transformed right behind a wave's own epilogue, before the layer's one
+    // workgroup barrier, instead of behind it and in front of a second barrier.
+    constexpr bool OWN = C == 128;
     __shared__ __attribute__((aligned(16))) float P[CP * IMG];  // staged input planes / mid activation of a block
     __shared__ __attribute__((aligned(16))) float Q[C * IMG];   // block input
     __shared__ bo_f32x4 V[2][16 * 4 * 16];                      // transformed patches: [buffer][channel 16][pos quad][tile]
@@ -100,8 +105,8 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
     // odd ones by waves 4-7 (one of each per SIMD), at C = 64 by all four waves
     auto my_chunk = [&](int c) { return C == 128 ? (wave >> 2) == (c & 1) : true; };
     auto transform = [&](const float *img, int c) {  // V[c&1][channel][.][tile] = B^T d B for one (channel, tile) per lane
-        const int icl = 4 * (wave & 3) + kq;
-        const float *p = img + (16 * c + icl) * IMG + patch;
+        const int icl = 4 * (wave & 3) + kq;  // slot in the chunk: K-step wave & 3, row kq
+        const float *p = img + (OWN ? 16 * wave + 4 * (c >> 1) + kq : 16 * c + icl) * IMG + patch;
         // 32 additions as 16 packed ones (v_pk_add_f32 with per-lane operand selection and negation): vector ALU work does
         // not overlap this SIMD's MFMAs, every instruction here comes out of the other wave's matrix time.
         typedef float f2 __attribute__((ext_vector_type(2)));
@@ -174,15 +179,22 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
             load_w(a2, layers[0].w_off4, 2);
         }
         __syncthreads();
+        if (OWN) {  // chunk 0 of the input convolution (every later layer's: behind the previous layer's epilogue)
+            if (LAB != 2 && LAB != 6 && my_chunk(0)) transform(P, 0);
+            __syncthreads();
+        }
+        bo_tower_layer Lnext = layers[0];
         for (int l = 0; l < n_layers; l++) {
-            const bo_tower_layer L = layers[l];
-            const bo_tower_layer Ln = layers[l + 1 < n_layers ? l + 1 : 0];
+            const bo_tower_layer L = Lnext;  // (fetched one layer ahead: no scalar-load latency at the top of a layer)
+            const bo_tower_layer Ln = Lnext = layers[l + 1 < n_layers ? l + 1 : 0];
             const float *img = L.kind == 1 ? Q : P;
             float bv[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) bv[r] = params[L.bias_off + oc0 + r];
-            if (LAB != 2 && LAB != 6 && my_chunk(0)) transform(img, 0);
-            __syncthreads();
+            if (!OWN) {
+                if (LAB != 2 && LAB != 6 && my_chunk(0)) transform(img, 0);
+                __syncthreads();
+            }
             // One chunk = 4 K-steps = one turn of the weight-set rotation: step s multiplies with set s%4 while the weights
             // of step s+3 (possibly the first steps of the next layer) are loaded into set (s+3)%4.
             const int nk = L.t4, nchunks = nk >> 2;
@@ -299,6 +311,12 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
                         *reinterpret_cast<float2 *>(g2 + 8) = float2{skip[r][2], skip[r][3]};
                     }
                 }
+            }
+            if (OWN && l + 1 < n_layers && LAB != 2 && LAB != 6 && my_chunk(0)) {
+                // this wave's output channels are the next layer's chunk-0 input channels of this wave: LDS operations of one
+                // wave execute in order, so its reads below see its writes above without a barrier
+                __builtin_amdgcn_wave_barrier();
+                transform(L.kind == 1 ? P : Q, 0);
             }
             __syncthreads();
         }

@@ -46,11 +46,22 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
 _WG_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
 
 
+def winograd_k_order(c_out: int, c_in: int) -> list:
+    """Input channel of (K-step, row k) of a BO_TOWER_WINOGRAD layer, flattened [step][k] (include/betaone_engine.h).
+    128 filters: K-step 4c + sl covers channels 16*(4*(c & 1) + sl) + 4*(c >> 1) + k -- the four channels that wave
+    4*(c & 1) + sl of the kernel produced itself in the previous layer; otherwise the natural order 4*step + k."""
+    if c_out == 128 and c_in == 128:
+        return [16 * (4 * (c & 1) + sl) + 4 * (c >> 1) + k for c in range(8) for sl in range(4) for k in range(4)]
+    return list(range(c_in))
+
+
 def pack_conv_weight_winograd(w: torch.Tensor) -> torch.Tensor:
     """[c_out, c_in, 3, 3] -> U = G g G^T laid out [c_in/4][c_out/16][4][64][4] (include/betaone_engine.h,
-    BO_TOWER_WINOGRAD): element (step, ob, pq, lane, e) = U[4*pq + e][16*ob + (lane & 15)][4*step + (lane >> 4)]."""
+    BO_TOWER_WINOGRAD): element (step, ob, pq, lane, e) = U[4*pq + e][16*ob + (lane & 15)][channel(step, lane >> 4)],
+    channel() = winograd_k_order."""
     co, ci = w.shape[0], w.shape[1]
     u = torch.einsum("ai,ocij,bj->aboc", _WG_G, w.double(), _WG_G).reshape(16, co, ci)  # [pos][oc][ic]
+    u = u[:, :, winograd_k_order(co, ci)]
     u = u.reshape(4, 4, co // 16, 16, ci // 4, 4)  # [pq][e][ob][o16][step][k]
     return u.permute(4, 2, 0, 5, 3, 1).contiguous().float()  # [step][ob][pq][k][o16][e]
 
