@@ -154,6 +154,9 @@ def select_roofline(args, device):
             "levels_per_launch": levels, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(t * 1e3, 4)}
 
 
+TOWER_WG_PMC_BYTES = 183_200_000  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of bo_k_tower_wg<128>, 256 boards (profiles/r02_tower_wg_pmc.md)
+
+
 def nn_roofline(net, batch, device):
     """MFMA roofline of the evaluate stage's tower kernel (csrc/bo_tower_wg.h / bo_tower.h), timed with events on the
     stream it is launched on.  `achieved` counts the fp32 MFMA flops the kernel executes (Winograd F(2x2,3x3): 16
@@ -165,22 +168,37 @@ def nn_roofline(net, batch, device):
     C, n_conv = net.c, 1 + 2 * len(net.blocks)
     x = torch.rand((batch, 120, 8, 8), device=device)
     with torch.no_grad():
-        for _ in range(5):
-            net._tower_forward(x, heads=conv == "tower_wg")
+        # the launches are timed the way the search issues them: nodes of a captured graph, back to back on one stream (an eager
+        # launch of this kernel adds ~10 us of launch gap to every repetition, which is not kernel time; rocprofv3's per-kernel
+        # duration of the same run is the cross-check -- profiles/r02_bench_kernel_stats.md)
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                net._tower_forward(x, heads=conv == "tower_wg")
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        per_graph, replays = 20, 4
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            keep = [net._tower_forward(x, heads=conv == "tower_wg") for _ in range(per_graph)]
+        g.replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 50
         e0.record()
-        for _ in range(reps):
-            net._tower_forward(x, heads=conv == "tower_wg")
+        for _ in range(replays):
+            g.replay()
         e1.record()
         e1.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / reps
+        del keep
+    us = e0.elapsed_time(e1) * 1e3 / (per_graph * replays)
     per_mac = 16 * 16 if conv == "tower_wg" else 9 * 64       # multiplies per (c_in, c_out) pair and board
     executed = 2.0 * per_mac * C * (128 + (n_conv - 1) * C) * batch
     algorithmic = 2.0 * 9 * 64 * C * (120 + (n_conv - 1) * C) * batch
     peak = 157.3  # TFLOP/s dense fp32 MFMA: 256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz (MI355X_MICROARCH.md)
     return {"bound": "mfma", "kernel": "bo_k_tower_wg" if conv == "tower_wg" else "bo_k_tower", "achieved": round(executed / us / 1e6, 1), "peak": peak,
-            "unit": "TFLOP/s", "frac": round(executed / us / 1e6 / peak, 4), "traffic": None, "avg_launch_us": round(us, 1),
+            "unit": "TFLOP/s", "frac": round(executed / us / 1e6 / peak, 4), "traffic": TOWER_WG_PMC_BYTES if conv == "tower_wg" and batch == 256 and C == 128 else None,
+            "traffic_source": "profiles/r02_tower_wg_pmc.md (2 x FETCH_SIZE + WRITE_SIZE per launch: every XCD's L2 streams the 21 MB of weights once)",
+            "avg_launch_us": round(us, 1),
             "boards_per_launch": batch, "conv_layers": n_conv,
             "algorithmic_direct_conv_tflops": round(algorithmic / us / 1e6, 1),
             "note": "fp32 v_mfma_f32_16x16x4_f32; one workgroup per board, activations LDS-resident for the whole tower"}

@@ -45,7 +45,7 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
     constexpr bool OWN = C == 128;
     __shared__ __attribute__((aligned(16))) float P[CP * IMG];  // staged input planes / mid activation of a block
     __shared__ __attribute__((aligned(16))) float Q[C * IMG];   // block input
-    __shared__ bo_f32x4 V[2][16 * 4 * 16];                      // transformed patches: [buffer][channel 16][pos quad][tile]
+    __shared__ bo_f32x4 V[3][16 * 4 * 16];                      // transformed patches: [buffer][channel 16][pos quad][tile]
     __shared__ float pooled[C], hid[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kq = lane >> 4, n = lane & 15;
     const int ty = n >> 2, tx = n & 3;
@@ -104,7 +104,7 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
     // chunk c of a layer = input channels 16c..16c+15; at C = 128 the even chunks are transformed by waves 0-3 and the
     // odd ones by waves 4-7 (one of each per SIMD), at C = 64 by all four waves
     auto my_chunk = [&](int c) { return C == 128 ? (wave >> 2) == (c & 1) : true; };
-    auto transform = [&](const float *img, int c) {  // V[c&1][channel][.][tile] = B^T d B for one (channel, tile) per lane
+    auto transform = [&](const float *img, int c, int vbuf) {  // V[vbuf][channel][.][tile] = B^T d B of chunk c, one (channel, tile) per lane
         const int icl = 4 * (wave & 3) + kq;  // slot in the chunk: K-step wave & 3, row kq
         const float *p = img + (OWN ? 16 * wave + 4 * (c >> 1) + kq : 16 * c + icl) * IMG + patch;
         // 32 additions as 16 packed ones (v_pk_add_f32 with per-lane operand selection and negation): vector ALU work does
@@ -120,7 +120,7 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
         wl[1] = dl[1] + dl[2]; wh[1] = dh[1] + dh[2];
         wl[2] = dl[2] - dl[1]; wh[2] = dh[2] - dh[1];
         wl[3] = dl[1] - dl[3]; wh[3] = dh[1] - dh[3];
-        f2 *dst = reinterpret_cast<f2 *>(&V[c & 1][icl * 64 + n]);
+        f2 *dst = reinterpret_cast<f2 *>(&V[vbuf][icl * 64 + n]);
 #pragma unroll
         for (int i = 0; i < 4; i++) {  // (.) B per row: (w0 - w2, w1 + w2) and (w2 - w1, w1 - w3), one instruction each
             f2 v01, v23;
@@ -147,13 +147,14 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
 #define BO_WG_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
     // first = the layer's first K-step: its MFMAs take a zero C operand (an inline constant) instead of accumulators that 64
     // v_mov instructions per wave and layer would have had to clear
-    auto kstep = [&](const bo_f32x4(&a)[4], const bo_f32x4(&v)[4], bo_f32x4(&an)[4], bo_f32x4(&vn)[4], int buf, int sl_next, int w_off4n,
+    // (vbuf_next, sl_next): where the B operands of the NEXT K-step are (the last K-step of a chunk reads the first of the next chunk)
+    auto kstep = [&](const bo_f32x4(&a)[4], const bo_f32x4(&v)[4], bo_f32x4(&an)[4], bo_f32x4(&vn)[4], int vbuf_next, int sl_next, int w_off4n,
                      int step_w, auto first) {
-        const bo_f32x4 *src = &V[buf][(4 * (sl_next < 0 ? 0 : sl_next) + kq) * 64 + n];
+        const bo_f32x4 *src = &V[vbuf_next][(4 * sl_next + kq) * 64 + n];
 #pragma unroll
         for (int pq = 0; pq < 4; pq++) {
             if (LAB != 1 && LAB != 6) an[pq] = ldw(w_off4n, step_w, pq);
-            if (sl_next >= 0) vn[pq] = src[pq * 16];
+            vn[pq] = src[pq * 16];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 if constexpr (decltype(first)::value)
@@ -179,10 +180,13 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
             load_w(a2, layers[0].w_off4, 2);
         }
         __syncthreads();
-        if (OWN) {  // chunk 0 of the input convolution (every later layer's: behind the previous layer's epilogue)
-            if (LAB != 2 && LAB != 6 && my_chunk(0)) transform(P, 0);
-            __syncthreads();
+        // chunks 0 and 1 of the input convolution (every later layer's: behind the previous layer's epilogue)
+        int vb0 = 0;  // V buffer of the current layer's chunk 0; chunk c is in buffer (vb0 + c) % 3
+        if (LAB != 2 && LAB != 6) {
+            if (my_chunk(0)) transform(P, 0, 0);
+            if (my_chunk(1)) transform(P, 1, 1);
         }
+        __syncthreads();
         bo_tower_layer Lnext = layers[0];
         for (int l = 0; l < n_layers; l++) {
             const bo_tower_layer L = Lnext;  // (fetched one layer ahead: no scalar-load latency at the top of a layer)
@@ -191,26 +195,36 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
             float bv[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) bv[r] = params[L.bias_off + oc0 + r];
-            if (!OWN) {
-                if (LAB != 2 && LAB != 6 && my_chunk(0)) transform(img, 0);
-                __syncthreads();
-            }
             // One chunk = 4 K-steps = one turn of the weight-set rotation: step s multiplies with set s%4 while the weights
             // of step s+3 (possibly the first steps of the next layer) are loaded into set (s+3)%4.
             const int nk = L.t4, nchunks = nk >> 2;
-            auto chunk = [&](int c, auto first) {
-                const int s = 4 * c, buf = c & 1, t4 = s + 4, t5 = s + 5, t6 = s + 6;
-                if (LAB != 2 && LAB != 6 && c + 1 < nchunks && my_chunk(c + 1)) transform(img, c + 1);
-                read_b(va, buf, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                kstep(a0, va, a3, vb, buf, 1, L.w_off4, s + 3, first);
-                kstep(a1, vb, a0, va, buf, 2, t4 < nk ? L.w_off4 : Ln.w_off4, t4 < nk ? t4 : t4 - nk, std::false_type{});
-                kstep(a2, va, a1, vb, buf, 3, t5 < nk ? L.w_off4 : Ln.w_off4, t5 < nk ? t5 : t5 - nk, std::false_type{});
-                kstep(a3, vb, a2, va, buf, -1, t6 < nk ? L.w_off4 : Ln.w_off4, t6 < nk ? t6 : t6 - nk, std::false_type{});
-                if (LAB != 5 && LAB != 6 && c + 1 < nchunks) __syncthreads();  // V[buf] is free for chunk c+2, V[buf^1] is complete
+            // V is triple-buffered and a chunk's transform runs TWO chunks ahead, behind the one workgroup barrier in the middle
+            // of a chunk: at that barrier chunk c+1's operands (transformed during chunk c-1) are complete, and every wave is
+            // done with chunk c-1's buffer, which chunk c+2's transform overwrites.  The B operands of a chunk's first K-step are
+            // read by the previous chunk's last K-step: no barrier is followed by an exposed LDS read inside a layer.
+            auto chunk = [&](int c, int vbuf, auto first) {
+                const int s = 4 * c, t4 = s + 4, t5 = s + 5, t6 = s + 6;
+                const int vbuf1 = vbuf == 2 ? 0 : vbuf + 1, vbuf2 = vbuf1 == 2 ? 0 : vbuf1 + 1;
+                kstep(a0, va, a3, vb, vbuf, 1, L.w_off4, s + 3, first);
+                kstep(a1, vb, a0, va, vbuf, 2, t4 < nk ? L.w_off4 : Ln.w_off4, t4 < nk ? t4 : t4 - nk, std::false_type{});
+                if (LAB != 5 && LAB != 6) __syncthreads();
+                if (LAB != 2 && LAB != 6 && c + 2 < nchunks && my_chunk(c + 2)) {
+                    __builtin_amdgcn_s_setprio(3);  // its vector instructions back to back, not alternating with the other wave's MFMAs
+                    transform(img, c + 2, vbuf2);
+                    __builtin_amdgcn_s_setprio(0);
+                }
+                kstep(a2, va, a1, vb, vbuf, 3, t5 < nk ? L.w_off4 : Ln.w_off4, t5 < nk ? t5 : t5 - nk, std::false_type{});
+                kstep(a3, vb, a2, va, vbuf1, 0, t6 < nk ? L.w_off4 : Ln.w_off4, t6 < nk ? t6 : t6 - nk, std::false_type{});
             };
-            chunk(0, std::true_type{});
-            for (int c = 1; c < nchunks; c++) chunk(c, std::false_type{});
+            read_b(va, vb0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            int vbc = vb0;
+            chunk(0, vbc, std::true_type{});
+            for (int c = 1; c < nchunks; c++) {
+                vbc = vbc == 2 ? 0 : vbc + 1;
+                chunk(c, vbc, std::false_type{});
+            }
+            vb0 = vbc == 2 ? 0 : vbc + 1;  // the next layer's chunk 0
 
             // ---- output transform Y = A^T M A per row r: M[i][j] = acc[4i+j][r] ----
             // (two output channels per instruction: the accumulator registers of rows r, r+1 are adjacent -> v_pk_add_f32;
@@ -312,11 +326,20 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
                     }
                 }
             }
-            if (OWN && l + 1 < n_layers && LAB != 2 && LAB != 6 && my_chunk(0)) {
-                // this wave's output channels are the next layer's chunk-0 input channels of this wave: LDS operations of one
-                // wave execute in order, so its reads below see its writes above without a barrier
-                __builtin_amdgcn_wave_barrier();
-                transform(L.kind == 1 ? P : Q, 0);
+            if (l + 1 < n_layers && LAB != 2 && LAB != 6) {
+                float *nimg = L.kind == 1 ? P : Q;  // the image just written = the next layer's input
+                const int vb1 = vb0 == 2 ? 0 : vb0 + 1;
+                if (OWN) {
+                    // this wave's output channels are the next layer's input channels of this wave's chunks: LDS operations of one
+                    // wave execute in order, so its reads below see its writes above without a barrier.  (Buffers: the last chunk
+                    // is still being read by slower waves from (vb0 + 2) % 3; vb0 and vb1 were last read before its barrier.)
+                    __builtin_amdgcn_wave_barrier();
+                    transform(nimg, my_chunk(0) ? 0 : 1, my_chunk(0) ? vb0 : vb1);
+                } else {
+                    __syncthreads();
+                    transform(nimg, 0, vb0);
+                    transform(nimg, 1, vb1);
+                }
             }
             __syncthreads();
         }
