@@ -157,20 +157,22 @@ def select_roofline(args, device):
 TOWER_WG_PMC_BYTES = 183_200_000  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of bo_k_tower_wg<128>, 256 boards (profiles/r02_tower_wg_pmc.md)
 
 
-def nn_roofline(net, batch, device):
+def nn_roofline(net, batch, device, ro=None, drv=None, plies=3):
     """MFMA roofline of the evaluate stage's tower kernel (csrc/bo_tower_wg.h / bo_tower.h), timed with events on the
     stream it is launched on.  `achieved` counts the fp32 MFMA flops the kernel executes (Winograd F(2x2,3x3): 16
     multiplies per 2x2 output tile and input channel, input conv padded to 128 channels); `algorithmic` is the direct
-    3x3 convolution's flop count for the same layers (what MIOpen / the reference's net would be charged)."""
+    3x3 convolution's flop count for the same layers (what MIOpen / the reference's net would be charged).
+    Launch duration: `plies` more plies of THIS run's workload (same engine, same games) are played with eager launches and
+    an event pair around every tower launch (FusedPolicyValueNet.tower_events) -- the kernel between the tree steps it runs
+    between in the timed region, which is what rocprofv3's per-kernel average of the same command shows
+    (profiles/r02_bench_kernel_stats.md).  `back_to_back_us` is the same kernel replayed as 20 consecutive graph nodes:
+    nothing but fp32 MFMA work for 30 ms, ~4 % slower per launch."""
     conv = getattr(net, "conv", None)
     if conv not in ("tower", "tower_wg"):
         return None
     C, n_conv = net.c, 1 + 2 * len(net.blocks)
     x = torch.rand((batch, 120, 8, 8), device=device)
     with torch.no_grad():
-        # the launches are timed the way the search issues them: nodes of a captured graph, back to back on one stream (an eager
-        # launch of this kernel adds ~10 us of launch gap to every repetition, which is not kernel time; rocprofv3's per-kernel
-        # duration of the same run is the cross-check -- profiles/r02_bench_kernel_stats.md)
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
@@ -190,7 +192,20 @@ def nn_roofline(net, batch, device):
         e1.record()
         e1.synchronize()
         del keep
-    us = e0.elapsed_time(e1) * 1e3 / (per_graph * replays)
+    b2b = e0.elapsed_time(e1) * 1e3 / (per_graph * replays)
+    us, n_timed, how = b2b, per_graph * replays, "20 consecutive graph nodes x 4 replays"
+    if ro is not None and drv is not None and conv == "tower_wg":
+        graph = ro.use_graph
+        ro.use_graph = False
+        net.tower_events = []
+        for _ in range(plies):
+            drv.step()
+        torch.cuda.synchronize(device)
+        ev, net.tower_events = net.tower_events, None
+        ro.use_graph = graph
+        if ev:
+            us = sum(a.elapsed_time(b) for a, b in ev) * 1e3 / len(ev)
+            n_timed, how = len(ev), f"event pair around every launch of {plies} more plies of this workload (eager launches)"
     per_mac = 16 * 16 if conv == "tower_wg" else 9 * 64       # multiplies per (c_in, c_out) pair and board
     executed = 2.0 * per_mac * C * (128 + (n_conv - 1) * C) * batch
     algorithmic = 2.0 * 9 * 64 * C * (120 + (n_conv - 1) * C) * batch
@@ -198,7 +213,7 @@ def nn_roofline(net, batch, device):
     return {"bound": "mfma", "kernel": "bo_k_tower_wg" if conv == "tower_wg" else "bo_k_tower", "achieved": round(executed / us / 1e6, 1), "peak": peak,
             "unit": "TFLOP/s", "frac": round(executed / us / 1e6 / peak, 4), "traffic": TOWER_WG_PMC_BYTES if conv == "tower_wg" and batch == 256 and C == 128 else None,
             "traffic_source": "profiles/r02_tower_wg_pmc.md (2 x FETCH_SIZE + WRITE_SIZE per launch: every XCD's L2 streams the 21 MB of weights once)",
-            "avg_launch_us": round(us, 1),
+            "avg_launch_us": round(us, 1), "launches_timed": n_timed, "timing": how, "back_to_back_us": round(b2b, 1),
             "boards_per_launch": batch, "conv_layers": n_conv,
             "algorithmic_direct_conv_tflops": round(algorithmic / us / 1e6, 1),
             "note": "fp32 v_mfma_f32_16x16x4_f32; one workgroup per board, activations LDS-resident for the whole tower"}
@@ -528,7 +543,7 @@ def main():
         # section 8f asks to price).  The north star's select target on the section-8d synthetic wide workload
         # (bo_k_select_wide: the same child-block layout and arithmetic, 262144 static trees) is reported beside it.
         wide = select_roofline(args, device)
-        rn = nn_roofline(net, G, device) if (not args.fast and args.net_dtype == "fp32") else None
+        rn = nn_roofline(net, G, device, ro if dist is None else None, drv) if (not args.fast and args.net_dtype == "fp32") else None
         if fast_roof is not None:
             out["roofline"] = fast_roof
         elif rn:

@@ -12,10 +12,11 @@
 //     K-step per wave cost exactly their issue time), so it is done ONCE per (channel, tile) and shared: a lane reads
 //     the 4x4 patch of its (channel, tile) from the zero-padded 10x10 LDS image, applies B^T d B (32 adds) and
 //     stores the 16 positions to an LDS staging buffer V[channel][position quad][tile] that all waves read as their
-//     B operand (4 ds_read_b128 per K-step, conflict-free).  V is double-buffered in chunks of 16 channels
-//     (4 K-steps); the chunk after the current one is transformed by four of the waves while all waves multiply.
+//     B operand (4 ds_read_b128 per K-step, conflict-free).  V is triple-buffered in chunks of 16 channels
+//     (4 K-steps); the chunk two after the current one is transformed by four of the waves while all waves multiply
+//     (one workgroup barrier per chunk, in its middle; see `chunk` below).
 //   * D lane (n = lane&15, rows 4*(lane>>4)+r) holds, over the 16 position accumulators, the complete 4x4 M matrix of
-//     tile n for 4 output channels: A^T M A (24 adds), bias, ReLU, the skip connection (kept in registers: a lane owns
+//     tile n for 4 output channels: A^T M A (24 adds), bias, ReLU, the skip connection (read back from LDS: a lane owns
 //     the same (channels, tile) in every layer) and the SE gate happen in registers; the 2x2 result goes straight
 //     into the other LDS image.
 //   * A operands: the host stores U = G g G^T as Up[step][oc/16][pos/4][lane = 16*(ic&3) + (oc&15)][pos&3], one
@@ -84,7 +85,6 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
     bo_f32x4 acc[16];
     bo_f32x4 a0[4], a1[4], a2[4], a3[4];  // A fragments of four consecutive K-steps: [position quad]
     bo_f32x4 va[4], vb[4];                // B operands of two consecutive K-steps: [position quad]
-    float skip[4][4];                     // block input at this lane's (channels, tile): the skip connection
     // Weight fragments come through a buffer descriptor: the per-thread part of the address (wave, lane) is ONE constant
     // VGPR, the per-step part (layer offset, K-step) is scalar arithmetic, the position quad is the instruction's immediate
     // offset -- no vector ALU work per load (as 64-bit global pointers every K-step cost three VALU address operations,
@@ -265,9 +265,6 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
 #pragma unroll
                     for (int e = 0; e < 4; e++) o[r][e] = relu(o[r][e]);
                     c[0] = o[r][0]; c[1] = o[r][1]; c[10] = o[r][2]; c[11] = o[r][3];
-                    if (L.kind == 0)
-#pragma unroll
-                        for (int e = 0; e < 4; e++) skip[r][e] = o[r][e];
                 }
             } else {
                 float gate[4] = {1.0f, 1.0f, 1.0f, 1.0f};
@@ -313,16 +310,17 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
                 for (int r = 0; r < 4; r++) {
                     const int oc = oc0 + r;
                     float *c = Q + oc * IMG + ocell;
+                    // the skip connection: the block's input at this lane's (channel, tile) is what this lane stored here two
+                    // layers ago (kept in registers it cost 16 VGPRs through both convolutions' K loops)
+                    const float skip[4] = {c[0], c[1], c[10], c[11]};
+                    float t[4];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const float t = L.kind == 3 ? o[r][e] * gate[r] + skip[r][e] : o[r][e] + skip[r][e];
-                        skip[r][e] = relu(t);
-                    }
-                    c[0] = skip[r][0]; c[1] = skip[r][1]; c[10] = skip[r][2]; c[11] = skip[r][3];
+                    for (int e = 0; e < 4; e++) t[e] = relu(L.kind == 3 ? o[r][e] * gate[r] + skip[e] : o[r][e] + skip[e]);
+                    c[0] = t[0]; c[1] = t[1]; c[10] = t[2]; c[11] = t[3];
                     if (L.last && y) {
                         float *g2 = yb + oc * 64 + 16 * ty + 2 * tx;
-                        *reinterpret_cast<float2 *>(g2) = float2{skip[r][0], skip[r][1]};
-                        *reinterpret_cast<float2 *>(g2 + 8) = float2{skip[r][2], skip[r][3]};
+                        *reinterpret_cast<float2 *>(g2) = float2{t[0], t[1]};
+                        *reinterpret_cast<float2 *>(g2 + 8) = float2{t[2], t[3]};
                     }
                 }
             }

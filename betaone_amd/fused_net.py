@@ -339,7 +339,13 @@ class FusedPolicyValueNet(nn.Module):
         if heads:
             pa = torch.empty((B, self._head_split * 64), dtype=torch.float32, device=x.device)
             pb = torch.empty((B, (self._head_ch - self._head_split) * 64), dtype=torch.float32, device=x.device)
+            timed = self.__dict__.get("tower_events")  # measurement hook (bench.py): a list -> one (start, end) event pair per launch
+            if timed is not None:
+                timed.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+                timed[-1][0].record()
             rc = self.lib.bo_nn_tower_forward(self._tower, x.data_ptr(), None, pa.data_ptr(), pb.data_ptr(), B, stream)
+            if timed is not None:
+                timed[-1][1].record()
             out = (pa, pb)
         else:
             y = torch.empty((B, self.c, 8, 8), dtype=torch.float32, device=x.device)
