@@ -483,9 +483,11 @@ def main():
         opening = {"nodes_per_sec": round((ro.n_sims - so) / do, 1), "ms_per_step": round(do / args.opening_steps * 1e3, 3),
                    "steps": args.opening_steps, "note": "all games within their first ~25 plies; not the headline"}
 
-    fast_roof = None
+    fast_roof = rn = None
     if rank == 0 and args.fast and not args.no_roofline and dist is None:
         fast_roof = fast_select_roofline(ro, drv, 2)
+    if rank == 0 and not args.no_roofline and not args.fast and args.net_dtype == "fp32":
+        rn = nn_roofline(net, G, device, ro if dist is None else None, drv)  # (more plies of this workload, after everything reported)
 
     out = None
     if rank == 0:
@@ -543,7 +545,6 @@ def main():
         # section 8f asks to price).  The north star's select target on the section-8d synthetic wide workload
         # (bo_k_select_wide: the same child-block layout and arithmetic, 262144 static trees) is reported beside it.
         wide = select_roofline(args, device)
-        rn = nn_roofline(net, G, device, ro if dist is None else None, drv) if (not args.fast and args.net_dtype == "fp32") else None
         if fast_roof is not None:
             out["roofline"] = fast_roof
         elif rn:
