@@ -154,7 +154,7 @@ def select_roofline(args, device):
             "levels_per_launch": levels, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(t * 1e3, 4)}
 
 
-TOWER_WG_PMC_BYTES = 183_200_000  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of bo_k_tower_wg<128>, 256 boards (profiles/r02_tower_wg_pmc.md)
+TOWER_WG_PMC_BYTES = 187_641_000  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of bo_k_tower_wg<128>, 256 boards (profiles/r02_tower_wg_pmc.md)
 
 
 def nn_roofline(net, batch, device, ro=None, drv=None, plies=3):
