@@ -514,14 +514,18 @@ extern "C" int bo_search_stop(bo_engine *e, const int32_t *stop_mask, int32_t *s
     return BO_OK;
 }
 
-extern "C" int bo_search_result(bo_engine *e, int32_t *res_n, int32_t *res_idx, float *res_val, int32_t *best_idx,
-                                int32_t *best_move, int32_t *total_visits, void *stream) {
-    if (!e) return fail(BO_E_ARG, "null engine");
+// the result kernel and the copy of its block, enqueued (no wait)
+static int result_enqueue(bo_engine *e, void *stream) {
     const size_t G = (size_t)e->d.c.G;
     if (e->fast) RT(RT_LAUNCH(bo_k_fw_result, e->d.c.G, stream, e->d, e->f));
     else RT(RT_LAUNCH(bo_k_result, e->d.c.G, stream, e->d));
     RT(rt_d2h(e->h_res, e->d_res_blk, G * (4 + 2 * (size_t)BO_RES_CAP) * 4, stream));  // the whole result block in one copy
-    RT(rt_sync(stream));
+    return BO_OK;
+}
+
+static int result_unpack(bo_engine *e, int32_t *res_n, int32_t *res_idx, float *res_val, int32_t *best_idx, int32_t *best_move,
+                         int32_t *total_visits) {
+    const size_t G = (size_t)e->d.c.G;
     const int *h = e->h_res;
     if (res_n) memcpy(res_n, h, G * 4);
     if (best_idx) memcpy(best_idx, h + G, G * 4);
@@ -530,6 +534,15 @@ extern "C" int bo_search_result(bo_engine *e, int32_t *res_n, int32_t *res_idx, 
     if (res_idx) memcpy(res_idx, h + 4 * G, G * BO_RES_CAP * 4);
     if (res_val) memcpy(res_val, h + 4 * G + G * BO_RES_CAP, G * BO_RES_CAP * 4);
     return BO_OK;
+}
+
+extern "C" int bo_search_result(bo_engine *e, int32_t *res_n, int32_t *res_idx, float *res_val, int32_t *best_idx,
+                                int32_t *best_move, int32_t *total_visits, void *stream) {
+    if (!e) return fail(BO_E_ARG, "null engine");
+    int rc = result_enqueue(e, stream);
+    if (rc) return rc;
+    RT(rt_sync(stream));
+    return result_unpack(e, res_n, res_idx, res_val, best_idx, best_move, total_visits);
 }
 
 extern "C" int bo_play(bo_engine *e, const int32_t *action, void *stream) {
@@ -636,11 +649,13 @@ extern "C" int bo_rng_state(bo_engine *e, int slot, int set, uint32_t *key624, i
     return BO_OK;
 }
 
-extern "C" int bo_selfplay_sample(bo_engine *e, const int32_t *active, const int32_t *move_number, int32_t threshold,
-                                  double t_initial, double t_final, int32_t *res_n, int32_t *res_idx, float *res_val,
-                                  int32_t *best_idx, int32_t *action_out, void *stream) {
+// fetched: the result block is already in e->h_res (bo_selfplay_turn asked for it together with the searches' state)
+static int selfplay_sample_impl(bo_engine *e, const int32_t *active, const int32_t *move_number, int32_t threshold, double t_initial,
+                                double t_final, int32_t *res_n, int32_t *res_idx, float *res_val, int32_t *best_idx,
+                                int32_t *action_out, bool fetched, void *stream) {
     if (!e || !active || !move_number || !res_n || !res_idx || !res_val || !action_out) return fail(BO_E_ARG, "null argument");
-    int rc = bo_search_result(e, res_n, res_idx, res_val, best_idx, nullptr, nullptr, stream);
+    int rc = fetched ? result_unpack(e, res_n, res_idx, res_val, best_idx, nullptr, nullptr)
+                     : bo_search_result(e, res_n, res_idx, res_val, best_idx, nullptr, nullptr, stream);
     if (rc) return rc;
     const int G = e->d.c.G;
     host_pool().run(G, [&](int g) {
@@ -652,6 +667,12 @@ extern "C" int bo_selfplay_sample(bo_engine *e, const int32_t *active, const int
         action_out[g] = a >= 0 ? a : -3;  // -3: not sparse enough, the caller samples with the dense NumPy mirror
     });
     return BO_OK;
+}
+
+extern "C" int bo_selfplay_sample(bo_engine *e, const int32_t *active, const int32_t *move_number, int32_t threshold,
+                                  double t_initial, double t_final, int32_t *res_n, int32_t *res_idx, float *res_val,
+                                  int32_t *best_idx, int32_t *action_out, void *stream) {
+    return selfplay_sample_impl(e, active, move_number, threshold, t_initial, t_final, res_n, res_idx, res_val, best_idx, action_out, false, stream);
 }
 
 static int selfplay_begin_impl(bo_engine *e, const int32_t *want, float *nn_in_dev, int32_t *n_legal_out, int32_t *terminal_out,
@@ -717,13 +738,19 @@ extern "C" int bo_selfplay_turn(bo_engine *e, const int32_t *active, const int32
     const bool poll_first = (defer_noise & 2) != 0;
     defer_noise &= 1;
     int rc;
-    if (poll_first) {  // are all searches finished?  Asked here, so that a ply costs ONE host round trip, not two
-        int running = 0;
-        rc = bo_search_poll(e, &running, nullptr, nullptr, stream);
+    if (poll_first) {
+        // "are all searches finished?" and their results in ONE round trip: the result kernel runs behind the last expected
+        // step without waiting for the answer (it only reads the trees; if a search needs one more evaluation -- rare -- its
+        // block is fetched again by the next call)
+        const size_t G = (size_t)e->d.c.G;
+        RT(rt_d2h(e->h_info, e->d_info_blk, 2 * G * 4, stream));  // [phase | req_node]
+        rc = result_enqueue(e, stream);
         if (rc) return rc;
-        if (running > 0) { *completed = -1; return BO_OK; }
+        RT(rt_sync(stream));
+        for (size_t g = 0; g < G; g++)
+            if (e->h_info[g] == PH_RUN) { *completed = -1; return BO_OK; }
     }
-    rc = bo_selfplay_sample(e, active, move_number, threshold, t_initial, t_final, res_n, res_idx, res_val, best_idx, action_out, stream);
+    rc = selfplay_sample_impl(e, active, move_number, threshold, t_initial, t_final, res_n, res_idx, res_val, best_idx, action_out, poll_first, stream);
     if (rc) return rc;
     for (int g = 0; g < e->d.c.G; g++)
         if (action_out[g] == -3) return BO_OK;  // a pi too dense for the native sampler: the caller samples it, then plays and begins
@@ -1074,6 +1101,7 @@ extern "C" int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layer
         if (L.t4 != want_t4) return fail(BO_E_ARG, "layer " + std::to_string(l) + ": t4 must be " + std::to_string(want_t4));
         if (L.w_off4 < 0 || ((int64_t)L.w_off4 + w4) * 4 > n_weights) return fail(BO_E_ARG, "weights offset out of range");
         if (L.bias_off < 0 || (int64_t)L.bias_off + C > n_params) return fail(BO_E_ARG, "bias offset out of range");
+        if (algo == BO_TOWER_WINOGRAD && (L.bias_off & 3)) return fail(BO_E_ARG, "BO_TOWER_WINOGRAD: bias_off must be a multiple of 4 floats");
         if (L.kind == 3) {
             if (L.hidden < 1 || L.hidden > 16) return fail(BO_E_CONFIG, "SE hidden width must be 1..16");
             if (algo == BO_TOWER_DIRECT_F16 && L.hidden > C / 16) return fail(BO_E_CONFIG, "BO_TOWER_DIRECT_F16: SE hidden width must be <= channels/16");

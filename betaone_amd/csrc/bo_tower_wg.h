@@ -83,6 +83,7 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
     }
 
     bo_f32x4 acc[16];
+    bo_f32x4 bias4 = {0, 0, 0, 0};
     bo_f32x4 a0[4], a1[4], a2[4], a3[4];  // A fragments of four consecutive K-steps: [position quad]
     bo_f32x4 va[4], vb[4];                // B operands of two consecutive K-steps: [position quad]
     // Weight fragments come through a buffer descriptor: the per-thread part of the address (wave, lane) is ONE constant
@@ -157,8 +158,8 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
             vn[pq] = src[pq * 16];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                if constexpr (decltype(first)::value)
-                    acc[4 * pq + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[pq][e], v[pq][e], bo_f32x4{0, 0, 0, 0}, 0, 0, 0);
+                if constexpr (decltype(first)::value)  // position 5 = M[1][1] enters every output of A^T M A once: it starts at the bias
+                    acc[4 * pq + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[pq][e], v[pq][e], 4 * pq + e == 5 ? bias4 : bo_f32x4{0, 0, 0, 0}, 0, 0, 0);
                 else
                     acc[4 * pq + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[pq][e], v[pq][e], acc[4 * pq + e], 0, 0, 0);
             }
@@ -188,13 +189,11 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
         }
         __syncthreads();
         bo_tower_layer Lnext = layers[0];
+        bias4 = *reinterpret_cast<const bo_f32x4 *>(params + Lnext.bias_off + oc0);  // this lane's 4 output channels, first layer
         for (int l = 0; l < n_layers; l++) {
             const bo_tower_layer L = Lnext;  // (fetched one layer ahead: no scalar-load latency at the top of a layer)
             const bo_tower_layer Ln = Lnext = layers[l + 1 < n_layers ? l + 1 : 0];
             const float *img = L.kind == 1 ? Q : P;
-            float bv[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) bv[r] = params[L.bias_off + oc0 + r];
             // One chunk = 4 K-steps = one turn of the weight-set rotation: step s multiplies with set s%4 while the weights
             // of step s+3 (possibly the first steps of the next layer) are loaded into set (s+3)%4.
             const int nk = L.t4, nchunks = nk >> 2;
@@ -220,6 +219,7 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
             __builtin_amdgcn_sched_barrier(0);
             int vbc = vb0;
             chunk(0, vbc, std::true_type{});
+            bias4 = *reinterpret_cast<const bo_f32x4 *>(params + Ln.bias_off + oc0);  // consumed by the first K-step only: the next layer's, now
             for (int c = 1; c < nchunks; c++) {
                 vbc = vbc == 2 ? 0 : vbc + 1;
                 chunk(c, vbc, std::false_type{});
@@ -247,9 +247,8 @@ bo_k_tower_wg(const float *__restrict__ x, const bo_f32x4 *__restrict__ wts, con
                     t0[j] = a0 + a1 + a2;
                     t1[j] = psub(psub(a1, a2), a3);
                 }
-                const f2 bp = {bv[2 * p2], bv[2 * p2 + 1]};
-                const f2 o0 = t0[0] + t0[1] + t0[2] + bp, o1 = psub(psub(t0[1], t0[2]), t0[3]) + bp;
-                const f2 o2 = t1[0] + t1[1] + t1[2] + bp, o3 = psub(psub(t1[1], t1[2]), t1[3]) + bp;
+                const f2 o0 = t0[0] + t0[1] + t0[2], o1 = psub(psub(t0[1], t0[2]), t0[3]);  // (the bias came in with acc[5])
+                const f2 o2 = t1[0] + t1[1] + t1[2], o3 = psub(psub(t1[1], t1[2]), t1[3]);
                 o[2 * p2][0] = o0[0]; o[2 * p2 + 1][0] = o0[1];
                 o[2 * p2][1] = o1[0]; o[2 * p2 + 1][1] = o1[1];
                 o[2 * p2][2] = o2[0]; o[2 * p2 + 1][2] = o2[1];

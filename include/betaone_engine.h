@@ -284,7 +284,7 @@ int bo_nn_conv3x3_small(const float *x_dev, const float *wpacked_dev, const floa
  *   g = W[16*ob + (lane & 15)][channel(step, lane >> 4)], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], position = 4*row + col;
  *   channel(step, k) = 4*step + k for C = 64 and, for C = 128 (every layer has 128 input channels, the first one padded),
  *   with step = 4*c + sl: 16*(4*(c & 1) + sl) + 4*(c >> 1) + k -- the K order in which a wave of the kernel only ever
- *   transforms input channels that it produced itself (csrc/bo_tower_wg.h: OWN).
+ *   transforms input channels that it produced itself (csrc/bo_tower_wg.h: OWN).  bias_off must be a multiple of 4.
  * algo BO_TOWER_DIRECT_F16 (csrc/bo_tower_h.h): fp16 weights and activations, fp32 accumulation, two boards per
  *   workgroup; channels in {128, 256}; t4 = 9*c_in/16 K-steps; `weights` holds fp16 data (n_weights still counts
  *   4-byte units): per layer [t4][C/32][64][8] with element (step, mt, lane, i) = W[32*mt + (lane & 31)]
