@@ -62,6 +62,10 @@ struct bo_engine {
     void *setup_dev = nullptr, *setup_host = nullptr;  // staging of bo_games_reset_ex (grow-only)
     size_t setup_cap = 0;
     std::vector<unsigned char> noise_pending;  // roots begun by bo_selfplay_turn(defer_noise) whose Dirichlet draw is still due
+    // bo_selfplay_turn(flag 4): searches begun on the device; the roots' state is on its way (ev_begin), bo_selfplay_begun collects it
+    std::vector<int> lazy_want;
+    bool begin_lazy = false, ev_begin_made = false;
+    rt_event ev_begin{};
     template <class T> int alloc(T **p, size_t n) {
         void *v = nullptr;
         int rc = rt_malloc(&v, n * sizeof(T));
@@ -304,6 +308,7 @@ extern "C" void bo_engine_destroy(bo_engine *e) {
     rt_host_free(e->h_res); rt_host_free(e->h_info); rt_host_free(e->h_noise); rt_host_free(e->h_go);
     if (e->setup_dev) rt_free(e->setup_dev);
     if (e->setup_host) rt_host_free(e->setup_host);
+    if (e->ev_begin_made) rt_event_destroy(e->ev_begin);
 #if !defined(BO_WAVE_EMU)
     if (e->sel_ev0) { (void)hipEventDestroy(e->sel_ev0); (void)hipEventDestroy(e->sel_ev1); }
 #endif
@@ -703,13 +708,61 @@ static int selfplay_begin_impl(bo_engine *e, const int32_t *want, float *nn_in_d
 
 extern "C" int bo_selfplay_begin(bo_engine *e, const int32_t *want, float *nn_in_dev, int32_t *n_legal_out, int32_t *terminal_out,
                                  int32_t *go_out, void *stream) {
+    if (e && e->begin_lazy) return fail(BO_E_STATE, "bo_selfplay_begun has not collected the previous turn's roots yet");
     return selfplay_begin_impl(e, want, nn_in_dev, n_legal_out, terminal_out, go_out, false, stream);
+}
+
+// The begin of bo_selfplay_turn(flag 4): nothing here waits for the device.  go is decided by the kernel (wanted and not
+// terminal); the roots' state travels behind it and is collected by bo_selfplay_begun once the caller has enqueued the first
+// evaluation -- the device goes from the played moves straight into that evaluation instead of idling through a host round trip.
+static int selfplay_begin_lazy(bo_engine *e, const int32_t *want, float *nn_in_dev, void *stream) {
+    if (e->fast) return fail(BO_E_CONFIG, "bo_selfplay_turn: flag 4 needs a reference-semantics engine");
+    const size_t G = (size_t)e->d.c.G;
+    e->lazy_want.assign(want, want + G);
+    memcpy(e->h_go, want, G * 4);
+    RT(rt_h2d(e->d_go, e->h_go, G * 4, stream));
+    e->nl_valid = false;
+    RT(RT_LAUNCH(bo_k_search_begin_want, e->d.c.G, stream, e->d, (const int *)e->d_go, nn_in_dev));
+    int rc = bo_step(e, nullptr, nullptr, BO_POLICY_NONE, nn_in_dev, stream);
+    if (rc) return rc;
+    RT(rt_d2h(e->h_info + 2 * G, e->d_info_blk + 2 * G, 3 * G * 4, stream));  // [root_nlegal | root_term | ply]
+    if (!e->ev_begin_made) { RT(rt_event_create(&e->ev_begin)); e->ev_begin_made = true; }
+    RT(rt_event_record(e->ev_begin, stream));
+    e->begin_lazy = true;
+    return BO_OK;
+}
+
+// Collect what bo_selfplay_turn(flag 4) left on its way: the new roots' legal-move counts, terminal codes and go flags (as
+// bo_selfplay_begin reports them), and which roots still need their Dirichlet draw (bo_selfplay_noise).  Waits for the copy
+// behind the begin kernels only, not for work enqueued after the turn.
+extern "C" int bo_selfplay_begun(bo_engine *e, int32_t *n_legal_out, int32_t *terminal_out, int32_t *go_out) {
+    if (!e) return fail(BO_E_ARG, "null engine");
+    if (!e->begin_lazy) return fail(BO_E_STATE, "no bo_selfplay_turn(flag 4) outstanding");
+    RT(rt_event_sync(e->ev_begin));
+    const int G = e->d.c.G;
+    const double alpha = e->cfg.dirichlet_alpha;
+    if ((int)e->noise_pending.size() != G) e->noise_pending.assign(G, 0);
+    for (int g = 0; g < G; g++) {
+        e->h_nl[g] = e->h_info[2 * G + g];
+        e->h_term[g] = e->h_info[3 * G + g];
+        const int go = e->lazy_want[g] && e->h_term[g] == 0;
+        e->h_go[g] = go;
+        if (e->lazy_want[g]) e->noise_pending[g] = 0;
+        if (go && alpha > 0) e->noise_pending[g] = 1;
+        if (n_legal_out) n_legal_out[g] = e->h_nl[g];
+        if (terminal_out) terminal_out[g] = e->h_term[g];
+        if (go_out) go_out[g] = go;
+    }
+    e->nl_valid = true;
+    e->begin_lazy = false;
+    return BO_OK;
 }
 
 // The Dirichlet draws bo_selfplay_turn(defer_noise = 1) left out, and their upload: call it after the root evaluation's
 // network forward has been enqueued (the host work then overlaps it) and before the bo_step that consumes that evaluation.
 extern "C" int bo_selfplay_noise(bo_engine *e, void *stream) {
     if (!e) return fail(BO_E_ARG, "null engine");
+    if (e->begin_lazy) return fail(BO_E_STATE, "bo_selfplay_noise: call bo_selfplay_begun first");
     const int G = e->d.c.G;
     const double alpha = e->cfg.dirichlet_alpha;
     if ((int)e->noise_pending.size() != G || alpha <= 0) return BO_OK;
@@ -735,8 +788,10 @@ extern "C" int bo_selfplay_turn(bo_engine *e, const int32_t *active, const int32
                                 int32_t defer_noise, int32_t *completed, void *stream) {
     if (!e || !want_next || !nn_in_dev || !completed) return fail(BO_E_ARG, "null argument");
     *completed = 0;
-    const bool poll_first = (defer_noise & 2) != 0;
+    const bool poll_first = (defer_noise & 2) != 0, lazy_begin = (defer_noise & 4) != 0;
     defer_noise &= 1;
+    if (lazy_begin && !defer_noise) return fail(BO_E_ARG, "bo_selfplay_turn: flag 4 (begin without waiting) needs flag 1 (noise later)");
+    if (e->begin_lazy) return fail(BO_E_STATE, "bo_selfplay_begun has not collected the previous turn's roots yet");
     int rc;
     if (poll_first) {
         // "are all searches finished?" and their results in ONE round trip: the result kernel runs behind the last expected
@@ -756,9 +811,10 @@ extern "C" int bo_selfplay_turn(bo_engine *e, const int32_t *active, const int32
         if (action_out[g] == -3) return BO_OK;  // a pi too dense for the native sampler: the caller samples it, then plays and begins
     rc = bo_play(e, action_out, stream);
     if (rc) return rc;
-    rc = selfplay_begin_impl(e, want_next, nn_in_dev, n_legal_out, terminal_out, go_out, defer_noise != 0, stream);
+    rc = lazy_begin ? selfplay_begin_lazy(e, want_next, nn_in_dev, stream)
+                    : selfplay_begin_impl(e, want_next, nn_in_dev, n_legal_out, terminal_out, go_out, defer_noise != 0, stream);
     if (rc) return rc;
-    *completed = 1;
+    *completed = lazy_begin ? 2 : 1;
     return BO_OK;
 }
 

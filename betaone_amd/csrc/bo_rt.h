@@ -19,6 +19,11 @@ static inline int rt_h2d_2d(void *d, size_t dpitch, const void *h, size_t hpitch
     for (size_t r = 0; r < height; r++) memcpy((char *)d + r * dpitch, (const char *)h + r * hpitch, width);
     return 0;
 }
+typedef int rt_event;  // (copies are synchronous on the emulator: an event has nothing to wait for)
+static inline int rt_event_create(rt_event *) { return 0; }
+static inline int rt_event_record(rt_event, void *) { return 0; }
+static inline int rt_event_sync(rt_event) { return 0; }
+static inline void rt_event_destroy(rt_event) {}
 static inline const char *rt_errstr(int) { return "emulator error"; }
 #define RT_LAUNCH(kernel, grid, stream, ...) (bo_emu::launch((grid), [&]() { kernel(__VA_ARGS__); }), 0)
 #else
@@ -36,6 +41,11 @@ static inline void rt_host_free(void *p) { (void)hipHostFree(p); }
 static inline int rt_h2d_2d(void *d, size_t dpitch, const void *h, size_t hpitch, size_t width, size_t height, void *s) {
     return (int)hipMemcpy2DAsync(d, dpitch, h, hpitch, width, height, hipMemcpyHostToDevice, (hipStream_t)s);
 }
+typedef hipEvent_t rt_event;
+static inline int rt_event_create(rt_event *ev) { return (int)hipEventCreateWithFlags(ev, hipEventDisableTiming); }
+static inline int rt_event_record(rt_event ev, void *s) { return (int)hipEventRecord(ev, (hipStream_t)s); }
+static inline int rt_event_sync(rt_event ev) { return (int)hipEventSynchronize(ev); }
+static inline void rt_event_destroy(rt_event ev) { (void)hipEventDestroy(ev); }
 static inline const char *rt_errstr(int e) { return hipGetErrorString((hipError_t)e); }
 #define RT_LAUNCH(kernel, grid, stream, ...)                                                                   \
     ([&]() -> int {                                                                                            \

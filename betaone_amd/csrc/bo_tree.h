@@ -979,6 +979,15 @@ BO_KERNEL void bo_k_search_begin(Eng e, const int *go, float *nn_in) {
     if (bo_lane() == 0) e.phase[g] = PH_RUN;
 }
 
+// The same with the decision on the device: a wanted game whose root is not terminal searches (mcts.py:160-162).  The host
+// learns the roots' state from a copy it does not wait for before the first evaluation is enqueued (bo_selfplay_turn, flag 4).
+BO_KERNEL void bo_k_search_begin_want(Eng e, const int *want, float *nn_in) {
+    const int g = bo_block();
+    if (!want[g] || e.root_term[g] != 0) return;
+    encode_static(e, g, nn_in + (size_t)g * BO_ROW);
+    if (bo_lane() == 0) e.phase[g] = PH_RUN;
+}
+
 // End running searches early, between two steps: flush the pending rows as the tail batch (mcts.py:256-257), drop the
 // outstanding evaluation request, phase = DONE.  The tree then is the reference's tree after sims_done simulations.
 BO_KERNEL void bo_k_stop(Eng e, const int *mask) {

@@ -29,6 +29,9 @@ STATUS_BITS = {1: "node overflow", 2: "depth overflow", 4: "NaN PUCT score", 8: 
 ST_PLY_OVERFLOW, ST_ILLEGAL_ACTION = 8, 16   # per-GAME conditions (the reference aborts that game only); the rest are engine faults
 
 
+LAZY_BEGIN = "lazy-begin"  # selfplay_turn(lazy_begin=True): the begun searches' root info comes from selfplay_begun()
+
+
 class EngineError(RuntimeError):
     pass
 
@@ -78,6 +81,7 @@ _SYMBOLS = {
     "bo_selfplay_turn": (C.c_int, [C.c_void_p, _I32P, _I32P, C.c_int32, C.c_double, C.c_double, _I32P, _I32P, _F32P, _I32P, _I32P, _I32P,
                                    C.c_void_p, _I32P, _I32P, _I32P, C.c_int32, _I32P, C.c_void_p]),
     "bo_selfplay_noise": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bo_selfplay_begun": (C.c_int, [C.c_void_p, _I32P, _I32P, _I32P]),
     "bo_selfplay_begin": (C.c_int, [C.c_void_p, _I32P, C.c_void_p, _I32P, _I32P, _I32P, C.c_void_p]),
     "bo_records_encode": (C.c_int, [C.c_int, C.POINTER(BoPosition), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bo_debug_tree": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BoNode), C.c_int32, _I32P, C.c_void_p]),
@@ -324,20 +328,32 @@ class Engine:
     def selfplay_noise(self, stream: int = 0):
         self._check(self.lib.bo_selfplay_noise(self.h, stream))
 
+    def selfplay_begun(self):
+        """(n_legal, terminal, go) of the searches a selfplay_turn(lazy_begin=True) began; to be called after the first
+        evaluation's forward has been enqueued and before selfplay_noise."""
+        nl, tm, go = (np.zeros(self.G, dtype=np.int32) for _ in range(3))
+        self._check(self.lib.bo_selfplay_begun(self.h, _p(nl), _p(tm), _p(go)))
+        return nl, tm, go
+
     def selfplay_turn(self, active, move_number, temperature, out, want_next, nn_in_ptr: int, stream: int = 0, defer_noise: bool = False,
-                      poll_first: bool = False):
+                      poll_first: bool = False, lazy_begin: bool = False):
         """selfplay_sample + play + selfplay_begin(want_next) in one call.  Returns (out, (n_legal, terminal, go) or None):
         None when a game needs the dense NumPy sampler (action -3) -- nothing was played then.  poll_first: check that all
-        searches are finished first; returns (None, None) if one is still running (issue another step and call again)."""
+        searches are finished first; returns (None, None) if one is still running (issue another step and call again).
+        lazy_begin (with defer_noise): the begin does not wait for the device; the second item is then LAZY_BEGIN and
+        selfplay_begun() returns the triple later."""
         a, m, w = _i32(active), _i32(move_number), _i32(want_next)
         th, ti, tf = temperature
         nl, tm, go = (np.zeros(self.G, dtype=np.int32) for _ in range(3))
         done = C.c_int32(0)
         self._check(self.lib.bo_selfplay_turn(self.h, _p(a), _p(m), int(th), float(ti), float(tf), _p(out["n"]), _p(out["idx"]),
                                               _p(out["val"], _F32P), _p(out["best_idx"]), _p(out["action"]), _p(w), nn_in_ptr, _p(nl), _p(tm),
-                                              _p(go), (1 if defer_noise else 0) | (2 if poll_first else 0), C.byref(done), stream))
+                                              _p(go), (1 if defer_noise else 0) | (2 if poll_first else 0) | (4 if lazy_begin else 0),
+                                              C.byref(done), stream))
         if done.value < 0:
             return None, None
+        if done.value == 2:
+            return out, LAZY_BEGIN
         return out, ((nl, tm, go) if done.value else None)
 
     def selfplay_begin(self, want, nn_in_ptr: int, stream: int = 0):

@@ -348,18 +348,24 @@ class Rollout:
         self._fgraph.replay()
 
     def _run_search_steps(self, poll: bool = True):
+        """The evaluate -> step iterations of one search per game.  Returns the (n_legal, terminal, go) of searches that the
+        previous turn began without waiting for the device (engine.LAZY_BEGIN), else None."""
         burst = self.expected_evals
+        info = None
         if self._noise_pending:  # root evaluation: forward | host draws the noise meanwhile | upload | apply
             self._noise_pending = False
             self.n_forward += 1
             self._forward_only()
+            if self._begun is E.LAZY_BEGIN:  # the roots' state, now that the device has its next 0.4 ms of work
+                info = self.eng.selfplay_begun()
+                self._begun = None
             self.eng.selfplay_noise(self._stream())
             self.eng.step(self._f_logits.data_ptr(), self._f_value.data_ptr(), self.policy_kind, self.nn_in.data_ptr(), self._stream())
             burst -= 1
         while True:
             self._eval_and_step_n(burst)
             if not poll:  # the caller asks the engine itself (bo_selfplay_turn, poll_first)
-                return
+                return info
             running, _, _ = self.eng.poll(self._stream(), want_mask=False)
             if running == 0:
                 break
@@ -373,13 +379,17 @@ class Rollout:
         want = self._active & (self._plies < self.max_game_moves)
         limit_done = np.nonzero(self._active & ~want)[0]
         self.host_seconds += time.perf_counter() - t0
+        lazy = False
         if self._begun is not None:  # the previous turn already began these searches (bo_selfplay_turn)
-            nl, term, go = self._begun
             extra = want & ~self._begun_want
-            self._begun = None
-            if extra.any():  # games started in between
-                nl2, t2, go2 = eng.selfplay_begin(extra.astype(np.int32), self.nn_in.data_ptr(), stream)
-                nl, term, go = np.where(extra, nl2, nl), np.where(extra, t2, term), go | go2
+            if self._begun is E.LAZY_BEGIN and not extra.any():
+                lazy = True  # ... without waiting for the device: their roots' state arrives with the first evaluation below
+            else:
+                nl, term, go = eng.selfplay_begun() if self._begun is E.LAZY_BEGIN else self._begun
+                self._begun = None
+                if extra.any():  # games started in between
+                    nl2, t2, go2 = eng.selfplay_begin(extra.astype(np.int32), self.nn_in.data_ptr(), stream)
+                    nl, term, go = np.where(extra, nl2, nl), np.where(extra, t2, term), go | go2
         else:
             nl, term, go = eng.selfplay_begin(want.astype(np.int32), self.nn_in.data_ptr(), stream)
         # Games that are over: their slots sit this ply out.  Exporting them, the caller's callback and setting up the next
@@ -387,13 +397,16 @@ class Rollout:
         # touched by the search (bo_k_step skips idle slots) -- and the new games' first searches are begun with everyone
         # else's next one by bo_selfplay_turn below.  (One idle slot-ply per game, ~0.3 % of the capacity, instead of an
         # idle GPU during ~0.3 ms of host work in every ply in which a game ends.)
+        if lazy:
+            nl, term, go = self._run_search_steps(poll=False)
         done = [int(g) for g in limit_done] + [int(g) for g in np.nonzero(want & (term != 0))[0]]
         for g in done:
             self._active[g] = False
         if not go.any():
             self._finish_and_refill(done, term, on_finished, refill)
             return 0
-        self._run_search_steps(poll=False)
+        if not lazy:
+            self._run_search_steps(poll=False)
         if done:
             if self._side is not None:
                 with torch.cuda.stream(self._side):  # torch's current stream in here: exports, encodes and set-up run beside the search
@@ -409,7 +422,7 @@ class Rollout:
         # (fast mode mixes the noise into a kept root's priors when the search begins, so its draws cannot be deferred)
         while True:  # one native call per ply: "all searches finished?" + sample + play + begin the next searches
             out, begun = eng.selfplay_turn(go, move_number, self.temperature, self._out, want_next.astype(np.int32), self.nn_in.data_ptr(), stream,
-                                           defer_noise=not self.fast, poll_first=True)
+                                           defer_noise=not self.fast, poll_first=True, lazy_begin=not self.fast)
             if out is not None:
                 break
             self._eval_and_step()  # a search needed one more evaluation than expected

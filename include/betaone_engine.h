@@ -172,7 +172,13 @@ int bo_selfplay_turn(bo_engine *e, const int32_t *active, const int32_t *move_nu
  * running nothing is done and *completed = -1 -- the caller issues another evaluate + step and calls again.
  * Bit 0, defer_noise = 1: the Dirichlet draws of the new roots (mcts.py:190-201) and their upload are left to bo_selfplay_noise,
  * to be called after the root evaluations' network forward has been enqueued on `stream` (the host work overlaps it) and
- * before the bo_step that consumes those evaluations.  Per game the RNG stream order is the same either way. */
+ * before the bo_step that consumes those evaluations.  Per game the RNG stream order is the same either way.
+ * Bit 2 (value 4, with bit 0): the begin does not wait for the device either -- the kernel itself starts the search of every
+ * wanted game whose new root is not terminal (mcts.py:160-162), *completed = 2, and n_legal_out / terminal_out / go_out are
+ * NOT written: bo_selfplay_begun returns them (as bo_selfplay_begin would have) once the caller has enqueued the first
+ * evaluation; it waits for the copy behind the begin kernels only.  Order: bo_selfplay_turn(4) -> enqueue the network
+ * forward -> bo_selfplay_begun -> bo_selfplay_noise -> bo_step.  (Reference-semantics engines.) */
+int bo_selfplay_begun(bo_engine *e, int32_t *n_legal_out, int32_t *terminal_out, int32_t *go_out);
 int bo_selfplay_noise(bo_engine *e, void *stream);
 
 /* ---- records ------------------------------------------------------------------------------------

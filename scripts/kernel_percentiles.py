@@ -6,7 +6,7 @@ import csv, glob, os, sys
 import numpy as np
 
 d = sys.argv[1]
-want = sys.argv[2:] or ["bo_k_", "Cijk", "softmax"]
+want = sys.argv[2:] or ["bo_k_", "Cijk", "softmax", "copyBuffer", "fillBuffer"]
 files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
 if not files:
     print("no kernel_trace.csv under", d); sys.exit(1)
@@ -46,3 +46,30 @@ print("|---|---|---|---|---|")
 for (n0, n1), v in sorted(gaps.items(), key=lambda kv: -sum(kv[1]))[:14]:
     a = np.array(v, dtype=np.float64) / 1e3
     print(f"| {n0} -> {n1} | {len(a)} | {a.mean():.1f} | {np.percentile(a, 50):.1f} | {np.percentile(a, 90):.1f} |")
+
+# ---- where a ply goes: the span between two bo_k_play launches, by kernel and idle (union of kernel intervals) ----
+plays = [k for k in allk if k[2].startswith("bo_k_play")]
+if len(plays) > 2:
+    t0, t1 = plays[0][0], plays[-1][0]
+    n_plies = len(plays) - 1
+    inside = [k for k in allk if t0 <= k[0] < t1]
+    by = {}
+    for s, e, n in inside:
+        by[n] = by.get(n, 0) + (e - s)
+    busy, cur_s, cur_e = 0, None, None
+    for s, e, n in inside:
+        if cur_e is None or s > cur_e:
+            if cur_e is not None:
+                busy += cur_e - cur_s
+            cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    if cur_e is not None:
+        busy += cur_e - cur_s
+    span = t1 - t0
+    print()
+    print(f"| per ply ({n_plies} plies, {span / n_plies / 1e3:.1f} us each under the profiler) | us | share |")
+    print("|---|---|---|")
+    for n, v in sorted(by.items(), key=lambda kv: -kv[1])[:10]:
+        print(f"| {n} | {v / n_plies / 1e3:.1f} | {v / span:.3f} |")
+    print(f"| device idle (no kernel or copy running) | {(span - busy) / n_plies / 1e3:.1f} | {(span - busy) / span:.3f} |")
