@@ -144,7 +144,6 @@ class Rollout:
         self._fgraph = None
         self._side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None  # finished games' hand-over beside the search
         self._noise_pending = False
-        self._root_done = False     # the begun searches' root evaluation has been applied already (_root_eval)
         self._begun = None          # (n_legal, terminal, go) of searches already begun by the previous selfplay_turn
         self._begun_want = None
         self._active = np.zeros(G, dtype=bool)
@@ -348,30 +347,25 @@ class Rollout:
             self._fgraph, self._f_logits, self._f_value = g, logits, value
         self._fgraph.replay()
 
-    def _root_eval(self):
-        """The root evaluation of searches whose Dirichlet noise is still due: forward | the host collects the roots' state (if
-        the turn began them without waiting, engine.LAZY_BEGIN) and draws the noise meanwhile | upload | apply."""
-        self._noise_pending = False
-        self.n_forward += 1
-        self._forward_only()
-        if self._begun is E.LAZY_BEGIN:  # the roots' state, now that the device has its next 0.4 ms of work
-            self._begun = self.eng.selfplay_begun()
-        self.eng.selfplay_noise(self._stream())
-        self.eng.step(self._f_logits.data_ptr(), self._f_value.data_ptr(), self.policy_kind, self.nn_in.data_ptr(), self._stream())
-        self._root_done = True
-
     def _run_search_steps(self, poll: bool = True):
-        """The evaluate -> step iterations of one search per game."""
+        """The evaluate -> step iterations of one search per game.  Returns the (n_legal, terminal, go) of searches that the
+        previous turn began without waiting for the device (engine.LAZY_BEGIN), else None."""
         burst = self.expected_evals
-        if self._noise_pending:
-            self._root_eval()
-        if self._root_done:
-            self._root_done = False
+        info = None
+        if self._noise_pending:  # root evaluation: forward | host draws the noise meanwhile | upload | apply
+            self._noise_pending = False
+            self.n_forward += 1
+            self._forward_only()
+            if self._begun is E.LAZY_BEGIN:  # the roots' state, now that the device has its next 0.4 ms of work
+                info = self.eng.selfplay_begun()
+                self._begun = None
+            self.eng.selfplay_noise(self._stream())
+            self.eng.step(self._f_logits.data_ptr(), self._f_value.data_ptr(), self.policy_kind, self.nn_in.data_ptr(), self._stream())
             burst -= 1
         while True:
             self._eval_and_step_n(burst)
             if not poll:  # the caller asks the engine itself (bo_selfplay_turn, poll_first)
-                return
+                return info
             running, _, _ = self.eng.poll(self._stream(), want_mask=False)
             if running == 0:
                 break
@@ -385,15 +379,17 @@ class Rollout:
         want = self._active & (self._plies < self.max_game_moves)
         limit_done = np.nonzero(self._active & ~want)[0]
         self.host_seconds += time.perf_counter() - t0
+        lazy = False
         if self._begun is not None:  # the previous turn already began these searches (bo_selfplay_turn)
-            if self._begun is E.LAZY_BEGIN:  # (normally collected by the root evaluation that the turn itself started)
-                self._begun = eng.selfplay_begun()
-            nl, term, go = self._begun
             extra = want & ~self._begun_want
-            self._begun = None
-            if extra.any():  # games started in between (their root evaluation: one step behind the others')
-                nl2, t2, go2 = eng.selfplay_begin(extra.astype(np.int32), self.nn_in.data_ptr(), stream)
-                nl, term, go = np.where(extra, nl2, nl), np.where(extra, t2, term), go | go2
+            if self._begun is E.LAZY_BEGIN and not extra.any():
+                lazy = True  # ... without waiting for the device: their roots' state arrives with the first evaluation below
+            else:
+                nl, term, go = eng.selfplay_begun() if self._begun is E.LAZY_BEGIN else self._begun
+                self._begun = None
+                if extra.any():  # games started in between
+                    nl2, t2, go2 = eng.selfplay_begin(extra.astype(np.int32), self.nn_in.data_ptr(), stream)
+                    nl, term, go = np.where(extra, nl2, nl), np.where(extra, t2, term), go | go2
         else:
             nl, term, go = eng.selfplay_begin(want.astype(np.int32), self.nn_in.data_ptr(), stream)
         # Games that are over: their slots sit this ply out.  Exporting them, the caller's callback and setting up the next
@@ -401,13 +397,16 @@ class Rollout:
         # touched by the search (bo_k_step skips idle slots) -- and the new games' first searches are begun with everyone
         # else's next one by bo_selfplay_turn below.  (One idle slot-ply per game, ~0.3 % of the capacity, instead of an
         # idle GPU during ~0.3 ms of host work in every ply in which a game ends.)
+        if lazy:
+            nl, term, go = self._run_search_steps(poll=False)
         done = [int(g) for g in limit_done] + [int(g) for g in np.nonzero(want & (term != 0))[0]]
         for g in done:
             self._active[g] = False
         if not go.any():
             self._finish_and_refill(done, term, on_finished, refill)
             return 0
-        self._run_search_steps(poll=False)
+        if not lazy:
+            self._run_search_steps(poll=False)
         if done:
             if self._side is not None:
                 with torch.cuda.stream(self._side):  # torch's current stream in here: exports, encodes and set-up run beside the search
@@ -440,10 +439,6 @@ class Rollout:
             eng.play(actions, stream)
         else:
             self._begun, self._begun_want, self._noise_pending = begun, want_next.copy(), not self.fast
-            if begun is E.LAZY_BEGIN:
-                # the next searches' root evaluation goes to the device NOW: it must not idle through this call's bookkeeping and
-                # the caller's code between two plies (~45 us per ply at 256 games)
-                self._root_eval()
         k = max(1, int(out["n"].max()))
         self._hist[self._step] = (out["n"].copy(), out["idx"][:, :k].copy(), out["val"][:, :k].copy())
         if self._pk and k <= self._pk:  # this ply's pi of every searched game into its slot's row (one scatter)
