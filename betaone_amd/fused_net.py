@@ -115,7 +115,7 @@ class FusedPolicyValueNet(nn.Module):
         self.conv = conv
         # policy FC + softmax + value head as one kernel behind the Winograd tower (needs contiguous float32 Linear weights of the
         # reference's head shapes: 2 policy planes, 32 value planes, 256 hidden units)
-        self.fused_heads = conv == "tower_wg"
+        self.fused_heads = conv in ("tower_wg", "tower", "mfma", "mfma_small")
         f = net.for_inference(dtype=torch.float32, channels_last=False)
         dev = next(f.parameters()).device
         if dev.type != "cuda":
@@ -461,6 +461,9 @@ class FusedPolicyValueNet(nn.Module):
             h = self._epi(F.conv2d(x, self.w_head, None), self.b_head)
             p = h[:, :self.n_policy_ch].flatten(1)
             v = h[:, self.n_policy_ch:].flatten(1)
+            if self.fused_heads and h.dtype == torch.float32 and p.shape[1] == 128 and v.shape[1] == 2048:
+                # (batch 1 -- uci.py's analysis -- : the slices are contiguous already; this replaces nine small launches)
+                return self._heads(p.contiguous(), v.contiguous(), probs)
             logits = self.policy_fc(p)
             return (torch.softmax(logits.float(), dim=1) if probs else logits), torch.tanh(self.value_fc2(F.relu(self.value_fc1(v))))
         x = self._epi(F.conv2d(x, self.w_in, None, padding=1), self.b_in)
