@@ -288,12 +288,15 @@ class Rollout:
 
     # ---- one ply for every active game (the body of self_play.py:101-184) --------------------------------
     def play_ply(self, on_finished: Optional[Callable[[FinishedGame], None]] = None,
-                 refill: Optional[Callable[[int], Optional[tuple]]] = None) -> int:
+                 refill: Optional[Callable[[int], Optional[tuple]]] = None,
+                 while_searching: Optional[Callable[[], None]] = None) -> int:
         """Advance every active game by one move.  Finished games are reported through `on_finished`
-        and their slots refilled by `refill(slot) -> (game_id, rng, fen)`.  Returns the number of
-        moves played."""
+        and their slots refilled by `refill(slot) -> (game_id, rng, fen)`.  `while_searching()` is the place for the caller's
+        own per-ply host work (handing records on, logging): it runs once the ply's searches are enqueued and the finished
+        games have been reported, while the device works -- code between two play_ply calls runs with the device idle.
+        Returns the number of moves played."""
         if self.rng_mode == "native":
-            return self._play_ply_native(on_finished, refill)
+            return self._play_ply_native(on_finished, refill, while_searching)
         n_legal, terminal, ply = self.eng.root_info(self._stream())
         t0 = time.perf_counter()
         done_slots = [g for g in range(self.G) if self.games[g] is not None and
@@ -315,6 +318,8 @@ class Rollout:
                 n_legal, terminal, ply = self.eng.root_info(self._stream())
         go = np.array([1 if (self.games[g] is not None and terminal[g] == 0) else 0 for g in range(self.G)], dtype=np.int32)
         if not go.any():
+            if while_searching is not None:
+                while_searching()
             return 0
         res = self.search(go, n_legal, terminal)
         t0 = time.perf_counter()
@@ -329,6 +334,8 @@ class Rollout:
             gs.plies += 1
         self.host_seconds += time.perf_counter() - t0
         self.eng.play(actions, self._stream())
+        if while_searching is not None:
+            while_searching()
         n_moves = int(np.count_nonzero(go))
         self.n_plies += n_moves
         return n_moves
@@ -371,7 +378,7 @@ class Rollout:
                 break
             burst = 1
 
-    def _play_ply_native(self, on_finished, refill) -> int:
+    def _play_ply_native(self, on_finished, refill, while_searching=None) -> int:
         """play_ply with the per-move host work done inside the library (same streams, same results)."""
         eng, G = self.eng, self.G
         stream = self._stream()
@@ -404,6 +411,8 @@ class Rollout:
             self._active[g] = False
         if not go.any():
             self._finish_and_refill(done, term, on_finished, refill)
+            if while_searching is not None:
+                while_searching()
             return 0
         if not lazy:
             self._run_search_steps(poll=False)
@@ -413,6 +422,8 @@ class Rollout:
                     self._finish_and_refill(done, term, on_finished, refill)
             else:
                 self._finish_and_refill(done, term, on_finished, refill)
+        if while_searching is not None:
+            while_searching()
         self.n_sims += int(np.count_nonzero(go)) * self.S
         t0 = time.perf_counter()
         move_number = self._start_full + (self._plies + self._start_black) // 2   # board.fullmove_number, self_play.py:104
