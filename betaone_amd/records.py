@@ -152,11 +152,14 @@ class _Gather:
                      torch.empty(world * cap, dtype=tdt, device=device), torch.empty(world * cap, dtype=tdt).pin_memory())
                 if bufs is not None:
                     bufs[key] = b
+                side.wait_stream(torch.cuda.current_stream(device))  # (new device buffers come from the compute stream's allocator)
             self.h_in, self.d_in = b[0][:src.size], b[1][:src.size]
             self.d_out, self.h_out = b[2][:world * src.size], b[3][:world * src.size]
             self.h_in.numpy()[:] = src
             self.event = torch.cuda.Event()
-            side.wait_stream(torch.cuda.current_stream(device))
+            # The side stream does NOT wait for the compute stream: nothing here depends on it, and behind a whole ply of queued
+            # search the staging copies and the collective would start exactly at the ply boundary, in front of the copies of the
+            # one host round trip the ply has (measured: +0.27 ms per ply on every rank).
             with torch.cuda.stream(side):
                 self.d_in.copy_(self.h_in, non_blocking=True)
                 work = dist.all_gather_into_tensor(self.d_out, self.d_in, group=group, async_op=True)
