@@ -447,8 +447,10 @@ def main():
     gc.collect()
     gc.disable()  # no cyclic-GC pause of the interpreter inside a 0.1 s timed region (it was worth up to 5 % of 20 steps)
     t0 = time.perf_counter()
+    step_end = []
     for _ in range(args.steps):
         drv.step()
+        step_end.append(time.perf_counter())
     torch.cuda.synchronize(device)
     if dist is not None:
         dist.barrier()
@@ -471,6 +473,7 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         mine = tot.tolist()
     sims, plies, fwd, fin_timed, fin_plies_timed, fin_all, fin_plies_all = [float(x) for x in mine]
+    step_ms = np.diff(np.array([t0] + step_end)) * 1e3  # host-side period of each step on this rank (a step returns when its moves are played)
     ro.eng.check_status()
     host_frac = (ro.host_seconds - h0) / dt
 
@@ -525,6 +528,7 @@ def main():
             "games_finished_in_timed_region": int(fin_timed),
             "games_per_hour_measured": (round(fin_timed * 3600.0 / dt, 1) if fin_timed else None),
             "mean_plies_of_finished_games": (round(fin_plies_timed / fin_timed, 1) if fin_timed else None),
+            "step_ms_min_p50_p90_max": [round(float(x), 3) for x in (step_ms.min(), np.percentile(step_ms, 50), np.percentile(step_ms, 90), step_ms.max())],
             "games_finished_since_start": int(fin_all),
             "mean_plies_of_all_finished_games": (round(mean_len, 1) if mean_len else None),
             "games_per_hour_from_ply_rate": (round(plies / dt * 3600.0 / mean_len, 1) if mean_len else None),
