@@ -6,7 +6,7 @@ import json, sys
 print("| configuration | nodes/s | ms per ply | unique NN evals/s | games/hour measured | opening-phase ms per ply | roofline (dominant kernel) |")
 print("|---|---|---|---|---|---|---|")
 for arg in sys.argv[1:]:
-    label, path = arg.split("=", 1)
+    label, path = arg.rsplit("=", 1)
     lines = [l for l in open(path).read().splitlines() if l.startswith('{"metric')]
     if not lines:
         print(f"| {label} (`{path.split('/')[-1]}`) | no JSON line | | | | | |")
