@@ -110,6 +110,12 @@ class CastIn(torch.nn.Module):
             return self.net(x)
         return self.net(x.to(self.dtype))
 
+    def forward_probs(self, x):  # (softmax(logits), value) where the net has its own fused form
+        if hasattr(self.net, "forward_probs") and getattr(self.net, "wants_float32_input", False):
+            return self.net.forward_probs(x)
+        logits, value = self.forward(x)
+        return torch.softmax(logits.float(), dim=1), value
+
 
 def select_roofline(args, device):
     """HBM roofline of the PUCT-select kernel on the SURVEY section 8d wide workload."""

@@ -1253,12 +1253,12 @@ extern "C" void bo_nn_tower_destroy(bo_tower *t) {
 }
 
 // ---- policy FC + softmax + value head behind the tower: two launches (bo_heads.h) ------------------------------------
-extern "C" int bo_nn_heads(const float *p_dev, const float *v_dev, const float *wp_dev, const float *bp_dev, const float *w1_dev,
+extern "C" int bo_nn_heads(const void *p_dev, const void *v_dev, const float *wp_dev, const float *bp_dev, const float *w1_dev,
                            const float *b1_dev, const float *w2_dev, const float *b2_dev, float *policy_out_dev, float *value_out_dev,
-                           float *scratch_dev, int batch, int softmax, void *stream) {
+                           float *scratch_dev, int batch, int flags, void *stream) {
 #if defined(BO_WAVE_EMU)
     (void)p_dev; (void)v_dev; (void)wp_dev; (void)bp_dev; (void)w1_dev; (void)b1_dev; (void)w2_dev; (void)b2_dev; (void)policy_out_dev;
-    (void)value_out_dev; (void)scratch_dev; (void)batch; (void)softmax; (void)stream;
+    (void)value_out_dev; (void)scratch_dev; (void)batch; (void)flags; (void)stream;
     return fail(BO_E_CONFIG, "bo_nn_heads is a gfx950-only kernel");
 #else
     if (!p_dev || !v_dev || !wp_dev || !bp_dev || !w1_dev || !b1_dev || !w2_dev || !b2_dev || !policy_out_dev || !value_out_dev || !scratch_dev)
@@ -1268,9 +1268,10 @@ extern "C" int bo_nn_heads(const float *p_dev, const float *v_dev, const float *
     a.p = p_dev; a.v = v_dev; a.wp = wp_dev; a.bp = bp_dev; a.w1 = w1_dev; a.b1 = b1_dev; a.w2 = w2_dev; a.b2 = b2_dev;
     a.policy_out = policy_out_dev; a.value_out = value_out_dev;
     a.vpart = scratch_dev;  // [16 K chunks][batch][256]
-    a.B = batch; a.softmax = softmax;
+    a.B = batch; a.softmax = flags & 1;
     const unsigned tiles = (unsigned)(((batch + BO_HEADS_PROWS - 1) / BO_HEADS_PROWS) * (BO_HEADS_NA / 32) + ((batch + 63) / 64) * 4 * BO_HEADS_KS);
-    hipLaunchKernelGGL(bo_k_heads_tiles, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
+    if (flags & 2) hipLaunchKernelGGL(bo_k_heads_tiles<true>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);   // fp16 head planes
+    else hipLaunchKernelGGL(bo_k_heads_tiles<false>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(bo_k_heads_rows, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, a);
     RT((int)hipGetLastError());
     return BO_OK;

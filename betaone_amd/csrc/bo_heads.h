@@ -35,14 +35,27 @@
 #define BO_HEADS_PROWS 128    // boards per logits tile
 
 struct bo_heads_args {
-    const float *p, *v;                       // [B,128], [B,2048]
+    const void *p, *v;                        // [B,128], [B,2048]: float32, or float16 behind the fp16 tower (bo_tower_h.h)
     const float *wp, *bp, *w1, *b1, *w2, *b2;  // policy_fc [4672,128]+[4672]; value_fc1 [256,2048]+[256]; value_fc2 [256]+[1]
     float *policy_out, *value_out;            // [B,4672] (probabilities if softmax != 0, else logits), [B]
     float *vpart;                             // scratch [16 K chunks][B][256]: partial sums of value_fc1
     int B, softmax;
 };
 
-extern "C" __global__ void __launch_bounds__(256)
+// four consecutive activations as float32 from a float32 or float16 array (element index e, a multiple of 4)
+template <bool HALF>
+__device__ __forceinline__ bo_f32x4 bo_heads_load4(const void *base, size_t e) {
+    if constexpr (HALF) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 h = *reinterpret_cast<const h4 *>(reinterpret_cast<const _Float16 *>(base) + e);
+        return bo_f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    } else {
+        return *reinterpret_cast<const bo_f32x4 *>(reinterpret_cast<const float *>(base) + e);
+    }
+}
+
+template <bool HALF>
+__global__ void __launch_bounds__(256)
 bo_k_heads_tiles(bo_heads_args a) {
     __shared__ __attribute__((aligned(16))) float tileA[64 * BO_HEADS_PITCH], tileW[64 * BO_HEADS_PITCH];  // value tiles [64][128 + 4]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kq = lane >> 4, i = lane & 15;
@@ -51,7 +64,7 @@ bo_k_heads_tiles(bo_heads_args a) {
     if (wg < n_policy) {
         // ---- logits tile: boards 128*rb + 32*wave + [0,32) (N), outputs 32*ct + [0,32) (M) ----
         const int rb = wg / NPT, ct = wg - rb * NPT, r0 = BO_HEADS_PROWS * rb + 32 * wave, c0 = 32 * ct;
-        const bo_f32x4 *p4 = reinterpret_cast<const bo_f32x4 *>(a.p), *w4 = reinterpret_cast<const bo_f32x4 *>(a.wp);
+        const bo_f32x4 *w4 = reinterpret_cast<const bo_f32x4 *>(a.wp);
         constexpr int PG = BO_HEADS_KP / 16;
         bo_f32x4 fp[PG][2], fw[PG][2];
 #pragma unroll
@@ -62,7 +75,7 @@ bo_k_heads_tiles(bo_heads_args a) {
 #pragma unroll
             for (int rt = 0; rt < 2; rt++) {
                 const int row = r0 + 16 * rt + i;
-                fp[t][rt] = row < B ? p4[((size_t)row * BO_HEADS_KP + kk) >> 2] : bo_f32x4{0, 0, 0, 0};
+                fp[t][rt] = row < B ? bo_heads_load4<HALF>(a.p, (size_t)row * BO_HEADS_KP + kk) : bo_f32x4{0, 0, 0, 0};
             }
         }
         bo_f32x4 bias[2];
@@ -99,12 +112,12 @@ bo_k_heads_tiles(bo_heads_args a) {
         //      fragment-order fetch of rows 8 KB apart serialises on a few L2 channels), fragments come from LDS. ----
         const int vt = wg - n_policy, ks = vt & (BO_HEADS_KS - 1), ht = (vt >> 4) & 3, rbv = vt >> 6;
         const int r0 = 64 * rbv, h0 = 64 * ht, k0 = (BO_HEADS_KV / BO_HEADS_KS) * ks;
-        const bo_f32x4 *v4 = reinterpret_cast<const bo_f32x4 *>(a.v), *w4 = reinterpret_cast<const bo_f32x4 *>(a.w1);
+        const bo_f32x4 *w4 = reinterpret_cast<const bo_f32x4 *>(a.w1);
         bo_f32x4 ga[8], gw[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int idx = tid + 256 * q, row = idx >> 5, c4 = idx & 31;  // 32 lanes per 512-byte row segment
-            ga[q] = r0 + row < B ? v4[(((size_t)(r0 + row)) * BO_HEADS_KV + k0) / 4 + c4] : bo_f32x4{0, 0, 0, 0};
+            ga[q] = r0 + row < B ? bo_heads_load4<HALF>(a.v, ((size_t)(r0 + row)) * BO_HEADS_KV + k0 + 4 * c4) : bo_f32x4{0, 0, 0, 0};
             gw[q] = w4[(((size_t)(h0 + row)) * BO_HEADS_KV + k0) / 4 + c4];
         }
 #pragma unroll

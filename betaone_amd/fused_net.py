@@ -115,7 +115,7 @@ class FusedPolicyValueNet(nn.Module):
         self.conv = conv
         # policy FC + softmax + value head as one kernel behind the Winograd tower (needs contiguous float32 Linear weights of the
         # reference's head shapes: 2 policy planes, 32 value planes, 256 hidden units)
-        self.fused_heads = conv in ("tower_wg", "tower", "mfma", "mfma_small")
+        self.fused_heads = conv in ("tower_wg", "tower", "mfma", "mfma_small", "tower_f16")
         f = net.for_inference(dtype=torch.float32, channels_last=False)
         dev = next(f.parameters()).device
         if dev.type != "cuda":
@@ -368,7 +368,8 @@ class FusedPolicyValueNet(nn.Module):
         value = torch.empty((B, 1), dtype=torch.float32, device=dev)
         rc = self.lib.bo_nn_heads(p.data_ptr(), v.data_ptr(), self.policy_fc.weight.data_ptr(), self.policy_fc.bias.data_ptr(),
                                   self.value_fc1.weight.data_ptr(), self.value_fc1.bias.data_ptr(), self.value_fc2.weight.data_ptr(),
-                                  self.value_fc2.bias.data_ptr(), out.data_ptr(), value.data_ptr(), scr.data_ptr(), B, 1 if probs else 0,
+                                  self.value_fc2.bias.data_ptr(), out.data_ptr(), value.data_ptr(), scr.data_ptr(), B,
+                                  (1 if probs else 0) | (2 if p.dtype == torch.float16 else 0),
                                   torch.cuda.current_stream(dev).cuda_stream)
         if rc:
             raise E.EngineError(self.lib.bo_last_error().decode())
@@ -436,6 +437,10 @@ class FusedPolicyValueNet(nn.Module):
     def forward(self, x, probs: bool = False):
         if self.conv == "tower_f16":
             p, v = self._tower_f16_forward(x)
+            if self.fused_heads and p.shape[1] == 128 and v.shape[1] == 2048:
+                # fp16 head planes widened on load; float32 head weights, accumulation, softmax and value (closer to the float32 net
+                # than the half-precision GEMMs this replaces)
+                return self._heads(p, v, probs)
             logits = self.policy_fc_h(p)
             return (torch.softmax(logits.float(), dim=1) if probs else logits), torch.tanh(self.value_fc2_h(F.relu(self.value_fc1_h(v))))
         if self.conv == "tower_wg":  # tower + head convolutions in one kernel, then the heads

@@ -261,13 +261,15 @@ int bo_nn_se_residual(float *x_dev, const float *bias_dev, const float *w1_dev, 
 int bo_nn_se_residual_small(const float *x_dev, const float *bias_dev, const float *w1_dev, const float *w2_dev,
                             float *residual_inout_dev, int batch, int channels, int hidden, void *stream);
 /* Everything behind the tower's head convolutions in two launches (csrc/bo_heads.h; network.py:186-197 + the softmax of
- * mcts.py:185,287): policy_out = softmax(policy_fc(p)) (softmax = 0: the logits), value_out = tanh(value_fc2(relu(value_fc1(v)))).
+ * mcts.py:185,287): policy_out = softmax(policy_fc(p)) (flags bit 0 clear: the logits), value_out = tanh(value_fc2(relu(value_fc1(v)))).
  * p [batch,128], v [batch,2048], policy_fc weight [4672,128] + bias, value_fc1 weight [256,2048] + bias, value_fc2 weight
  * [256] + bias [1], all float32 row-major on the device; policy_out [batch,4672], value_out [batch].  scratch_dev:
- * 4096 * batch floats (value_fc1's partial sums, no initial contents needed).  Any batch up to 65536. */
-int bo_nn_heads(const float *p_dev, const float *v_dev, const float *wp_dev, const float *bp_dev, const float *w1_dev,
+ * 4096 * batch floats (value_fc1's partial sums, no initial contents needed).  Any batch up to 65536.
+ * flags: bit 0 = softmax; bit 1 (value 2) = p and v are float16 (the head planes of the BO_TOWER_DIRECT_F16 tower): they are
+ * widened on load, weights, accumulation and outputs stay float32. */
+int bo_nn_heads(const void *p_dev, const void *v_dev, const float *wp_dev, const float *bp_dev, const float *w1_dev,
                 const float *b1_dev, const float *w2_dev, const float *b2_dev, float *policy_out_dev, float *value_out_dev,
-                float *scratch_dev, int batch, int softmax, void *stream);
+                float *scratch_dev, int batch, int flags, void *stream);
 int bo_nn_conv3x3(const float *x_dev, const float *wpacked_dev, const float *bias_dev, const float *residual_dev,
                   float *y_dev, int batch, int c_in, int c_out, int mode, void *stream);
 

@@ -489,3 +489,13 @@ def test_fused_heads_kernel_matches_torch(backend):
             assert (val.double() - value_ref).abs().max().item() < 5e-6, (B, softmax)
             if softmax:
                 assert (out.sum(dim=1) - 1.0).abs().max().item() < 1e-5
+        # float16 head planes (behind the fp16 tower): widened on load, everything else as above
+        ph, vh = p.half(), v.half()
+        ref = torch.softmax(ph.double() @ wp.double().t() + bp.double(), dim=1)
+        value_ref = torch.tanh(torch.relu(vh.double() @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double())
+        out = torch.empty((B, 4672), device="cuda"); val = torch.empty((B, 1), device="cuda")
+        rc = lib.bo_nn_heads(ph.data_ptr(), vh.data_ptr(), wp.data_ptr(), bp.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                             b2.data_ptr(), out.data_ptr(), val.data_ptr(), scratch.data_ptr(), B, 1 | 2, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.bo_last_error()
+        torch.cuda.synchronize()
+        assert (out.double() - ref).abs().max().item() < 2e-6 and (val.double() - value_ref).abs().max().item() < 5e-6, B
