@@ -437,9 +437,10 @@ class FusedPolicyValueNet(nn.Module):
     def forward(self, x, probs: bool = False):
         if self.conv == "tower_f16":
             p, v = self._tower_f16_forward(x)
-            if self.fused_heads and p.shape[1] == 128 and v.shape[1] == 2048:
+            if self.fused_heads and p.shape[1] == 128 and v.shape[1] == 2048 and p.shape[0] <= 1024:
                 # fp16 head planes widened on load; float32 head weights, accumulation, softmax and value (closer to the float32 net
-                # than the half-precision GEMMs this replaces)
+                # than the half-precision GEMMs this replaces).  Up to 1024 boards (configs[4]: 512): the head kernels multiply on
+                # the fp32 matrix pipe, beyond that the library's fp16 GEMM wins (fast mode at 4096+ rows: measured 5-8 % per step).
                 return self._heads(p, v, probs)
             logits = self.policy_fc_h(p)
             return (torch.softmax(logits.float(), dim=1) if probs else logits), torch.tanh(self.value_fc2_h(F.relu(self.value_fc1_h(v))))
