@@ -42,6 +42,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import betaone_amd  # noqa: F401  (first: sets GPU_MAX_HW_QUEUES before the HIP runtime starts -- betaone_amd/__init__.py)
 import numpy as np
 import torch
 
