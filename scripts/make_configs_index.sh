@@ -7,11 +7,11 @@ echo; echo "## final code of the round"; echo
 python scripts/configs_table.py \
   "default: configs[2] per-GPU shard (256 games x 800 sims, 10x128 fp32), 20 timed plies=$L/r04a_bench_default.log" \
   "same, 200 timed plies=$L/r04a_bench_200a.log" "same, 200 timed plies (2nd run)=$L/r04a_bench_200b.log" \
-  "same, 600 timed plies=$L/r04a_bench_steady600.log" "same, 60 timed plies=$L/r04h_steps60.log" \
+  "same, 600 timed plies=$L/r04a_bench_steady600.log" "same, 60 timed plies=$L/r04j_steps60.log" \
   "configs[1] (256 games x 400 sims)=$L/r04a_bench_cfg1.log" "configs[4] per-GPU shard (512 games, 20x256 fp16)=$L/r04i_bench_cfg4.log" "configs[4] shard before the head kernels took fp16 planes=$L/r04a_bench_cfg4.log" \
   "2048 games per GPU (10x128 fp32)=$L/r04a_bench_g2048.log" \
-  "N=1 through RCCL (--force-dist, exchange every 4 plies, 60 timed plies)=$L/r04h_bench_nccl1.log" \
-  "2 ranks sharing the GPU, gloo, 128 games each, exchange every 4 plies=$L/r04d_bench_dist2_gloo.log" \
+  "N=1 through RCCL (--force-dist, exchange every 4 plies, 60 timed plies)=$L/r04j_bench_nccl1.log" "N=1 through RCCL with 4 hardware queues (ROCm default)=$L/r04h_bench_nccl1.log" \
+  "2 ranks sharing the GPU, gloo, 128 games each, exchange every 4 plies=$L/r04j_bench_dist2_gloo.log" \
   "fast mode, 256 games x 16 leaves, fp32 net=$L/r04b_bench_fast.log" "fast mode, 256 games x 16 leaves, fp16 net=$L/r04b_bench_fast_f16.log" \
   "fast mode, 4096 games x 4 leaves, fp16 net=$L/r04b_bench_fast_4096.log"
 echo; echo "UCI latency path (configs[3], \`r04c_uci_latency.log\`): $(tail -1 $L/r04c_uci_latency.log)"
