@@ -10,10 +10,10 @@
 // evaluations of a ply.  Here:
 //   bo_k_heads_tiles   workgroups 0 .. NP-1   logits tile [128 boards x 32 outputs] on v_mfma_f32_16x16x4_f32 (K = 128): every
 //                                             fragment of a wave is requested before its first MFMA (one memory round trip)
-//                      workgroups NP ..       value_fc1 partial tile [64 boards x 64 hidden x 256 of K = 2048]: both operand
+//                      workgroups NP ..       value_fc1 partial tile [64 boards x 64 hidden x 128 of K = 2048]: both operand
 //                                             tiles are staged through LDS with coalesced loads; partial sums go to scratch
 //   bo_k_heads_rows    one board per workgroup: softmax of its logits row (the row passes through registers once) and
-//                      value = tanh(value_fc2(relu(sum of the 8 K chunks in a fixed order + bias)))
+//                      value = tanh(value_fc2(relu(sum of the 16 K chunks in a fixed order + bias)))
 // (A single launch with a device-wide barrier between the two phases was measured first: what crosses the barrier has to be
 // written through / fetched past the XCDs' private L2s, or every workgroup has to write back and invalidate its L2; either way
 // the tiles' stores took longer than the kernel boundary costs -- profiles/r02_heads_probe.md.)
@@ -30,7 +30,7 @@
 #define BO_HEADS_KP 128
 #define BO_HEADS_KV 2048
 #define BO_HEADS_NH 256
-#define BO_HEADS_KS 8         // K chunks of value_fc1 (partial sums reduced by the rows kernel, in a fixed order)
+#define BO_HEADS_KS 16        // K chunks of value_fc1 (partial sums reduced by the rows kernel, in a fixed order)
 #define BO_HEADS_PITCH 132    // floats per LDS tile row: 128 + 4 (conflict-free 16-byte fragment reads)
 #define BO_HEADS_PROWS 128    // boards per logits tile
 
@@ -38,7 +38,7 @@ struct bo_heads_args {
     const void *p, *v;                        // [B,128], [B,2048]: float32, or float16 behind the fp16 tower (bo_tower_h.h)
     const float *wp, *bp, *w1, *b1, *w2, *b2;  // policy_fc [4672,128]+[4672]; value_fc1 [256,2048]+[256]; value_fc2 [256]+[1]
     float *policy_out, *value_out;            // [B,4672] (probabilities if softmax != 0, else logits), [B]
-    float *vpart;                             // scratch [8 K chunks][B][256]: partial sums of value_fc1
+    float *vpart;                             // scratch [16 K chunks][B][256]: partial sums of value_fc1
     int B, softmax;
 };
 
@@ -107,30 +107,26 @@ bo_k_heads_tiles(bo_heads_args a) {
             }
         }
     } else {
-        // ---- value_fc1 partial tile: boards 64*rbv + [0,64), hidden units 64*ht + [0,64), K chunk 256*ks + [0,256) in two
-        //      halves of 128.  Both operand tiles are contiguous 512-byte row segments: fetched with whole-wave coalesced loads
-        //      into LDS (a fragment-order fetch of rows 8 KB apart serialises on a few L2 channels), fragments come from LDS;
-        //      the second half is on its way to registers while the first is multiplied. ----
-        const int vt = wg - n_policy, ks = vt & (BO_HEADS_KS - 1), ht = (vt / BO_HEADS_KS) & 3, rbv = vt / (4 * BO_HEADS_KS);
+        // ---- value_fc1 partial tile: boards 64*rbv + [0,64), hidden units 64*ht + [0,64), K chunk 128*ks + [0,128).
+        //      Both operand tiles are contiguous 512-byte row segments: fetched with whole-wave coalesced loads into LDS (a
+        //      fragment-order fetch of rows 8 KB apart serialises on a few L2 channels), fragments come from LDS. ----
+        const int vt = wg - n_policy, ks = vt & (BO_HEADS_KS - 1), ht = (vt >> 4) & 3, rbv = vt >> 6;
         const int r0 = 64 * rbv, h0 = 64 * ht, k0 = (BO_HEADS_KV / BO_HEADS_KS) * ks;
         const bo_f32x4 *w4 = reinterpret_cast<const bo_f32x4 *>(a.w1);
         bo_f32x4 ga[8], gw[8];
-        auto fetch = [&](int kbase) {
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int idx = tid + 256 * q, row = idx >> 5, c4 = idx & 31;  // 32 lanes per 512-byte row segment
-                ga[q] = r0 + row < B ? bo_heads_load4<HALF>(a.v, ((size_t)(r0 + row)) * BO_HEADS_KV + kbase + 4 * c4) : bo_f32x4{0, 0, 0, 0};
-                gw[q] = w4[(((size_t)(h0 + row)) * BO_HEADS_KV + kbase) / 4 + c4];
-            }
-        };
-        auto stage = [&]() {
+        for (int q = 0; q < 8; q++) {
+            const int idx = tid + 256 * q, row = idx >> 5, c4 = idx & 31;  // 32 lanes per 512-byte row segment
+            ga[q] = r0 + row < B ? bo_heads_load4<HALF>(a.v, ((size_t)(r0 + row)) * BO_HEADS_KV + k0 + 4 * c4) : bo_f32x4{0, 0, 0, 0};
+            gw[q] = w4[(((size_t)(h0 + row)) * BO_HEADS_KV + k0) / 4 + c4];
+        }
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int idx = tid + 256 * q, row = idx >> 5, c4 = idx & 31;
-                *reinterpret_cast<bo_f32x4 *>(&tileA[row * BO_HEADS_PITCH + 4 * c4]) = ga[q];
-                *reinterpret_cast<bo_f32x4 *>(&tileW[row * BO_HEADS_PITCH + 4 * c4]) = gw[q];
-            }
-        };
+        for (int q = 0; q < 8; q++) {
+            const int idx = tid + 256 * q, row = idx >> 5, c4 = idx & 31;
+            *reinterpret_cast<bo_f32x4 *>(&tileA[row * BO_HEADS_PITCH + 4 * c4]) = ga[q];
+            *reinterpret_cast<bo_f32x4 *>(&tileW[row * BO_HEADS_PITCH + 4 * c4]) = gw[q];
+        }
+        __syncthreads();
         // wave: hidden units 32*(wave & 1) + [0,32) (M), boards 32*(wave >> 1) + [0,32) (N)
         const int hb = 32 * (wave & 1), bb = 32 * (wave >> 1);
         bo_f32x4 acc[2][2];
@@ -138,31 +134,20 @@ bo_k_heads_tiles(bo_heads_args a) {
         for (int c = 0; c < 2; c++)
 #pragma unroll
             for (int rt = 0; rt < 2; rt++) acc[c][rt] = bo_f32x4{0, 0, 0, 0};
-        auto multiply = [&]() {
 #pragma unroll
-            for (int t = 0; t < 128 / 16; t++) {
-                bo_f32x4 fw[2], fv[2];
+        for (int t = 0; t < BO_HEADS_KV / BO_HEADS_KS / 16; t++) {
+            bo_f32x4 fw[2], fv[2];
 #pragma unroll
-                for (int c = 0; c < 2; c++) fw[c] = *reinterpret_cast<const bo_f32x4 *>(&tileW[(hb + 16 * c + i) * BO_HEADS_PITCH + 16 * t + 4 * kq]);
+            for (int c = 0; c < 2; c++) fw[c] = *reinterpret_cast<const bo_f32x4 *>(&tileW[(hb + 16 * c + i) * BO_HEADS_PITCH + 16 * t + 4 * kq]);
 #pragma unroll
-                for (int rt = 0; rt < 2; rt++) fv[rt] = *reinterpret_cast<const bo_f32x4 *>(&tileA[(bb + 16 * rt + i) * BO_HEADS_PITCH + 16 * t + 4 * kq]);
+            for (int rt = 0; rt < 2; rt++) fv[rt] = *reinterpret_cast<const bo_f32x4 *>(&tileA[(bb + 16 * rt + i) * BO_HEADS_PITCH + 16 * t + 4 * kq]);
 #pragma unroll
-                for (int e = 0; e < 4; e++)
+            for (int e = 0; e < 4; e++)
 #pragma unroll
-                    for (int c = 0; c < 2; c++)
+                for (int c = 0; c < 2; c++)
 #pragma unroll
-                        for (int rt = 0; rt < 2; rt++) acc[c][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[c][e], fv[rt][e], acc[c][rt], 0, 0, 0);
-            }
-        };
-        fetch(k0);
-        stage();
-        __syncthreads();
-        fetch(k0 + 128);
-        multiply();
-        __syncthreads();  // everybody is done with the first half's tiles
-        stage();
-        __syncthreads();
-        multiply();
+                    for (int rt = 0; rt < 2; rt++) acc[c][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[c][e], fv[rt][e], acc[c][rt], 0, 0, 0);
+        }
         // partial sums [ks][board][256 hidden]: this lane holds hidden h0 + hb + 16c + 4kq + [0,4) of board r0 + bb + 16rt + i
 #pragma unroll
         for (int c = 0; c < 2; c++)
