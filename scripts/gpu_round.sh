@@ -1,6 +1,6 @@
 #!/bin/bash
 # scripts/gpu_round.sh -- one gpurun call: GPU tests, then the bench lines; stops at the first step that timed out / was killed.
-# usage (on the GPU box): bash scripts/gpu_round.sh <tag> [steps...]   steps: tests bench softmax dist2 steady
+# usage (on the GPU box): bash scripts/gpu_round.sh <tag> [steps...]   steps: see the case list below (tests bench bench200 steady cfg1 cfg4 g2048 fast* uci nccl1 dist2 trace pmctower ...)
 set -u
 tag=$1; shift
 out=gpurun_out
