@@ -99,8 +99,14 @@ def test_native_rollout_equals_python_rollout_and_oracle():
         rngs = seeds if mode == "native" else [np.random.RandomState(s) for s in seeds]
         ro.start_games([0, 1, 2, 3], [0, 1, 2, 3], rngs, fens)
         fins = {}
+        calls = [0, 0]  # play_ply calls, while_searching calls; finished games must already be reported when the hook runs
+        seen_at_hook = []
         while any(g is not None for g in ro.games):
-            ro.play_ply(on_finished=lambda f: fins.__setitem__(f.game_id, f))
+            calls[0] += 1
+            ro.play_ply(on_finished=lambda f: fins.__setitem__(f.game_id, f),
+                        while_searching=lambda: (calls.__setitem__(1, calls[1] + 1), seen_at_hook.append(len(fins))))
+            assert seen_at_hook[-1] == len(fins)  # nothing is reported after the hook of the same ply
+        assert calls[0] == calls[1]  # exactly once per ply, in every exit path of play_ply
         ro.close()
         return fins
 
