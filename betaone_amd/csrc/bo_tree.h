@@ -541,37 +541,7 @@ BO_DEV void backup_run(const Eng &e, int g, int leaf, float v, int cnt, int *scr
         const float val = (i & 1) ? -v : v;
         int n = e.n_visits[no + nd];
         float qv = e.q[no + nd];
-        int c = 0;
-        // The batch's `cnt` incremental-mean updates are a recurrence: q depends on the previous q, the divisors n+1 .. n+cnt do
-        // not.  Their correctly rounded reciprocals come from the host-built table eight at a time, one block ahead of the
-        // chain, and each division is the 3-operation exact form (bo_div_count: == dd / (float)n bit for bit) instead of the
-        // ~10 dependent operations of the general sequence.
-        if (cnt >= 16 && n + cnt <= e.c.S + 2) {
-            const float *rt = e.rcp_lut + n + 1;
-            float ra[8], rb[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) ra[j] = rt[j];
-            for (; c + 16 <= cnt; c += 16) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) rb[j] = rt[c + 8 + j];
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    n += 1;
-                    const float dd = val - qv;
-                    qv = qv + bo_div_count(dd, (float)n, ra[j]);
-                }
-                const bool more = c + 32 <= cnt;  // (the block after next exists: fetch it while this one is applied)
-#pragma unroll
-                for (int j = 0; j < 8; j++) ra[j] = more ? rt[c + 16 + j] : 0.0f;
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    n += 1;
-                    const float dd = val - qv;
-                    qv = qv + bo_div_count(dd, (float)n, rb[j]);
-                }
-            }
-        }
-        for (; c < cnt; c++) {
+        for (int c = 0; c < cnt; c++) {  // (the table division of the burst does not pay here: its reciprocal would be a load per step)
             n += 1;
             const float dd = val - qv;
             const float ee = dd / (float)n;
