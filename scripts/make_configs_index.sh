@@ -7,7 +7,7 @@ echo; echo "## final code of the round"; echo
 python scripts/configs_table.py \
   "default: configs[2] per-GPU shard (256 games x 800 sims, 10x128 fp32), 20 timed plies=$L/r04a_bench_default.log" \
   "same, 200 timed plies=$L/r04a_bench_200a.log" "same, 200 timed plies (2nd run)=$L/r04a_bench_200b.log" \
-  "same, 600 timed plies=$L/r04a_bench_steady600.log" "same, 60 timed plies=$L/r04j_steps60.log" \
+  "same, 600 timed plies=$L/r04a_bench_steady600.log" "same, 5000 timed plies (3847 games finished, mean 331 plies)=$L/r05c_bench_5000.log" "same, 60 timed plies=$L/r04j_steps60.log" \
   "configs[1] (256 games x 400 sims)=$L/r04a_bench_cfg1.log" "configs[4] per-GPU shard (512 games, 20x256 fp16)=$L/r04i_bench_cfg4.log" "configs[4] shard before the head kernels took fp16 planes=$L/r04a_bench_cfg4.log" \
   "2048 games per GPU (10x128 fp32)=$L/r04a_bench_g2048.log" \
   "N=1 through RCCL (--force-dist, exchange every 4 plies, 60 timed plies)=$L/r04j_bench_nccl1.log" "N=1 through RCCL with 4 hardware queues (ROCm default)=$L/r04h_bench_nccl1.log" \
