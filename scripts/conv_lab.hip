@@ -209,7 +209,11 @@ int main() {
         for (int l = 0; l < NL; l++) L[l] = {(int)(l * per), l == 0 ? 72 : 144, l * 256, l == 0 ? 0 : (l % 2 ? 1 : 2), 0, 0, 0, l == NL - 1};
         CK(hipMemcpy(tl, L.data(), NL * sizeof(bo_tower_layer), hipMemcpyHostToDevice));
         bo_tower_head_h hh; hh.channels = 34; hh.split = 2; hh.w_off8 = (int)(NL * per); hh.b_off = 0; hh.out_a = oa; hh.out_b = ob;
-        for (int variant = 0; variant < 6; variant++) {
+        for (int variant = 0; variant < 7; variant++) {
+            if (variant == 6) {  // every layer reads layer 1's weights: they stay in L2 (is the weight stream latency or bandwidth?)
+                for (int l = 1; l < NL; l++) L[l].w_off4 = (int)(1 * per);
+                CK(hipMemcpy(tl, L.data(), NL * sizeof(bo_tower_layer), hipMemcpyHostToDevice));
+            }
             for (int B : {512}) {
                 hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
                 auto go = [&]() {
@@ -225,7 +229,7 @@ int main() {
                 for (int i = 0; i < 10; i++) go();
                 (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
                 float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
-                const char *names[6] = {"full", "no weight loads", "no B reads", "no epilogue", "MFMA loop only", "MFMA loop only, no barriers"};
+                const char *names[7] = {"full", "no weight loads", "no B reads", "no epilogue", "MFMA loop only", "MFMA loop only, no barriers", "full, shared weights"};
                 printf("fp16 tower 20x256 (%s) B=%d: %.1f us = %.2f us/layer/512 boards\n", names[variant], B, ms * 1000 / 10, ms * 1000 / 10 / NL / (B / 512));
             }
         }
