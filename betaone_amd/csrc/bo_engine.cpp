@@ -222,7 +222,7 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
     rc |= e->alloc(&sq, (size_t)c.S + 2); rc |= e->alloc(&wl, (size_t)c.B + 1); rc |= e->alloc(&rcp, (size_t)c.S + 3);
     int **iscal[] = {&d.sims_done, &d.n_nodes, &d.rows, &d.n_runs, &d.n_ul, &d.req_nlegal, &d.status,
                      &d.trk_n, &d.n_hist, &d.ctx_mode, &d.root_nch, &d.stat_evals,
-                     &d.stat_flushes, &d.stat_term_sims, &d.stat_levels, &d.stat_children_scanned, &d.term_bank, &e->d_go, &e->d_action};
+                     &d.stat_flushes, &d.stat_term_sims, &d.stat_levels, &d.stat_children_scanned, &e->d_go, &e->d_action};
     for (int **p : iscal) rc |= e->alloc(p, G);
     const size_t res_ints = G * (4 + 2 * (size_t)BO_RES_CAP), info_ints = G * 5;
     rc |= e->alloc(&e->d_res_blk, res_ints); rc |= e->alloc(&e->d_info_blk, info_ints);

@@ -59,7 +59,6 @@ struct Eng {
     int *phase, *sims_done, *n_nodes, *rows, *n_runs, *n_ul, *req_node, *req_nlegal, *status;
     int *ply, *trk_n, *n_hist, *ctx_mode, *root_nlegal, *root_term, *root_nch;
     int *stat_evals, *stat_flushes, *stat_term_sims, *stat_levels, *stat_children_scanned;
-    int *term_bank;  // terminal simulations of this search that no yield has been charged against yet (bo_k_step)
     // game stack, tracker, explicit history
     DPos *gpos, *trk, *hist;
     int *trk_cnt;
@@ -393,7 +392,6 @@ BO_DEV int select_leaf(const Eng &e, int g, int *flags, int *path, int *depth_ou
 // registers, and as long as it reproduces the same path the loop continues.  Returns the number of simulations
 // applied (>= 1); the caller re-selects from memory afterwards.  Bit-identical to backup_run + select_leaf.
 #define BO_BURST_LEVELS 4
-#define BO_YIELD_CYCLES 120000ull
 #define BO_BURST_FITS(S) (2 * (S) + 5 <= BO_NUM_ACTIONS)  // both tables in the step kernel's 18 KB probability buffer (S <= 2333)
 // x / fn for fn = (float)n, n a small positive integer (a visit count), y = RN(1 / fn) from the host-built table: quotient
 // estimate, exact remainder (fma), one correction (fma) -- the correctly rounded quotient (Markstein's division; it holds
@@ -797,17 +795,7 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
     // therefore absorbs at most MCTS_BATCH_SIZE of them per game and then YIELDS: the game asks for nothing (its NN row is
     // evaluated and ignored) and carries on in the next launch.  Results are unchanged (the same operations in the same
     // order), and the search needs no more launches than one that spends those simulations on a batch of 96 rows would.
-    // A yield costs the game one launch without a batch of MCTS_BATCH_SIZE rows, so it has to be paid for with that many
-    // terminal simulations -- of this launch, or BANKED: terminal simulations of earlier launches of this search that came
-    // on top of a batch (the game is that far ahead of one that never meets a terminal leaf, which is what the number of
-    // launches per search is sized for).  With a bank the game may therefore yield before this launch's own budget is
-    // used up; it does so once the launch has run BO_YIELD_CYCLES (about what a launch takes a game without terminal
-    // simulations) -- the tail of the launch durations is games that alternate between terminal leaves at ~5000 cycles
-    // per simulation (two per burst), 96 of them.
     int term_budget = e.c.B;
-    const int bank0 = e.term_bank[g];
-    const unsigned long long t_launch = bo_clock();
-    bool yielded = false;
     int path_leaf = -1, path_depth = -1;  // the leaf whose descent sh.path holds (none yet in this launch)
     for (;;) {
         if (sims >= e.c.S) {  // mcts.py:256-257
@@ -850,10 +838,7 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
             term_budget -= applied;
             if (lane == 0) e.stat_term_sims[g] += applied;
             BO_PROF(3)
-            if (sims < e.c.S && (term_budget <= 0 || (bank0 + (e.c.B - term_budget) >= e.c.B && bo_clock() - t_launch > BO_YIELD_CYCLES))) {
-                yielded = true;  // req stays -1, phase stays RUN
-                break;
-            }
+            if (term_budget <= 0 && sims < e.c.S) break;  // yield: req stays -1, phase stays RUN
             continue;
         }
         if (e.eval_slot[no + leaf] < 0) {  // needs the net: emit planes 98..119 into row g and pause
@@ -892,7 +877,6 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
     if (lane == 0) {
         e.sims_done[g] = sims; e.rows[g] = rows; e.n_runs[g] = n_runs; e.n_ul[g] = n_ul; e.n_nodes[g] = n_nodes;
         e.req_node[g] = req; e.phase[g] = phase;
-        e.term_bank[g] = bank0 + (e.c.B - term_budget) - (yielded ? e.c.B : 0);  // (>= 0: a yield needs bank + this launch's >= B)
         if (flags) e.status[g] |= flags;
     }
 }
@@ -907,7 +891,7 @@ BO_DEV void root_prepare(const Eng &e, int g, StepShared &sh) {
     if (lane == 0) {
         init_node(e, no, 0, -1, 1.0f, 0, P);
         e.n_nodes[g] = 1; e.sims_done[g] = 0; e.rows[g] = 0; e.n_runs[g] = 0; e.n_ul[g] = 0;
-        e.req_node[g] = -1; e.phase[g] = PH_IDLE; e.root_nch[g] = 0; e.term_bank[g] = 0;
+        e.req_node[g] = -1; e.phase[g] = PH_IDLE; e.root_nch[g] = 0;
         if (e.ctx_mode[g] == 0) {  // self-play context: history = the <=7 real positions before the root
             int nh = ply < 7 ? ply : 7;
             e.n_hist[g] = nh;
