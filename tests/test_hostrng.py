@@ -166,3 +166,56 @@ def test_native_rollout_with_slot_recycling_equals_python_rollout():
         assert a[gid].moves == b[gid].moves and a[gid].terminal == b[gid].terminal, gid
         for (i1, v1), (i2, v2) in zip(a[gid].pis, b[gid].pis):
             assert i1.tolist() == i2.tolist() and v1.tolist() == v2.tolist()
+
+
+def test_turn_without_waiting_reports_the_roots_later_and_refuses_calls_out_of_order():
+    """bo_selfplay_turn(flag 4): the next searches are begun on the device without a host round trip; bo_selfplay_begun then
+    returns what bo_selfplay_begin would have (n_legal, terminal, go) -- compared here with the waiting form of the same turn on
+    a second engine -- and calls out of order are refused (BO_E_STATE), not silently wrong."""
+    import torch
+    from fake_model import fake_logits_values
+
+    def search_all(en, nn_in):
+        for _ in range(12):
+            running, _, _ = en.poll(0, want_mask=False)
+            if running == 0:
+                return
+            planes = nn_in.numpy().copy()
+            logits, values = fake_logits_values(planes, 0.0, 5)
+            probs = torch.softmax(torch.from_numpy(logits), dim=1).numpy().astype(np.float32)
+            en.step(probs.ctypes.data, values.astype(np.float32).ctypes.data, E.POLICY_PROBS, nn_in.data_ptr(), 0)
+        raise AssertionError("search did not finish")
+
+    outs = []
+    for lazy in (False, True):
+        en = emu_call(E.Engine, 3, num_simulations=20, mcts_batch_size=8)
+        nn_in = torch.zeros((3, E.INPUT_CHANNELS, 8, 8), dtype=torch.float32)
+        en.reset([0, 1, 2], ["k7/8/1K6/8/8/8/8/7R w - - 0 1", None, "7k/5Q2/6K1/8/8/8/8/8 w - - 0 1"], None)
+        for g in range(3):
+            en.rng_seed(g, 100 + g)
+        want = np.ones(3, dtype=np.int32)
+        nl, term, go = en.selfplay_begin(want, nn_in.data_ptr(), 0)
+        assert go.tolist() == [1, 1, 1]
+        search_all(en, nn_in)
+        out = dict(n=np.zeros(3, np.int32), idx=np.zeros((3, E.RES_CAP), np.int32), val=np.zeros((3, E.RES_CAP), np.float32),
+                   best_idx=np.zeros(3, np.int32), action=np.zeros(3, np.int32))
+        o, begun = en.selfplay_turn(go, np.ones(3, np.int32), (30, 1.0, 0.1), out, want, nn_in.data_ptr(), 0, defer_noise=True,
+                                    poll_first=True, lazy_begin=lazy)
+        assert o is not None
+        if lazy:
+            assert begun is E.LAZY_BEGIN
+            with pytest.raises(E.EngineError):   # the roots of the turn have not been collected yet
+                en.selfplay_begin(want, nn_in.data_ptr(), 0)
+            with pytest.raises(E.EngineError):
+                en.selfplay_noise(0)
+            begun = en.selfplay_begun()
+            with pytest.raises(E.EngineError):   # ... and only once
+                en.selfplay_begun()
+        en.selfplay_noise(0)
+        outs.append((o["action"].copy(), [b.copy() for b in begun], nn_in.numpy().copy()))
+        en.close()
+    (a0, b0, x0), (a1, b1, x1) = outs
+    assert a0.tolist() == a1.tolist()
+    for u, v in zip(b0, b1):
+        assert u.tolist() == v.tolist()
+    assert np.array_equal(x0, x1)   # the same root planes are on their way to the net
