@@ -607,9 +607,11 @@ struct BoPool {
             cv_done.notify_one();
         }
     }
-    void run(int n, const std::function<void(int)> &f) {
+    // light: microseconds of work in total (sampling one of <= 2 moves per game, flag bookkeeping) -- inline: waking the workers
+    // and waiting for every one of them to report back costs a futex round trip (~30-50 us) the device idles through
+    void run(int n, const std::function<void(int)> &f, bool light = false) {
         // (a fork()ed child inherits the object but not the threads: it works inline)
-        if (workers.empty() || n < 64 || getpid() != owner) { for (int i = 0; i < n; i++) f(i); return; }
+        if (workers.empty() || n < 64 || (light && n <= 2048) || getpid() != owner) { for (int i = 0; i < n; i++) f(i); return; }
         {
             std::lock_guard<std::mutex> l(m);
             job = &f; n_items = n; chunk = 8; next = 0; pending = (int)workers.size(); generation++;
@@ -670,7 +672,7 @@ static int selfplay_sample_impl(bo_engine *e, const int32_t *active, const int32
         const int a = e->fast ? hr_select_action_general(&e->rng[g], res_n[g], ri, rv, move_number[g], threshold, t_initial, t_final)
                               : hr_select_action(&e->rng[g], res_n[g], ri, rv, move_number[g], threshold, t_initial, t_final);
         action_out[g] = a >= 0 ? a : -3;  // -3: not sparse enough, the caller samples with the dense NumPy mirror
-    });
+    }, !e->fast);  // reference semantics: pi has <= 2 entries, a few dozen nanoseconds per game
     return BO_OK;
 }
 
@@ -699,7 +701,7 @@ static int selfplay_begin_impl(bo_engine *e, const int32_t *want, float *nn_in_d
         if (n_legal_out) n_legal_out[g] = e->h_nl[g];
         if (terminal_out) terminal_out[g] = e->h_term[g];
         if (go_out) go_out[g] = go;
-    });
+    }, defer_noise || alpha <= 0);  // (without the Dirichlet draws this is flag bookkeeping)
     e->nl_valid = true;
     rc = search_begin_impl(e, e->h_go, (alpha > 0 && !defer_noise) ? e->h_noise : nullptr, defer_noise, nn_in_dev, stream);
     if (rc) return rc;
