@@ -31,7 +31,9 @@
 #define BO_PATH_CAP 1024 // max tree depth
 #define BO_RES_CAP 256
 #define BO_PLANES 120
-#define BO_PROF_SLOTS 16  // bo_debug_profile: u64 counters per game
+#ifndef BO_PROF_SLOTS
+#define BO_PROF_SLOTS 16  // bo_debug_profile: u64 counters per game (public: include/betaone_engine.h)
+#endif
 #define BO_ROW (BO_PLANES * 64)
 
 enum { PH_IDLE = 0, PH_RUN = 1, PH_DONE = 2 };

@@ -123,6 +123,8 @@ def bind(cdll: C.CDLL) -> C.CDLL:
 
 
 _hip_lib: Optional[C.CDLL] = None
+ABI_VERSION = 3   # BO_ABI_VERSION of include/betaone_engine.h this binding was written against (tests/test_abi.py compares)
+PROF_SLOTS = 16   # BO_PROF_SLOTS
 
 
 def load_hip_library() -> C.CDLL:
@@ -138,8 +140,8 @@ def load_hip_library() -> C.CDLL:
             raise EngineError(f"{HIP_LIB_PATH} was not built from the sources next to it (csrc/*.h changed since): "
                               "run `python -m betaone_amd.build`")
         _hip_lib = bind(C.CDLL(HIP_LIB_PATH))
-        if _hip_lib.bo_abi_version() != 1:
-            raise EngineError("libbetaone_hip.so ABI version mismatch")
+        if _hip_lib.bo_abi_version() != ABI_VERSION:
+            raise EngineError(f"libbetaone_hip.so ABI version {_hip_lib.bo_abi_version()} != {ABI_VERSION} (include/betaone_engine.h)")
     return _hip_lib
 
 
@@ -420,7 +422,7 @@ class Engine:
             raise EngineError(f"game slot {g}: {self.describe_status(int(st[g]))}")
 
     def profile(self, enable: int = -1, read: bool = True, stream: int = 0):
-        out = np.zeros((self.G, 16), dtype=np.uint64) if read else None
+        out = np.zeros((self.G, PROF_SLOTS), dtype=np.uint64) if read else None
         self._check(self.lib.bo_debug_profile(self.h, enable, out.ctypes.data_as(C.POINTER(C.c_uint64)) if read else None, stream))
         return out
 

@@ -361,9 +361,10 @@ class FusedPolicyValueNet(nn.Module):
     def _heads(self, p, v, probs):
         B = p.shape[0]
         dev = p.device
-        scr = self.__dict__.get("_heads_scratch")
-        if scr is None or scr.device != dev or scr.numel() < 4096 * B:  # value_fc1 partial sums
-            scr = self.__dict__["_heads_scratch"] = torch.empty(4096 * max(B, 256), dtype=torch.float32, device=dev)
+        # value_fc1 partial sums: allocated per call -- under graph capture it then comes from the graph's own pool (a module-wide
+        # scratch that grew with a later, larger batch left earlier captured graphs writing into freed memory, and was shared
+        # by concurrent streams); the caching allocator makes the eager cost a free-list lookup
+        scr = torch.empty(4096 * B, dtype=torch.float32, device=dev)
         out = torch.empty((B, 4672), dtype=torch.float32, device=dev)
         value = torch.empty((B, 1), dtype=torch.float32, device=dev)
         rc = self.lib.bo_nn_heads(p.data_ptr(), v.data_ptr(), self.policy_fc.weight.data_ptr(), self.policy_fc.bias.data_ptr(),

@@ -153,7 +153,7 @@ class Rollout:
         self._start_step = np.zeros(G, dtype=np.int64)
         self._first_ply = np.zeros(G, dtype=np.int64)
         self._step = 0
-        self._hist = {}             # step -> (n[G], idx[G,K], val[G,K]) sparse pi of every game at that step
+        self._hist = {}             # step -> (go[G], n[G], idx[G,K], val[G,K]) sparse pi of every game that searched at that step
         # reference semantics: pi has <= 2 entries, kept per slot and ply in dense arrays that grow with the longest game
         self._pk = 0 if self.fast else 2
         self._pi_n = np.zeros((G, 256), np.int32)
@@ -451,7 +451,9 @@ class Rollout:
         else:
             self._begun, self._begun_want, self._noise_pending = begun, want_next.copy(), not self.fast
         k = max(1, int(out["n"].max()))
-        self._hist[self._step] = (out["n"].copy(), out["idx"][:, :k].copy(), out["val"][:, :k].copy())
+        # (keyed by step WITH the mask of the games that searched: a slot refilled inside a ply sits that ply out, so its new
+        # game's first pi belongs to the next step -- the row of this step is still its previous occupant's)
+        self._hist[self._step] = (go.astype(bool), out["n"].copy(), out["idx"][:, :k].copy(), out["val"][:, :k].copy())
         if self._pk and k <= self._pk:  # this ply's pi of every searched game into its slot's row (one scatter)
             rows = np.nonzero(go)[0]
             cols = (self._plies[rows] - self._first_ply[rows]).astype(np.int64)
@@ -502,8 +504,9 @@ class Rollout:
         elif self.rng_mode == "native":  # (fast mode: pi over many moves) gather from the per-step arrays
             pis = []
             for st in range(int(self._start_step[g]), self._step):
-                n, idx, val = self._hist[st]
-                pis.append((idx[g, :n[g]].copy(), val[g, :n[g]].copy()))
+                went, n, idx, val = self._hist[st]
+                if went[g]:
+                    pis.append((idx[g, :n[g]].copy(), val[g, :n[g]].copy()))
         # one (state, pi) per move actually played (self_play.py:122,171): a start position that is already over yields
         # none, and a move the engine refused (no room left in the slot's position stack) leaves no record either
         pis = pis[:max(0, len(moves) - gs.first_ply)]

@@ -24,7 +24,12 @@
 extern "C" {
 #endif
 
-#define BO_ABI_VERSION 1
+/* Bumped whenever an output size, a struct, or the layout a caller has to produce changes (2: bo_debug_profile returns
+ * [G][BO_PROF_SLOTS = 16] counters, the BO_TOWER_WINOGRAD packed-weight K order for 128 filters is winograd_k_order's;
+ * 3: fast-mode arenas are allocated in 128-byte granules of 8 records, bo_fast_stats counts granules).  A caller checks
+ * bo_abi_version() == BO_ABI_VERSION before anything else (tests/c_abi_smoke.c). */
+#define BO_ABI_VERSION 3
+#define BO_PROF_SLOTS 16             /* uint64 counters per game returned by bo_debug_profile */
 #define BO_NUM_ACTIONS 4672          /* config.NUM_ACTIONS, config.py:29 */
 #define BO_INPUT_CHANNELS 120        /* config.INPUT_CHANNELS, config.py:28 */
 #define BO_ROW_FLOATS (120 * 64)
@@ -218,9 +223,12 @@ int bo_fast_stats(bo_engine *e, uint64_t *blocks_read, uint64_t *path_nodes, int
 int bo_engine_status(bo_engine *e, int32_t *status, int32_t *evals, int32_t *flushes, int32_t *term_sims,
                      int32_t *levels, int32_t *children_scanned, void *stream);
 
-/* Per-phase shader cycles of bo_step (s_memtime), accumulated per game while enabled: cycles_out [G][10] =
- * apply, select, first visit (move generation + draw rules), terminal backups, leaf encode, flush, total, steps,
- * simulation-loop iterations, first visits.
+/* Per-phase shader cycles of bo_step (s_memtime), accumulated per game while enabled: cycles_out [G][BO_PROF_SLOTS] (16
+ * uint64 per game; size the buffer with the macro) =
+ *   [0] apply, [1] select, [2] first visit (move generation + draw rules), [3] terminal backups, [4] leaf encode, [5] flush,
+ *   [6] total, [7] game-steps counted, [8] simulation-loop iterations, [9] first visits, [10] terminal-burst calls,
+ *   [11] simulations applied inside bursts, [12] terminal simulations on the general path, [13] cycles in burst set-up,
+ *   [14] cycles in the burst loop, [15] reserved (0).
  * enable: 1 = every game-step, N > 1 = only game-steps longer than N cycles, 0 = off (a 0->on switch clears the
  * counters), -1 = only read.  A captured hipGraph keeps the setting it
  * was captured with.  Synchronises when cycles_out != NULL. */

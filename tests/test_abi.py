@@ -25,7 +25,9 @@ def test_hip_library_builds_loads_and_exports_the_abi():
     for name in declared_symbols():
         assert hasattr(lib, name), name
     E.bind(lib)
-    assert lib.bo_abi_version() == 1
+    header = open(os.path.join(ROOT, "include", "betaone_engine.h")).read()
+    assert lib.bo_abi_version() == E.ABI_VERSION == int(re.search(r"#define BO_ABI_VERSION (\d+)", header).group(1))
+    assert E.PROF_SLOTS == int(re.search(r"#define BO_PROF_SLOTS (\d+)", header).group(1))
 
 
 def test_product_loader_has_no_fallback(monkeypatch, tmp_path):

@@ -155,3 +155,50 @@ def test_fast_mode_invariants_many_games():
     # different seeds (noise) -> different games, same seed -> identical
     a = [tuple((k["n"]) for k in eng.debug_tree(g)[1:21]) for g in range(G)]
     assert len(set(a)) > 1
+
+
+def test_fast_rollout_refilled_slot_records_the_pis_of_its_own_game():
+    """A slot refilled inside a ply sits that ply out: the new game's first pi belongs to the NEXT step, not to the row its
+    slot's previous occupant left behind (round-2 advisor finding: every (state, pi) record of such a game was shifted by
+    one ply).  Staggered starts + refill in a 2-slot rollout; every game's (moves, pis) must equal a solo run of its id."""
+    import torch
+    from betaone_amd.rollout import Rollout
+    from fake_model import FakeNet
+
+    class Net(torch.nn.Module):
+        def forward(self, x):
+            return FakeNet(scale=2.0, salt=3)(x)
+
+    start = ["k7/8/1K6/8/8/8/8/7R w - - 96 60", None, "6k1/5ppp/8/8/8/8/5PPP/3R2K1 w - - 0 30"]
+
+    def run(slots, ids, stagger):
+        ro = emu_call(Rollout, Net(), slots, num_simulations=12, mcts_batch_size=8, max_game_moves=4, device="cpu", use_graph=False,
+                      rng_mode="native", fast=True, leaves_per_step=4)
+        todo, fins = list(ids), {}
+
+        def refill(_slot):
+            if not todo:
+                return None
+            gid = todo.pop(0)
+            return gid, 50 + gid, start[gid % 3]
+
+        first = [todo.pop(0) for _ in range(min(slots, len(todo)))]
+        ro.start_games([0], [first[0]], [50 + first[0]], [start[first[0] % 3]])
+        for _ in range(stagger):  # slot 1 enters two plies later: the two games never end in the same ply
+            ro.play_ply(on_finished=lambda f: fins.__setitem__(f.game_id, f), refill=refill)
+        if len(first) > 1:
+            ro.start_games([1], [first[1]], [50 + first[1]], [start[first[1] % 3]])
+        while any(g is not None for g in ro.games):
+            ro.play_ply(on_finished=lambda f: fins.__setitem__(f.game_id, f), refill=refill)
+        ro.close()
+        return fins
+
+    many = run(2, list(range(6)), 2)
+    assert sorted(many) == list(range(6))
+    for gid in range(6):
+        solo = run(1, [gid], 0)[gid]
+        got = many[gid]
+        assert got.moves == solo.moves and got.terminal == solo.terminal, gid
+        assert len(got.pis) == len(solo.pis) == len(got.moves), gid
+        for (i1, v1), (i2, v2) in zip(got.pis, solo.pis):
+            assert i1.tolist() == i2.tolist() and v1.tolist() == v2.tolist(), gid
