@@ -55,17 +55,17 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--games", type=int, default=256, help="concurrent games per GPU")
-    ap.add_argument("--sims", type=int, default=800)
+    ap.add_argument("--games", type=int, default=None, help="concurrent games per GPU (default 256; --fast: 32768)")
+    ap.add_argument("--sims", type=int, default=None, help="simulations per move (default 800; --fast: 128)")
     ap.add_argument("--batch", type=int, default=96)
-    ap.add_argument("--net", default="10x128", choices=list(NETS))
-    ap.add_argument("--net-dtype", default="fp32", choices=["fp32", "fp16", "bf16"])
+    ap.add_argument("--net", default=None, choices=list(NETS), help="default 10x128")
+    ap.add_argument("--net-dtype", default=None, choices=["fp32", "fp16", "bf16"], help="default fp32; --fast: fp16")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-cores", type=int, default=0, help="0 = the box's CPU share (affinity mask, at most 16)")
-    ap.add_argument("--preroll", type=int, default=640, help="untimed plies played before warm-up to reach steady state (0 = opening phase)")
+    ap.add_argument("--preroll", type=int, default=None, help="untimed plies played before warm-up to reach steady state (0 = opening phase; default 640, --fast: 10)")
     ap.add_argument("--opening-steps", type=int, default=20, help="plies of the labelled opening-only extra measurement (0 = skip)")
     ap.add_argument("--softmax", default="torch", choices=["torch", "engine"], help="policy softmax: torch.softmax in the graph (the reference's op) or the step kernel's own")
     ap.add_argument("--exchange-every", type=int, default=16, help="N>1: plies per record-exchange period")
@@ -73,12 +73,26 @@ def parse():
     ap.add_argument("--wide-trees", type=int, default=0, help="0 = 262144 if >= 150 GB of HBM is free, else 131072")
     ap.add_argument("--wide-nodes", type=int, default=800)
     ap.add_argument("--fast", action="store_true", help="FAST search mode (virtual loss; not the reference's semantics; not the headline)")
-    ap.add_argument("--leaves", type=int, default=16, help="FAST mode: leaves per game per step")
-    ap.add_argument("--max-game-moves", type=int, default=16384, help="config.MAX_GAME_MOVES (small values make games finish: record path)")
+    ap.add_argument("--leaves", type=int, default=4, help="FAST mode: leaves per game per step")
+    ap.add_argument("--select-games-per-halfwave", type=int, default=None, help="FAST mode: bo_fast_options games_per_halfwave (2 or 4)")
+    ap.add_argument("--select-flags", type=int, default=None, help="FAST mode: bo_fast_options select_flags (1 nt, 2 root in registers, 4 dense)")
+    ap.add_argument("--select-sweep", action="store_true", help="FAST mode: time every variant of the select + backup kernel on this run's trees")
+    ap.add_argument("--roofline-plies", type=int, default=2, help="FAST mode: plies played eagerly for the select kernel's event timing")
+    ap.add_argument("--max-game-moves", type=int, default=None, help="config.MAX_GAME_MOVES (small values make games finish: record path; default 16384, --fast: 510)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 path on one GPU")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with WORLD_SIZE=1")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
-    return ap.parse_args()
+    args = ap.parse_args()
+    # --fast is priced on its own workload: enough resident games for the select + backup kernel to be
+    # bandwidth-bound (a descent is a chain of dependent reads), a small fp16 net so that the evaluate stage does not starve it
+    d_ref = dict(games=256, sims=800, net="10x128", net_dtype="fp32", preroll=640, max_game_moves=16384)
+    d_fast = dict(games=32768, sims=128, net="10x128", net_dtype="fp16", preroll=10, max_game_moves=510)
+    for k, v in (d_fast if args.fast else d_ref).items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    if args.fast and args.steps == 20 and args.warmup == 3:
+        args.steps, args.warmup = 3, 1
+    return args
 
 
 def make_net(name, device, dtype, batch=256):
@@ -116,6 +130,18 @@ class CastIn(torch.nn.Module):
             return self.net.forward_probs(x)
         logits, value = self.forward(x)
         return torch.softmax(logits.float(), dim=1), value
+
+
+def softmax_site(net, args, rows):
+    """Where the policy softmax of mcts.py:185,287 actually runs in this configuration (the label follows the code path)."""
+    if args.softmax != "torch":
+        return "bo_k_step / bo_k_fw_apply (the tree kernel's own softmax over the row)"
+    inner = getattr(net, "net", net)
+    conv = getattr(inner, "conv", None)
+    if getattr(inner, "fused_heads", False) and hasattr(inner, "forward_probs") and (conv != "tower_f16" or rows <= 1024) \
+            and (args.net_dtype == "fp32" or getattr(inner, "wants_float32_input", False)):
+        return "bo_k_heads_rows (hand-written head kernel csrc/bo_heads.h: the row's softmax in registers, float32)"
+    return "torch.softmax(logits.float(), dim=1) inside the captured graph"
 
 
 def select_roofline(args, device):
@@ -219,47 +245,77 @@ def nn_roofline(net, batch, device, ro=None, drv=None, plies=3):
     peak = 157.3  # TFLOP/s dense fp32 MFMA: 256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz (MI355X_MICROARCH.md)
     return {"bound": "mfma", "kernel": "bo_k_tower_wg" if conv == "tower_wg" else "bo_k_tower", "achieved": round(executed / us / 1e6, 1), "peak": peak,
             "unit": "TFLOP/s", "frac": round(executed / us / 1e6 / peak, 4), "traffic": TOWER_WG_PMC_BYTES if conv == "tower_wg" and batch == 256 and C == 128 else None,
-            "traffic_source": "profiles/r02_tower_wg_pmc.md (2 x FETCH_SIZE + WRITE_SIZE per launch: every XCD's L2 streams the 21 MB of weights once)",
+            "traffic_source": "constant from the committed PMC pass profiles/r02_tower_wg_pmc.md (2 x FETCH_SIZE + WRITE_SIZE per launch: every XCD's L2 streams "
+                              "the 21 MB of weights once); valid for 256 boards x 128 filters only, null for any other shape -- counters cannot be read from inside the process",
             "avg_launch_us": round(us, 1), "launches_timed": n_timed, "timing": how, "back_to_back_us": round(b2b, 1),
             "boards_per_launch": batch, "conv_layers": n_conv,
             "algorithmic_direct_conv_tflops": round(algorithmic / us / 1e6, 1),
             "note": "fp32 v_mfma_f32_16x16x4_f32; one workgroup per board, activations LDS-resident for the whole tower"}
 
 
-def fast_select_roofline(ro, drv, plies):
-    """FAST mode: the select + backup kernel (csrc/bo_fastw.h: bo_k_fw_select) on the trees the searches of this run grew --
-    no synthetic topology.  `plies` more plies are played eagerly (same engine, same games, no graph) with HIP events around
-    every launch of that kernel on its stream; algorithmic bytes from the engine's own counters over the same launches
-    (12 B per child scanned + 8 B per level; backup + virtual loss 16 B per path node)."""
+def _fast_counters(eng):
+    st, fs = eng.status(), eng.fast_stats()
+    return dict(levels=int(st["levels"].astype(np.int64).sum()), kids=int(st["children_scanned"].astype(np.int64).sum()),
+                gran=int(fs["granules_read"].sum()), pnodes=int(fs["path_nodes"].sum()), arena=int(fs["arena_granules"].astype(np.int64).sum()))
+
+
+def fast_select_measure(ro, drv, plies):
+    """`plies` more plies played eagerly (same engine, same games, no graph) with HIP events around every launch of the select +
+    backup kernel on its stream; bytes from the engine's own counters over the same launches."""
     eng = ro.eng
-    st0, fs0 = eng.status(), eng.fast_stats(time_select=1)
+    c0 = _fast_counters(eng)
+    eng.fast_stats(time_select=1)
     graph = ro.use_graph
     ro.use_graph = False
     for _ in range(plies):
         drv.step()
     torch.cuda.synchronize(ro.device)
     ro.use_graph = graph
-    st1, fs1 = eng.status(), eng.fast_stats(time_select=0)
+    fs1 = eng.fast_stats(time_select=0)
+    c1 = _fast_counters(eng)
     launches = int(fs1["select_launches"])
     if launches == 0:
         return None
-    levels = int(st1["levels"].astype(np.int64).sum() - st0["levels"].astype(np.int64).sum())
-    kids = int(st1["children_scanned"].astype(np.int64).sum() - st0["children_scanned"].astype(np.int64).sum())
-    blocks = int(fs1["blocks_read"].sum() - fs0["blocks_read"].sum())
-    pnodes = int(fs1["path_nodes"].sum() - fs0["path_nodes"].sum())
-    alg = 12 * kids + 8 * levels + 16 * pnodes
-    moved = 512 * blocks + 16 * pnodes
+    d = {k: c1[k] - c0[k] for k in ("levels", "kids", "gran", "pnodes")}
+    alg = 12 * d["kids"] + 8 * d["levels"] + 16 * d["pnodes"]       # SURVEY.md section 8d
+    moved = eng.GRANULE_BYTES * d["gran"] + 16 * d["pnodes"]           # what the kernel requests: whole record granules + the backup's (n, w) pairs
     t = fs1["select_ms"] * 1e-3 / launches
-    ach = alg / launches / t / 1e9
+    return dict(launches=launches, t=t, alg=alg / launches, moved=moved / launches, levels=d["levels"] / launches,
+                kids=d["kids"] / launches, pnodes=d["pnodes"] / launches, arena_bytes=c1["arena"] * eng.GRANULE_BYTES)
+
+
+def fast_select_roofline(ro, drv, plies, label=""):
+    """FAST mode: the select + backup kernel (csrc/bo_fastw.h: bo_k_fw_select) on the trees the searches of this run grew --
+    no synthetic topology; virtual loss and backup included (SURVEY.md section 8d: 12 B per child scanned + 8 B per level;
+    backup 16 B per path node)."""
+    m = fast_select_measure(ro, drv, plies)
+    if m is None:
+        return None
+    ach = m["alg"] / m["t"] / 1e9
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "traffic": None, "kernel": "bo_k_fw_select",
-            "workload": f"the search trees of this run ({ro.G} games x {ro.L} descents per launch with virtual loss, backup of the previous "
-                        f"launch's simulations in the same kernel; child-block arenas, {int(fs1['arena_blocks'].sum()) * 512 / 1e6:.1f} MB live); "
-                        f"bytes = 12 B x children scanned + 8 B x levels + 16 B x path nodes; the kernel moves 512 B per child block read",
-            "launches_timed": launches, "avg_launch_us": round(t * 1e6, 2), "alg_bytes_per_launch": alg // launches,
-            "moved_bytes_per_launch": moved // launches, "levels_per_launch": levels // launches,
-            "note": "latency-bound at this many trees: a descent is a chain of dependent reads, bandwidth scales with the games in flight "
-                    "(see roofline_wide_synthetic for the same select arithmetic on 262144 trees)"}
+            "traffic": None, "kernel": "bo_k_fw_select" + label,
+            "workload": f"the search trees of this run ({ro.G} games x {ro.L} descents per launch under a virtual loss, backup of the previous "
+                        f"launch's simulations in the same kernel; arenas of 128-byte granules, {m['arena_bytes'] / 1e9:.2f} GB live); "
+                        f"bytes = 12 B x children scanned + 8 B x levels + 16 B x path nodes; the kernel requests whole 128-byte record granules",
+            "launches_timed": m["launches"], "avg_launch_us": round(m["t"] * 1e6, 2), "alg_bytes_per_launch": int(m["alg"]),
+            "moved_bytes_per_launch": int(m["moved"]), "moved_over_algorithmic": round(m["moved"] / m["alg"], 3),
+            "levels_per_launch": int(m["levels"]), "children_per_level": round(m["kids"] / max(1.0, m["levels"]), 2),
+            "levels_per_descent": round(m["levels"] / max(1.0, m["pnodes"] - m["levels"]), 2),
+            "moved_GBps": round(m["moved"] / m["t"] / 1e9, 1)}
+
+
+def fast_select_sweep(ro, drv):
+    """Every variant of the select + backup kernel over one more ply each of this run's trees (they keep growing meanwhile)."""
+    out = []
+    for ut in (4, 2):
+        for fl in range(8):
+            ro.eng.fast_options(games_per_halfwave=ut, select_flags=fl)
+            r = fast_select_roofline(ro, drv, 1, f" u{ut} flags{fl}")
+            if r:
+                out.append({k: r[k] for k in ("kernel", "frac", "achieved", "avg_launch_us", "moved_GBps", "moved_over_algorithmic", "launches_timed",
+                                              "levels_per_descent", "children_per_level")})
+                print("[sweep]", json.dumps(out[-1]), file=sys.stderr, flush=True)
+    return out
 
 
 def step_roofline(ro, n_steps_timed):
@@ -431,6 +487,8 @@ def main():
     ro = Rollout(net, G, num_simulations=args.sims, mcts_batch_size=args.batch, device=str(device), use_graph=not args.no_graph,
                  rng_mode="native", max_game_moves=args.max_game_moves, fast=args.fast, leaves_per_step=args.leaves,
                  policy_kind="probs" if args.softmax == "torch" else "logits")
+    if args.fast and (args.select_games_per_halfwave is not None or args.select_flags is not None):
+        ro.eng.fast_options(games_per_halfwave=args.select_games_per_halfwave, select_flags=args.select_flags)
     exchange = records.PeriodicGameExchange(device, every=args.exchange_every) if dist is not None else None
     dump = [] if args.dump_games else None
     drv = Driver(ro, rank, world, exchange, dump)
@@ -501,9 +559,16 @@ def main():
         opening = {"nodes_per_sec": round((ro.n_sims - so) / do, 1), "ms_per_step": round(do / args.opening_steps * 1e3, 3),
                    "steps": args.opening_steps, "note": "all games within their first ~25 plies; not the headline"}
 
-    fast_roof = rn = None
+    fast_roof = rn = sweep = None
     if rank == 0 and args.fast and not args.no_roofline and dist is None:
-        fast_roof = fast_select_roofline(ro, drv, 2)
+        if args.select_sweep:
+            sweep = fast_select_sweep(ro, drv)
+            best = max(sweep, key=lambda r: r["frac"]) if sweep else None
+            if best:  # (kernel label = " u<games per half-wave> flags<n>")
+                ro.eng.fast_options(games_per_halfwave=int(best["kernel"].split(" u")[1][0]), select_flags=int(best["kernel"].split("flags")[1]))
+        fast_roof = fast_select_roofline(ro, drv, args.roofline_plies)
+        if fast_roof is not None and args.select_sweep:
+            fast_roof["variants"] = sweep
     if rank == 0 and not args.no_roofline and not args.fast and args.net_dtype == "fp32":
         rn = nn_roofline(net, G, device, ro if dist is None else None, drv)  # (more plies of this workload, after everything reported)
 
@@ -525,7 +590,7 @@ def main():
                                       f"exported and their slots refilled inside the timed region); " if args.preroll > 0 else "opening phase (all games start together); ")
                                    + cfg_name,
                        "games_per_gpu": G, "sims_per_move": args.sims, "net": args.net, "net_dtype": args.net_dtype,
-                       "hipgraph": not args.no_graph, "net_layout": net_layout, "policy_softmax": args.softmax, "preroll_plies": args.preroll,
+                       "hipgraph": not args.no_graph, "net_layout": net_layout, "policy_softmax": softmax_site(net, args, G * (args.leaves if args.fast else 1)), "evaluate_stage": getattr(getattr(net, "net", net), "route", net_layout), "hw_queues": betaone_amd.hw_queues(), "preroll_plies": args.preroll,
                        "search_mode": ("fast: virtual loss, %d leaves/step, full-width expansion (NOT the reference's semantics)" % args.leaves)
                                       if args.fast else "reference semantics (bit-exact)",
                        "parallelism": f"games sharded over {world} GPU(s) by id; record all-gather every {args.exchange_every} plies, pipelined" if world > 1
@@ -564,16 +629,19 @@ def main():
         # (~80 % of a ply, MFMA-bound).  Fast mode: its select + backup kernel on the trees this run grew (what SURVEY.md
         # section 8f asks to price).  The north star's select target on the section-8d synthetic wide workload
         # (bo_k_select_wide: the same child-block layout and arithmetic, 262144 static trees) is reported beside it.
-        wide = select_roofline(args, device)
         if fast_roof is not None:
             out["roofline"] = fast_roof
-        elif rn:
-            out["roofline"] = rn
         else:
-            out["roofline"] = wide
-        out["roofline_select_wide_synthetic"] = wide
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # "on rank 0 at N=1 only"
+            # LAB kernel, run by no search: PUCT select alone over static synthetic trees (SURVEY.md section 8d's workload); the
+            # product's select + backup kernel on grown trees is priced by `python bench.py --fast`
+            wide = select_roofline(args, device)
+            wide["kernel"] = "bo_k_select_wide (lab kernel: select only, static synthetic trees; no search runs it)"
+            out["roofline"] = rn if rn else wide
+            out["roofline_select_wide_synthetic"] = wide
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.fast:  # "on rank 0 at N=1 only"
         out["cpu_baseline"] = cpu_baseline(args)
+    elif rank == 0 and args.fast:
+        out["cpu_baseline"] = None  # the fast mode is not the reference's algorithm: nothing of the reference to time beside it
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -185,7 +185,7 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
         return fail(BO_E_ARG, "n_games/num_simulations/mcts_batch_size/max_plies out of range");
     const bool fast = cfg->mode == 1;
     if (cfg->mode != 0 && cfg->mode != 1) return fail(BO_E_ARG, "mode must be 0 (reference semantics) or 1 (fast)");
-    if (fast && (cfg->leaves_per_step < 1 || cfg->leaves_per_step > 256)) return fail(BO_E_ARG, "leaves_per_step out of range");
+    if (fast && (cfg->leaves_per_step < 1 || cfg->leaves_per_step > BO_FW_LMAX)) return fail(BO_E_ARG, "leaves_per_step out of range (1..64)");
     const int root_m = fast ? 1 : (int)(cfg->widen_coeff * sqrt(1.0));
     const int ch_max = fast ? 1 : (int)(cfg->widen_coeff * sqrt((double)cfg->mcts_batch_size));
     if (!fast && (cfg->widen_coeff < 1.0 || ch_max > BO_CH_CAP))
@@ -252,26 +252,25 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
         FastW &f = e->f;
         const size_t L = (size_t)cfg->leaves_per_step;
         f.L = (int)L;
-        // Arena capacity per game, in 512-byte child blocks.  A search creates at most S + L + 1 runs (one per expanded
-        // node; a run is 1..7 blocks, 2 on average in chess: ~35 legal moves) on top of the subtree kept from the previous
-        // search, which re-rooting admits only up to KEEP blocks: NB = KEEP + 4 blocks per possible expansion.  A run that
-        // still does not fit is refused (status bit) -- the search goes on with that leaf unexpanded.
+        f.sel_ut = 4; f.sel_flags = FW_SEL_ROOT_IN_REGS;
+        // Arena capacity per game, in granules of BO_FW_GR records.  A search creates at most S + L + 1 runs (one per expanded
+        // node: header + 1..32 record granules, ~6 granules = 768 bytes at chess's ~35 legal moves) on top of the subtree kept
+        // from the previous search: room for 24 granules (3 KB) per possible expansion of this and of the previous search.
+        // A run that still does not fit is refused (status bit) -- the search goes on with that leaf unexpanded.
         const size_t expansions = (size_t)c.S + L + 2;
-        f.NB = (int)(2 * expansions + 4 * expansions + 8);
-        const size_t NB = (size_t)f.NB;
-        for (int a = 0; a < 2; a++) {
-            rc |= e->alloc(&f.arena[a], G * NB * BO_FW_C); rc |= e->alloc(&f.amove[a], G * NB * BO_FW_C); rc |= e->alloc(&f.bpos[a], G * NB);
-        }
+        f.NG = (int)((6 * expansions + 8) * (32 / BO_FW_GR));
+        const size_t NR = (size_t)f.NG * BO_FW_GR;
+        rc |= e->alloc(&f.arena, G * 2 * NR); rc |= e->alloc(&f.amove, G * 2 * NR);
         rc |= e->alloc(&f.cur, G); rc |= e->alloc(&f.top, G); rc |= e->alloc(&f.n_rows, G); rc |= e->alloc(&f.n_step, G);
-        rc |= e->alloc(&f.played_now, G); rc |= e->alloc(&f.stat_blocks, G); rc |= e->alloc(&f.stat_path_nodes, G);
-        rc |= e->alloc(&f.row_slot, G * L); rc |= e->alloc(&f.row_prun, G * L); rc |= e->alloc(&f.row_nlegal, G * L);
+        rc |= e->alloc(&f.played_now, G); rc |= e->alloc(&f.stat_gran, G); rc |= e->alloc(&f.stat_path_nodes, G);
+        rc |= e->alloc(&f.row_slot, G * L); rc |= e->alloc(&f.row_plink, G * L); rc |= e->alloc(&f.row_nlegal, G * L);
         rc |= e->alloc(&f.row_term, G * L); rc |= e->alloc(&f.row_sim, G * L); rc |= e->alloc(&f.row_pos, G * L);
         rc |= e->alloc(&f.row_moves, G * L * BO_MAX_MOVES);
         rc |= e->alloc(&f.sim_row, G * L); rc |= e->alloc(&f.sim_plen, G * L); rc |= e->alloc(&f.sim_path, G * L * BO_FW_PATH_CAP);
         if (!rc) {
             int *zero[] = {f.cur, f.top, f.n_rows, f.n_step, f.played_now};
             for (int *p : zero) rt_memset(p, 0, G * 4, nullptr);
-            rt_memset(f.stat_blocks, 0, G * 8, nullptr); rt_memset(f.stat_path_nodes, 0, G * 8, nullptr);
+            rt_memset(f.stat_gran, 0, G * 8, nullptr); rt_memset(f.stat_path_nodes, 0, G * 8, nullptr);
             rt_memset(f.row_term, 0, G * L * 4, nullptr); rt_memset(f.row_nlegal, 0, G * L * 4, nullptr);
             d.played_now = f.played_now;
         }
@@ -455,11 +454,35 @@ extern "C" int bo_search_begin(bo_engine *e, const int32_t *go, const double *no
     return search_begin_impl(e, go, noise, false, nn_in_dev, stream);
 }
 
+// bo_k_fw_select comes in one instantiation per (games per half-wave, leaves-per-step capacity, FW_SEL_* flags)
+static int launch_fw_select(bo_engine *e, const float *value_dev, int kind, void *stream) {
+    const FastW &f = e->f;
+    const int G = e->d.c.G, L = f.L;
+    const int ut = L > 16 ? 1 : (L > 8 && f.sel_ut > 2) ? 2 : L > 4 ? (L > 8 ? 2 : 4) : f.sel_ut;
+    const int grid = (G + 2 * ut - 1) / (2 * ut);
+#define SEL(K) return RT_LAUNCH(K, grid, stream, e->d, e->f, value_dev, kind)
+    const bool fancy = (f.sel_flags & FW_SEL_ROOT_IN_REGS) != 0;  // (L > 4: plain, or non-temporal + root in registers)
+    if (L > 16) { if (fancy) SEL(bo_k_fw_select_u1l64_3); SEL(bo_k_fw_select_u1l64_0); }
+    if (L > 8) { if (fancy) SEL(bo_k_fw_select_u2l16_3); SEL(bo_k_fw_select_u2l16_0); }
+    if (L > 4) { if (fancy) SEL(bo_k_fw_select_u4l8_3); SEL(bo_k_fw_select_u4l8_0); }
+#define SEL8(UT)                                                                                  \
+    switch (f.sel_flags & 7) {                                                                     \
+        case 0: SEL(bo_k_fw_select_u##UT##l4_0); case 1: SEL(bo_k_fw_select_u##UT##l4_1);         \
+        case 2: SEL(bo_k_fw_select_u##UT##l4_2); case 3: SEL(bo_k_fw_select_u##UT##l4_3);         \
+        case 4: SEL(bo_k_fw_select_u##UT##l4_4); case 5: SEL(bo_k_fw_select_u##UT##l4_5);         \
+        case 6: SEL(bo_k_fw_select_u##UT##l4_6); default: SEL(bo_k_fw_select_u##UT##l4_7);        \
+    }
+    if (ut >= 4) { SEL8(4) }
+    SEL8(2)
+#undef SEL8
+#undef SEL
+}
+
 extern "C" int bo_step(bo_engine *e, const float *policy_dev, const float *value_dev, int policy_kind, float *nn_in_dev,
                        void *stream) {
     if (!e || !nn_in_dev) return fail(BO_E_ARG, "null argument");
     if (policy_kind != BO_POLICY_NONE && (!policy_dev || !value_dev)) return fail(BO_E_ARG, "policy/value required");
-    if (e->fast) {  // apply (one wave per row) -> backup + select (one wave per game) -> leaf positions and planes (one wave per row)
+    if (e->fast) {  // apply (one wave per row) -> backup + select (half a wave per game) -> leaf positions and planes (one wave per row)
         const int rows = e->d.c.G * e->f.L;
         if (policy_kind != BO_POLICY_NONE) RT(RT_LAUNCH(bo_k_fw_apply, rows, stream, e->d, e->f, policy_dev, policy_kind));
 #if !defined(BO_WAVE_EMU)
@@ -474,7 +497,7 @@ extern "C" int bo_step(bo_engine *e, const float *policy_dev, const float *value
             RT((int)hipEventRecord(e->sel_ev0, (hipStream_t)stream));
         }
 #endif
-        RT(RT_LAUNCH(bo_k_fw_select, e->d.c.G, stream, e->d, e->f, value_dev, policy_kind));
+        RT(launch_fw_select(e, value_dev, policy_kind, stream));
 #if !defined(BO_WAVE_EMU)
         if (e->sel_profile) { RT((int)hipEventRecord(e->sel_ev1, (hipStream_t)stream)); e->sel_pending = 1; }
 #endif
@@ -879,10 +902,11 @@ extern "C" int bo_debug_tree(bo_engine *e, int slot, bo_node *out, int32_t cap, 
         int cur = 0, top = 0;
         RT(rt_d2h(&cur, f.cur + slot, 4, stream)); RT(rt_d2h(&top, f.top + slot, 4, stream));
         RT(rt_sync(stream));
-        std::vector<WRec> A((size_t)top * BO_FW_C);
-        std::vector<bo_mv> M((size_t)top * BO_FW_C);
-        RT(rt_d2h(A.data(), f.arena[cur] + (size_t)slot * f.NB * BO_FW_C, A.size() * sizeof(WRec), stream));
-        RT(rt_d2h(M.data(), f.amove[cur] + (size_t)slot * f.NB * BO_FW_C, M.size() * sizeof(bo_mv), stream));
+        std::vector<WRec> A((size_t)top * BO_FW_GR);
+        std::vector<bo_mv> M((size_t)top * BO_FW_GR);
+        const size_t aoff = ((size_t)slot * 2 + (size_t)cur) * (size_t)f.NG * BO_FW_GR;
+        RT(rt_d2h(A.data(), f.arena + aoff, A.size() * sizeof(WRec), stream));
+        RT(rt_d2h(M.data(), f.amove + aoff, M.size() * sizeof(bo_mv), stream));
         RT(rt_sync(stream));
         std::vector<bo_node> nodes;
         std::vector<int> rec;  // record id of each node
@@ -897,11 +921,11 @@ extern "C" int bo_debug_tree(bo_engine *e, int slot, bo_node *out, int32_t cap, 
         for (size_t i = 0; i < nodes.size(); i++) {
             const int link = A[rec[i]].link;
             if (link < 0) continue;
-            const int first = link & BO_FW_LINK_MASK, nb = ((link >> 24) & 7) + 1;
-            if ((size_t)(first + nb) * BO_FW_C > A.size()) return fail(BO_E_HIP, "corrupt child-block link");
+            const int first = link & BO_FW_LINK_MASK, ng = ((link >> 24) & 127) + 1;
+            if (first < 1 + BO_FW_HG || (size_t)(first + ng) * BO_FW_GR > A.size()) return fail(BO_E_HIP, "corrupt child-run link");
             nodes[i].first_child = (int)nodes.size();
-            for (int k = 0; k < nb * BO_FW_C; k++)
-                if (A[(size_t)first * BO_FW_C + k].n >= 0) { push(first * BO_FW_C + k, (int)i); nodes[i].n_children++; }
+            for (int k = 0; k < ng * BO_FW_GR; k++)
+                if (A[(size_t)first * BO_FW_GR + k].n >= 0) { push(first * BO_FW_GR + k, (int)i); nodes[i].n_children++; }
         }
         *n_nodes = (int)nodes.size();
         if (!out) return BO_OK;
@@ -929,21 +953,25 @@ extern "C" int bo_debug_tree(bo_engine *e, int slot, bo_node *out, int32_t cap, 
     return BO_OK;
 }
 
-extern "C" int bo_fast_options(bo_engine *e, int32_t tree_reuse) {
+extern "C" int bo_fast_options(bo_engine *e, int32_t tree_reuse, int32_t games_per_halfwave, int32_t select_flags) {
     if (!e) return fail(BO_E_ARG, "null engine");
     if (!e->fast) return fail(BO_E_CONFIG, "bo_fast_options: fast-mode engines only");
-    e->fast_reuse = tree_reuse ? 1 : 0;
+    if (games_per_halfwave >= 0 && games_per_halfwave != 1 && games_per_halfwave != 2 && games_per_halfwave != 4)
+        return fail(BO_E_ARG, "bo_fast_options: games_per_halfwave must be 1, 2 or 4");
+    if (tree_reuse >= 0) e->fast_reuse = tree_reuse ? 1 : 0;
+    if (games_per_halfwave >= 0) e->f.sel_ut = games_per_halfwave == 1 ? 2 : games_per_halfwave;  // (one game per half-wave is the form for more than 16 leaves per step)
+    if (select_flags >= 0) e->f.sel_flags = select_flags & (FW_SEL_NT | FW_SEL_ROOT_IN_REGS | FW_SEL_DENSE);
     return BO_OK;
 }
 
-extern "C" int bo_fast_stats(bo_engine *e, uint64_t *blocks_read, uint64_t *path_nodes, int32_t *arena_blocks, int32_t time_select, double *select_ms,
+extern "C" int bo_fast_stats(bo_engine *e, uint64_t *granules_read, uint64_t *path_nodes, int32_t *arena_granules, int32_t time_select, double *select_ms,
                              int64_t *select_launches, void *stream) {
     if (!e) return fail(BO_E_ARG, "null engine");
     if (!e->fast) return fail(BO_E_CONFIG, "bo_fast_stats: fast-mode engines only");
     const size_t G = (size_t)e->d.c.G;
-    if (blocks_read) RT(rt_d2h(blocks_read, e->f.stat_blocks, G * 8, stream));
+    if (granules_read) RT(rt_d2h(granules_read, e->f.stat_gran, G * 8, stream));
     if (path_nodes) RT(rt_d2h(path_nodes, e->f.stat_path_nodes, G * 8, stream));
-    if (arena_blocks) RT(rt_d2h(arena_blocks, e->f.top, G * 4, stream));
+    if (arena_granules) RT(rt_d2h(arena_granules, e->f.top, G * 4, stream));
     RT(rt_sync(stream));
 #if !defined(BO_WAVE_EMU)
     if (e->sel_pending) {

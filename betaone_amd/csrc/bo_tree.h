@@ -155,9 +155,9 @@ struct ChainBuf {
     unsigned long long hash[BO_CHAIN_CAP];
     int ref[BO_CHAIN_CAP];  // node index (>= 0) or -1 - ply of the game history
 };
-// ref >= 0: index into the caller's array of tree positions; ref < 0: ply -1 - ref of the game's position stack
-BO_DEV DPos chain_entry(const Eng &e, int g, const DPos *tree_pos, int ref) {
-    return ref >= 0 ? tree_pos[ref] : e.gpos[(size_t)g * e.c.PLY_CAP + (-1 - ref)];
+// ref >= 0: a tree position, fetched by the caller's pos_of(ref); ref < 0: ply -1 - ref of the game's position stack
+template <class PosFn> BO_DEV DPos chain_entry(const Eng &e, int g, PosFn pos_of, int ref) {
+    return ref >= 0 ? pos_of(ref) : e.gpos[(size_t)g * e.c.PLY_CAP + (-1 - ref)];
 }
 // the game-history part of a chain (entries ply-1 .. J, J = last irreversible ply): found and read by all lanes at once
 BO_DEV int chain_collect_history(const Eng &e, int g, ChainBuf &cb, int cnt) {
@@ -213,9 +213,9 @@ BO_DEV int chain_collect(const Eng &e, int g, const int *path, int d, ChainBuf &
 
 // Board.outcome(claim_draw=True) of a position P whose legal moves are mv[0..n): 0 ongoing, 1 mate, 2 draw.  `collect()`
 // fills cb with the positions python-chess would revisit (the chain back to the last irreversible move) and returns their
-// number; it is only called when the cheap rules have not decided; tree_pos = base of the refs >= 0 it stores.
-template <class CollectFn>
-BO_DEV int terminal_eval_with(const Eng &e, int g, const DPos *tree_pos, const DPos &P, const bo_mv *mv, int n, bool in_check, bo_mv *scratch,
+// number; it is only called when the cheap rules have not decided; tree_pos(ref) = the position behind a ref >= 0 it stores.
+template <class PosFn, class CollectFn>
+BO_DEV int terminal_eval_with(const Eng &e, int g, PosFn tree_pos, const DPos &P, const bo_mv *mv, int n, bool in_check, bo_mv *scratch,
                               ChainBuf &cb, CollectFn collect) {
     if (n == 0 && in_check) return 1;
     if (insufficient_material(P)) return 2;
@@ -262,7 +262,8 @@ BO_DEV int terminal_eval_with(const Eng &e, int g, const DPos *tree_pos, const D
 // the same for the leaf path[d] of the reference-semantics tree
 BO_DEV int terminal_eval(const Eng &e, int g, const int *path, int d, const DPos &P, const bo_mv *mv, int n, bool in_check, bo_mv *scratch,
                          ChainBuf &cb) {
-    return terminal_eval_with(e, g, e.npos + NOFF(e, g), P, mv, n, in_check, scratch, cb, [&]() { return chain_collect(e, g, path, d, cb); });
+    const DPos *np = e.npos + NOFF(e, g);
+    return terminal_eval_with(e, g, [np](int ref) { return np[ref]; }, P, mv, n, in_check, scratch, cb, [&]() { return chain_collect(e, g, path, d, cb); });
 }
 
 // tracker.repetitions(board) = max(0, count - 1)   (utils.py:91-99)

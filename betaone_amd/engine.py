@@ -85,7 +85,7 @@ _SYMBOLS = {
     "bo_selfplay_begin": (C.c_int, [C.c_void_p, _I32P, C.c_void_p, _I32P, _I32P, _I32P, C.c_void_p]),
     "bo_records_encode": (C.c_int, [C.c_int, C.POINTER(BoPosition), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bo_debug_tree": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BoNode), C.c_int32, _I32P, C.c_void_p]),
-    "bo_fast_options": (C.c_int, [C.c_void_p, C.c_int32]),
+    "bo_fast_options": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "bo_fast_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _I32P, C.c_int32, _F64P, C.POINTER(C.c_int64),
                                C.c_void_p]),
     "bo_engine_status": (C.c_int, [C.c_void_p, _I32P, _I32P, _I32P, _I32P, _I32P, _I32P, C.c_void_p]),
@@ -391,18 +391,25 @@ class Engine:
         self._check(self.lib.bo_engine_status(self.h, *[_p(out[k]) for k in names], stream))
         return out
 
-    def fast_options(self, tree_reuse: bool = True):
-        self._check(self.lib.bo_fast_options(self.h, 1 if tree_reuse else 0))
+    def fast_options(self, tree_reuse=None, games_per_halfwave=None, select_flags=None):
+        """FAST mode knobs (None = unchanged): tree reuse between moves; games the select + backup kernel interleaves per
+        half-wavefront (2 or 4); select_flags = SEL_NT | SEL_ROOT_IN_REGS | SEL_DENSE (include/betaone_engine.h)."""
+        self._check(self.lib.bo_fast_options(self.h, -1 if tree_reuse is None else (1 if tree_reuse else 0),
+                                             -1 if games_per_halfwave is None else int(games_per_halfwave),
+                                             -1 if select_flags is None else int(select_flags)))
+
+    SEL_NT, SEL_ROOT_IN_REGS, SEL_DENSE = 1, 2, 4
+    GRANULE_BYTES = 128  # BO_FAST_GRANULE_BYTES
 
     def fast_stats(self, stream: int = 0, time_select: int = -1) -> Dict[str, np.ndarray]:
-        """blocks_read / arena_blocks per game; select_ms / select_launches of the timed select + backup kernel since
-        time_select=1 (eager steps only); time_select: 1 on, 0 off, -1 unchanged."""
-        blocks, pnodes, top = np.zeros(self.G, np.uint64), np.zeros(self.G, np.uint64), np.zeros(self.G, np.int32)
+        """granules_read / arena_granules per game (x GRANULE_BYTES = bytes); select_ms / select_launches of the timed select +
+        backup kernel since time_select=1 (eager steps only); time_select: 1 on, 0 off, -1 unchanged."""
+        gran, pnodes, top = np.zeros(self.G, np.uint64), np.zeros(self.G, np.uint64), np.zeros(self.G, np.int32)
         ms, n = C.c_double(0.0), C.c_int64(0)
         u64 = C.POINTER(C.c_uint64)
-        self._check(self.lib.bo_fast_stats(self.h, blocks.ctypes.data_as(u64), pnodes.ctypes.data_as(u64), _p(top), time_select,
+        self._check(self.lib.bo_fast_stats(self.h, gran.ctypes.data_as(u64), pnodes.ctypes.data_as(u64), _p(top), time_select,
                                            C.byref(ms), C.byref(n), stream))
-        return dict(blocks_read=blocks, path_nodes=pnodes, arena_blocks=top, select_ms=ms.value, select_launches=n.value)
+        return dict(granules_read=gran, path_nodes=pnodes, arena_granules=top, select_ms=ms.value, select_launches=n.value)
 
     def status_bits(self, stream: int = 0) -> np.ndarray:
         """Only the per-slot status words (one small copy): 0 = fine, else a combination of STATUS_BITS."""

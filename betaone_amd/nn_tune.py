@@ -1,10 +1,10 @@
 """
 betaone_amd/nn_tune.py -- pick the evaluate stage's memory layout for the batch it will actually see.
 
-The engine writes NN input rows as NCHW float32.  Under PyTorch-ROCm/MIOpen the residual tower is faster in
-plain NCHW at a few hundred positions per batch and faster in channels-last from about a thousand
-(measured on MI355X, net 8+2x128 fp32: 1.48 vs 2.29 ms at 256, 4.49 vs 4.41 ms at 1024), so the layout is
-chosen by timing both once on the real batch shape.
+The engine writes NN input rows as NCHW float32.  The evaluate stage is chosen by SHAPE (kernel_route): the hand-written gfx950
+kernels wherever they exist; the library path (PyTorch-ROCm / MIOpen: NCHW at a few hundred positions per batch, channels-last
+from about a thousand -- measured on MI355X, net 8+2x128 fp32: 1.48 vs 2.29 ms at 256, 4.49 vs 4.41 ms at 1024) only for shapes
+without one, and then with a warning.  The timing race of rounds 1-2 is kept behind BETAONE_NN_TUNE=1 as a debugging aid.
 """
 from __future__ import annotations
 
@@ -43,13 +43,68 @@ def _time_forward(net, x, reps: int = 8) -> float:
     return best
 
 
-def best_inference_copy(model, batch: int, device, dtype: torch.dtype = torch.float32, verbose: bool = False):
-    """BN-folded inference copy of a PolicyValueNet in whichever layout runs faster for `batch` rows."""
+def kernel_route(filters: int, batch: int, dtype: torch.dtype):
+    """Which hand-written evaluate stage (betaone_amd/fused_net.py `conv=`) a net of this shape runs on -- decided by shape, not by a
+    timing race -- or None where none exists (the net then stays under PyTorch-ROCm's library kernels, and says so):
+      float32, 64 / 128 filters: batch <= 16 -> 'mfma_small' (a board's layer cut into c_out/16 x 4 workgroups), else 'tower_wg'
+                                 (the LDS-resident Winograd tower, one board per workgroup);
+      float32, 256 filters:      batch <= 16 -> 'mfma_small', else 'mfma' (per-layer implicit GEMM, csrc/bo_conv.h);
+      float16, 128 / 256 filters: 'tower_f16' (csrc/bo_tower_h.h, two boards per workgroup)."""
+    if dtype == torch.float32:
+        if filters in (64, 128):
+            return "mfma_small" if batch <= 16 else "tower_wg"
+        if filters == 256:
+            return "mfma_small" if batch <= 16 else "mfma"
+    if dtype == torch.float16 and filters in (128, 256):
+        return "tower_f16"
+    return None
+
+
+def best_inference_copy(model, batch: int, device, dtype: torch.dtype = torch.float32, verbose: bool = False, tune=None):
+    """BN-folded inference copy of a PolicyValueNet for `batch` rows: the hand-written kernels chosen by kernel_route(); where
+    there are none (other filter counts, bfloat16) the PyTorch-ROCm copy in NCHW up to 512 rows and channels-last beyond, with
+    a warning naming the library path.  tune=True (or BETAONE_NN_TUNE=1) runs the start-up timing race of rounds 1-2 instead
+    (a debugging aid: it can keep MIOpen where that measures faster)."""
+    import os
+    import warnings
+
     device = torch.device(device)
     if not hasattr(model, "for_inference"):
         return model
     if device.type != "cuda":
         return model.for_inference(dtype=dtype, channels_last=False)
+    if tune is None:
+        tune = os.environ.get("BETAONE_NN_TUNE", "0") not in ("", "0")
+    if tune:
+        return timed_inference_copy(model, batch, device, dtype, verbose)
+    from . import engine as E
+    from .fused_net import FusedPolicyValueNet
+
+    filters = model.conv_input.out_channels
+    route = kernel_route(filters, batch, dtype)
+    if route is not None:
+        try:
+            net = FusedPolicyValueNet(model.to(device), conv=route).to(device)
+            net.route = route
+            if verbose:
+                print(f"[nn_route] batch={batch} filters={filters} {dtype}: hand-written evaluate stage conv='{route}'")
+            return net
+        except E.EngineError as ex:  # (e.g. an SE block wider than the tower kernels take)
+            why = str(ex)
+    else:
+        why = f"no hand-written evaluate stage for {filters} filters in {dtype}"
+    cl = batch > 512
+    net = model.to(device).for_inference(dtype=dtype, channels_last=cl)
+    net.layout = "channels_last" if cl else "nchw"
+    net.route = "pytorch-rocm library kernels"
+    warnings.warn(f"betaone_amd: the evaluate stage of this net runs on PyTorch-ROCm library kernels (MIOpen / hipBLASLt), {net.layout}: {why}",
+                  RuntimeWarning, stacklevel=2)
+    return net
+
+
+def timed_inference_copy(model, batch: int, device, dtype: torch.dtype = torch.float32, verbose: bool = False):
+    """The start-up timing race (debugging aid): every candidate layout / kernel set is timed on the real batch shape."""
+    device = torch.device(device)
     x = torch.zeros((batch, 120, 8, 8), dtype=dtype, device=device)
     best, best_t, best_cl = None, None, None
     for cl in (False, True):

@@ -63,10 +63,10 @@ typedef struct {
     double widen_coeff;         /* config.WIDEN_COEFF (>= 1.0, int(w*sqrt(batch)) <= 32) */
     double dirichlet_alpha;     /* config.DIRICHLET_ALPHA (only its sign is used on the device) */
     double dirichlet_epsilon;   /* config.DIRICHLET_EPSILON */
-    int32_t mode;               /* 0 = the reference's search semantics (bit-exact); 1 = FAST mode (csrc/bo_fast.h):
+    int32_t mode;               /* 0 = the reference's search semantics (bit-exact); 1 = FAST mode (csrc/bo_fastw.h):
                                  * virtual loss, leaves_per_step distinct leaves per game per step, full-width
                                  * expansion -- NOT the reference's semantics */
-    int32_t leaves_per_step;    /* FAST mode: L; NN tensors then have n_games*L rows, row = g*L + r */
+    int32_t leaves_per_step;    /* FAST mode: L (1..64); NN tensors then have n_games*L rows, row = g*L + r */
 } bo_config;
 
 /* A position as plain data.  bb: pawns, knights, bishops, rooks, queens, kings, white, black. */
@@ -206,13 +206,18 @@ typedef struct {
     int32_t terminal;  /* -1 never visited as leaf, 0 no, 1 mate, 2 draw */
 } bo_node;
 int bo_debug_tree(bo_engine *e, int slot, bo_node *out, int32_t cap, int32_t *n_nodes, void *stream);
-/* FAST mode (cfg.mode = 1; NOT the reference's semantics): tree_reuse != 0 (default) keeps the
- * played child's subtree as the next search's tree -- the reference rebuilds the tree every move (mcts.py:176). */
-int bo_fast_options(bo_engine *e, int32_t tree_reuse);
-/* FAST mode, per game [G]: 512-byte child blocks read by PUCT descents so far (x 512 = bytes the select path moved), path
- * nodes written by virtual loss + backup (x 16 B; with 12 B x children_scanned + 8 B x levels of bo_engine_status these are
- * the algorithmic bytes of SURVEY.md section 8d), blocks in use in the game's arena. */
-int bo_fast_stats(bo_engine *e, uint64_t *blocks_read, uint64_t *path_nodes, int32_t *arena_blocks, int32_t time_select, double *select_ms,
+/* FAST mode (cfg.mode = 1; NOT the reference's semantics).  Every argument: -1 leaves the
+ * setting as it is.  tree_reuse != 0 (default) keeps the played child's subtree as the next search's tree -- the reference
+ * rebuilds the tree every move (mcts.py:176).  games_per_halfwave (2 or 4, default 4): games the select + backup kernel
+ * interleaves per half-wavefront (leaves_per_step > 8 caps it at 2, > 16 at 1).  select_flags: bit 0 non-temporal loads of
+ * the child runs below the root, bit 1 (default) the root's run stays in registers for all descents of a step, bit 2 the
+ * kernel is built for one more wavefront per SIMD (more runs in flight per CU at the price of register spills). */
+int bo_fast_options(bo_engine *e, int32_t tree_reuse, int32_t games_per_halfwave, int32_t select_flags);
+#define BO_FAST_GRANULE_BYTES 128    /* a fast-mode arena is allocated in granules of 8 16-byte records */
+/* FAST mode, per game [G]: record granules requested by PUCT descents so far (x BO_FAST_GRANULE_BYTES = bytes the select
+ * path moved), path nodes updated by the backup (x 16 B; with 12 B x children_scanned + 8 B x levels of bo_engine_status
+ * these are the algorithmic bytes of SURVEY.md section 8d), granules in use in the game's arena. */
+int bo_fast_stats(bo_engine *e, uint64_t *granules_read, uint64_t *path_nodes, int32_t *arena_granules, int32_t time_select, double *select_ms,
                   int64_t *select_launches, void *stream);
 /* time_select: 1 / 0 switches timing of the select + backup kernel (bo_k_fw_select) with HIP events on its launch stream
  * on / off for the following EAGER bo_step calls (not while the stream is being captured), -1 leaves it as it is;

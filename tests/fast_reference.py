@@ -28,11 +28,12 @@ def wave_sum(vals):
 
 
 class Node:
-    __slots__ = ("n", "w", "prior", "move", "state", "children", "row")
+    __slots__ = ("n", "w", "prior", "move", "state", "children", "row", "fl")
 
     def __init__(self, prior, move):
         self.n, self.w, self.prior, self.move = 0, F(0.0), F(prior), move
         self.state, self.children, self.row = UNVISITED, [], -1
+        self.fl = 0  # descents of the step in flight through the node
 
 
 class FastSearcher:
@@ -76,10 +77,14 @@ class FastSearcher:
     @staticmethod
     def _backup(path, v):
         plen = len(path)
+        path[0].n += 1
+        path[0].fl = 0
         for k in range(1, plen):
             nd = path[k]
             s = F(-v) if ((plen - 1 - k) & 1) else F(v)
-            nd.w = F(F(nd.w + F(1.0)) + s)
+            nd.n += 1
+            nd.w = F(nd.w + s)
+            nd.fl = 0
 
     # -- one search -------------------------------------------------------------------------------------------------------
     def search(self, noise):
@@ -97,39 +102,38 @@ class FastSearcher:
             for j, ch in enumerate(root.children):
                 ch.prior = F(np.float64(F(self.keep * ch.prior)) + self.eps * noise[j])
         while done < self.sims:
-            rows, sims_l = [], []  # rows: leaf nodes + their path moves; sims_l: (path, row or -1)
+            rows, sims_l = [], []  # rows: leaf nodes + their path moves; sims_l: (path, row | "mate" | "draw")
             while len(sims_l) < self.L and done + len(sims_l) < self.sims:
-                root.n += 1
+                root.fl += 1
                 path, cur = [root], root
                 while cur.state == EXPANDED and len(path) < PATH_CAP:
-                    sq = np.sqrt(F(cur.n))
+                    sq = np.sqrt(F(cur.n + cur.fl))  # visits of the node being expanded, this simulation included
                     best, bi = -np.inf, None
                     for ch in cur.children:
+                        ne = ch.n + ch.fl
+                        we = F(ch.w - F(ch.fl))
                         t2 = F(F(self.cp * ch.prior) * sq)
-                        u = F(t2 / F(1 + ch.n))
-                        qv = F(ch.w / F(ch.n)) if ch.n > 0 else F(0.0)
+                        u = F(t2 / F(1 + ne))
+                        qv = F(we / F(ne)) if ne > 0 else F(0.0)
                         sc = F(qv + u)
                         if sc > best:
                             best, bi = sc, ch
                     cur = bi
-                    cur.n += 1
-                    cur.w = F(cur.w - F(1.0))
+                    cur.fl += 1
                     path.append(cur)
                 assert cur.state != EXPANDED, "path cap not expected in tests"
-                if cur.state in (MATE, DRAW):  # known terminal: exact value now
-                    self._backup(path, F(1.0) if cur.state == MATE else F(0.0))
-                    self.n_term_sims += 1
-                    sims_l.append((path, -1))
+                if cur.state in (MATE, DRAW):  # known terminal: needs no row; backed up with the step's other simulations
+                    sims_l.append((path, cur.state))
                 elif cur.row >= 0:  # already selected in this step: shares the row
                     sims_l.append((path, cur.row))
                 else:
                     cur.row = len(rows)
                     rows.append((cur, [nd.move for nd in path[1:]]))
                     sims_l.append((path, cur.row))
+            info, vals = [], {}
             if rows:
                 info = [self._materialise(pm) for _leaf, pm in rows]
                 live = [i for i, (t, _m, _p) in enumerate(info) if t == 0]
-                vals = {}
                 if live:
                     probs, v = self.eval_fn(np.stack([info[i][2] for i in live]))
                     self.n_evals += len(live)
@@ -142,12 +146,15 @@ class FastSearcher:
                         leaf.state = MATE if t == 1 else DRAW
                     else:
                         self._expand(leaf, moves, vals[i][0], None)
-                for path, r in sims_l:
-                    if r >= 0:
-                        t = info[r][0]
-                        if t:
-                            self.n_term_sims += 1
-                        self._backup(path, (F(1.0) if t == 1 else F(0.0)) if t else F(-vals[r][1]))
+            for path, r in sims_l:
+                if r in (MATE, DRAW):
+                    self.n_term_sims += 1
+                    self._backup(path, F(1.0) if r == MATE else F(0.0))
+                else:
+                    t = info[r][0]
+                    if t:
+                        self.n_term_sims += 1
+                    self._backup(path, (F(1.0) if t == 1 else F(0.0)) if t else F(-vals[r][1]))
             done += len(sims_l)
 
     def visits(self):

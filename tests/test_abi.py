@@ -77,3 +77,15 @@ def test_tower_descriptors_are_validated_before_any_device_call():
     assert lib.bo_nn_conv3x3(1, 1, 1, None, 1, 4, 128, 128, 2, None) == -1    # residual epilogue without a residual
     assert lib.bo_nn_tower_forward(None, 1, 1, None, None, 4, None) == -1
     assert lib.bo_nn_value_tail(None, 1, 1, 1, 4, 8, None) == -1
+
+
+def test_evaluate_stage_route_is_a_shape_rule():
+    """nn_tune.kernel_route: which hand-written evaluate stage a (filters, batch, dtype) runs on; None = library path (warned)."""
+    import torch
+    from betaone_amd.nn_tune import kernel_route as R
+
+    assert R(128, 256, torch.float32) == "tower_wg" and R(64, 17, torch.float32) == "tower_wg" and R(128, 100000, torch.float32) == "tower_wg"
+    assert R(128, 1, torch.float32) == R(256, 16, torch.float32) == R(64, 8, torch.float32) == "mfma_small"
+    assert R(256, 17, torch.float32) == "mfma"
+    assert R(128, 4096, torch.float16) == R(256, 512, torch.float16) == R(256, 1, torch.float16) == "tower_f16"
+    assert R(64, 4096, torch.float16) is None and R(96, 32, torch.float32) is None and R(128, 256, torch.bfloat16) is None

@@ -422,9 +422,11 @@ def test_edge_cases_maximum_sizes_and_error_paths(backend):
     EC.check_edge_cases(backend)
 
 
-def test_nn_tune_prefers_the_hand_written_evaluate_stage(backend):
-    """At the batch sizes of BASELINE.json's configurations the evaluate stage that nn_tune keeps is one of the hand-written
-    MFMA kernels (a silent fallback to the library convolutions would halve the throughput and still pass parity)."""
+def test_evaluate_stage_is_routed_by_shape_to_the_hand_written_kernels(backend):
+    """The evaluate stage is chosen by shape rule (nn_tune.kernel_route), not by a start-up timing race: at BASELINE.json's shapes
+    AND at shapes in between it is one of the hand-written kernels (a silent fallback to the library convolutions would halve the
+    throughput and still pass parity); a shape without one keeps the PyTorch-ROCm path and says so; outputs agree with the plain net."""
+    import warnings
     import torch
     from betaone_amd import dropin
     dropin.install()
@@ -433,14 +435,31 @@ def test_nn_tune_prefers_the_hand_written_evaluate_stage(backend):
 
     saved = (config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS)
     try:
-        config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 8, 2, 128
-        torch.manual_seed(0)
-        net = network.PolicyValueNet().eval()
-        assert best_inference_copy(net, 256, "cuda:0").layout in ("nchw+tower_wg", "nchw+tower")
-        config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 3, 1, 256
-        big = network.PolicyValueNet().eval()
-        assert best_inference_copy(big, 1, "cuda:0").layout == "nchw+mfma_small"
-        assert best_inference_copy(big, 512, "cuda:0", torch.float16).layout == "nchw+tower_f16"
+        with warnings.catch_warnings():
+            warnings.filterwarnings("error", message=".*library kernels.*")  # no library-path warning for any routed shape
+            config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 8, 2, 128
+            torch.manual_seed(0)
+            net = network.PolicyValueNet().to("cuda:0").eval()
+            assert best_inference_copy(net, 256, "cuda:0").layout == "nchw+tower_wg"
+            for batch in (24, 100, 1000):  # not a BASELINE shape
+                routed = best_inference_copy(net, batch, "cuda:0")
+                assert routed.layout == "nchw+tower_wg", batch
+                x = torch.rand((batch, 120, 8, 8), device="cuda:0")
+                with torch.no_grad():
+                    (l0, v0), (l1, v1) = net(x), routed(x)
+                assert (l0 - l1).abs().max().item() < 1e-4 and (v0 - v1).abs().max().item() < 1e-4, batch
+            assert best_inference_copy(net, 3, "cuda:0").layout == "nchw+mfma_small"
+            assert best_inference_copy(net, 4096, "cuda:0", torch.float16).layout == "nchw+tower_f16"
+            config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 3, 1, 256
+            big = network.PolicyValueNet().to("cuda:0").eval()
+            assert best_inference_copy(big, 1, "cuda:0").layout == "nchw+mfma_small"
+            assert best_inference_copy(big, 64, "cuda:0").layout == "nchw+mfma"
+            assert best_inference_copy(big, 512, "cuda:0", torch.float16).layout == "nchw+tower_f16"
+        config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 2, 1, 96  # no hand-written kernels for 96 filters
+        odd = network.PolicyValueNet().to("cuda:0").eval()
+        with pytest.warns(RuntimeWarning, match="library kernels"):
+            kept = best_inference_copy(odd, 32, "cuda:0")
+        assert kept.route == "pytorch-rocm library kernels" and kept.layout == "nchw"
     finally:
         config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = saved
 

@@ -134,7 +134,7 @@ def test_fast_tree_reuse_between_moves_matches_restatement(reuse):
         assert after == ref.canonical(), ("after re-rooting", ply)   # the kept subtree, bit for bit (w, priors, states)
     assert (max(kept[1:]) > 1) == reuse                              # reuse really carried visits over
     fs = eng.fast_stats()
-    assert fs["blocks_read"][0] > 0 and 1 <= fs["arena_blocks"][0] < eng.cfg.num_simulations * 8
+    assert fs["granules_read"][0] > 0 and 1 <= fs["arena_granules"][0] < eng.cfg.num_simulations * 32
 
 
 def test_fast_mode_invariants_many_games():
@@ -202,3 +202,59 @@ def test_fast_rollout_refilled_slot_records_the_pis_of_its_own_game():
         assert len(got.pis) == len(solo.pis) == len(got.moves), gid
         for (i1, v1), (i2, v2) in zip(got.pis, solo.pis):
             assert i1.tolist() == i2.tolist() and v1.tolist() == v2.tolist(), gid
+
+
+MULTI = [
+    (O.STARTING_FEN, []),
+    (O.STARTING_FEN, "e2e4 e7e5 g1f3 b8c6 f1b5".split()),
+    ("k7/8/1K6/8/8/8/8/7R w - - 0 1", []),                               # mates in the tree: known-terminal simulations
+    (O.STARTING_FEN, "g1f3 g8f6 f3g1 f6g8 g1f3 g8f6".split()),           # claimable repetitions
+    ("R6R/3Q4/1Q4Q1/4Q3/2Q4Q/Q4Q2/pp1Q4/kBNN1KB1 w - - 0 1", []),         # 218 legal moves: a root run of 28 granules
+    ("8/8/4k3/8/8/3K4/8/6R1 w - - 97 80", []),                            # 50-move claims
+    ("r3k2r/p1ppqpb1/bn2pnp1/3PN3/1p2P3/2N2Q1p/PPPBBPPP/R3K2R w KQkq - 0 1", []),  # 48 legal moves: two records per lane
+]
+
+
+def run_multi(backend, L, sims, opts, seed=5):
+    """Every game slot holds a different position (the half-waves and the games interleaved per half-wave of bo_k_fw_select
+    then diverge in depth, run length and end of descent); returns engine + per-game noise."""
+    G = len(MULTI)
+    kw = dict(num_simulations=sims, dirichlet_alpha=0.1, fast=True, leaves_per_step=L, max_plies=256)
+    eng = emu_call(E.Engine, G, **kw) if backend == "emu" else E.Engine(G, **kw)
+    eng.fast_options(**opts)
+    eng.reset(list(range(G)), [m[0] for m in MULTI], [" ".join(m[1]) or None for m in MULTI])
+    nl, term, _ = eng.root_info()
+    noise = np.zeros((G, E.MAX_LEGAL))
+    for g in range(G):
+        noise[g, :nl[g]] = np.random.RandomState(seed + g).dirichlet([0.1] * int(nl[g]))
+    fn = softmax_eval(13)
+    drive_search(backend, eng, G, L, fn, noise)
+    return eng, noise, fn
+
+
+def check_multi(backend, L, sims, opts):
+    eng, noise, fn = run_multi(backend, L, sims, opts)
+    st = eng.status()
+    for g, (fen, moves) in enumerate(MULTI):
+        ref = reference_for(fen, moves, fn, sims, L)
+        ref.search(noise[g])
+        assert canonical_from_engine(eng.debug_tree(g), E.move_to_uci) == ref.canonical(), (g, L, opts)
+        assert int(st["evals"][g]) == ref.n_evals and int(st["term_sims"][g]) == ref.n_term_sims, (g, L, opts)
+    fs = eng.fast_stats()
+    assert (fs["granules_read"] > 0).all() and (fs["path_nodes"] >= sims).all()
+    return eng
+
+
+@pytest.mark.parametrize("L,sims,opts", [
+    (4, 60, dict(games_per_halfwave=4, select_flags=2)),
+    (4, 60, dict(games_per_halfwave=4, select_flags=0)),
+    (3, 50, dict(games_per_halfwave=2, select_flags=3)),
+    (2, 40, dict(games_per_halfwave=2, select_flags=0)),
+    (7, 70, dict(select_flags=2)),
+    (8, 64, dict(select_flags=0)),
+    (13, 90, dict(select_flags=2)),
+    (33, 99, dict(select_flags=2)),
+    (64, 128, dict(select_flags=0)),
+])
+def test_fast_select_variants_match_restatement_with_a_different_position_in_every_slot(L, sims, opts):
+    check_multi("emu", L, sims, opts)
