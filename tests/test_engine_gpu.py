@@ -349,6 +349,24 @@ def test_fast_mode_kernels_on_gpu_match_numpy_restatement(backend):
         assert int(st["evals"][0]) == ref.n_evals and int(st["term_sims"][0]) == ref.n_term_sims
 
 
+@pytest.mark.parametrize("L,ut", [(4, 4), (4, 2), (3, 4), (2, 2)])
+def test_fast_select_kernel_variants_on_gpu_match_restatement(backend, L, ut):
+    """Every instantiation of the select + backup kernel (games per half-wave x {non-temporal loads, root run in registers,
+    capped registers}) with a different position in every game slot: whole trees against tests/fast_reference.py, bit for bit."""
+    import test_fast_mode_emu as T
+
+    for flags in range(8):
+        T.check_multi("hip", L, 80, dict(games_per_halfwave=ut, select_flags=flags))
+
+
+@pytest.mark.parametrize("L,sims", [(7, 70), (8, 96), (13, 90), (16, 128), (33, 99), (64, 192)])
+def test_fast_select_kernel_more_leaves_per_step_on_gpu(backend, L, sims):
+    import test_fast_mode_emu as T
+
+    for flags in (0, 3):
+        T.check_multi("hip", L, sims, dict(select_flags=flags))
+
+
 def test_fast_mode_tree_reuse_on_gpu_matches_numpy_restatement(backend):
     """Tree reuse between moves on the product library: after every search the played child's subtree is compacted into the
     game's other arena and becomes the next tree; six plies, trees compared with the restatement after every search and
