@@ -30,13 +30,19 @@ def select_move_with_temperature(probs: np.ndarray, move_number: int) -> int:
                                                  config.TEMPERATURE_INITIAL, config.TEMPERATURE_FINAL)
 
 
-def _rollout(model, n_slots: int, rng_mode: str = "python") -> Rollout:
+def _inference_copy(model, n_slots: int):
     dev = E.runtime_device(config.DEVICE)  # raises off the GPU: there is no CPU path
-    if dev.type == "cuda" and hasattr(model, "for_inference"):  # BN-folded copy in the faster layout for n_slots rows
+    if dev.type == "cuda" and hasattr(model, "for_inference"):  # BN-folded copy on the hand-written evaluate stage for n_slots rows
         from betaone_amd.nn_tune import best_inference_copy
 
         rows = n_slots * (config.FAST_LEAVES if config.SEARCH_MODE == "fast" else 1)
         model = best_inference_copy(model, rows, dev, next(model.parameters()).dtype)
+    return model
+
+
+def _rollout(model, n_slots: int, rng_mode: str = "python") -> Rollout:
+    dev = E.runtime_device(config.DEVICE)
+    model = _inference_copy(model, n_slots)
     return Rollout(model, n_slots, num_simulations=config.NUM_SIMULATIONS, mcts_batch_size=config.MCTS_BATCH_SIZE,
                    cpuct=config.CPUCT, widen_coeff=config.WIDEN_COEFF, dirichlet_alpha=config.DIRICHLET_ALPHA,
                    dirichlet_epsilon=config.DIRICHLET_EPSILON, max_plies=config.ENGINE_MAX_PLIES,  # None = room for MAX_GAME_MOVES
@@ -58,11 +64,17 @@ def _records(ro: Rollout, fin: FinishedGame) -> List[SelfPlayData]:
 
 
 def run_self_play_games(model, game_ids: Sequence[int], seeds: Optional[Sequence[int]] = None,
-                        n_slots: Optional[int] = None, start_fens: Optional[Sequence[Optional[str]]] = None
+                        n_slots: Optional[int] = None, start_fens: Optional[Sequence[Optional[str]]] = None,
+                        on_game=None, dense: bool = True, reload_model=None
                         ) -> Dict[int, Optional[List[SelfPlayData]]]:
     """Play len(game_ids) games, n_slots at a time, on one GPU.  Game i draws its Dirichlet noise and its
     moves from numpy.random.RandomState(seeds[i]) -- the stream the reference consumes after
-    np.random.seed(seeds[i]) -- so results do not depend on n_slots or on which GPU a game lands on."""
+    np.random.seed(seeds[i]) -- so results do not depend on n_slots or on which GPU a game lands on.
+    on_game(FinishedGame): called for every finished game while it is still resident in its slot (compact records:
+    betaone_amd.records.save_games); dense=False skips the reference's dense tuples (the result values are then empty lists).
+    reload_model() -> None | a new PolicyValueNet: polled once per ply; a returned model replaces the evaluate stage for every
+    evaluation from the next ply on (main.py:147-148 hands weights to its workers through best_model.pth: betaone_amd.selfplay_main
+    watches that file)."""
     ids = list(game_ids)
     seeds = list(seeds) if seeds is not None else ids
     n_slots = min(n_slots or len(ids), len(ids))
@@ -79,12 +91,18 @@ def run_self_play_games(model, game_ids: Sequence[int], seeds: Optional[Sequence
     def finished(fin: FinishedGame):
         if fin.terminal == 0:
             print(f"Game {fin.game_id} aborted after {len(fin.moves)} moves (max).")  # self_play.py:186-187
-        results[fin.game_id] = _records(ro, fin)
+        if on_game is not None:
+            on_game(fin)
+        results[fin.game_id] = _records(ro, fin) if dense else []
 
     first = [next_game(s) for s in range(n_slots)]
     ro.start_games(list(range(n_slots)), [f[0] for f in first], [f[1] for f in first], [f[2] for f in first])
     try:
         while any(g is not None for g in ro.games):
+            if reload_model is not None:
+                fresh = reload_model()
+                if fresh is not None:
+                    ro.swap_model(_inference_copy(fresh, n_slots))
             ro.play_ply(on_finished=finished, refill=next_game)
             _settle_status(ro, results, finished, next_game)
     finally:

@@ -95,6 +95,121 @@ def expand_game(game: dict, device="cuda:0") -> List[Tuple[torch.Tensor, np.ndar
     return recs
 
 
+# ---- on disk ---------------------------------------------------------------------------------
+# The reference writes one pickle per game of DENSE tuples, 49.4 KB per ply (self_play.py:220-231), and train.py reads them all
+# back into one Python list (train.py:187-219).  The compact form on disk is the wire format above, games simply concatenated
+# (a file can be appended to and two files can be cat'ed together): ~100 B per ply.  CompactDataset yields exactly the triple
+# ChessDataset.__getitem__ yields (train.py:179-184), planes re-expanded by the engine's encode kernel one game at a time.
+COMPACT_SUFFIX = ".bog"
+
+
+def compact_path(data_dir: str, iteration: int, rank: int = 0) -> str:
+    """DATA_DIR/iter_{iteration}/games_rank{rank}.bog -- beside the reference's game_{id}.pkl files (self_play.py:224-226)."""
+    import os
+
+    return os.path.join(data_dir, f"iter_{iteration}", f"games_rank{rank}{COMPACT_SUFFIX}")
+
+
+def save_games(path: str, finished: Sequence, append: bool = True) -> int:
+    """Append the compact records of `finished` (rollout.FinishedGame objects, or already packed bytes) to `path`; returns the
+    bytes written.  One write per call, flushed: a reader (or a resume) never sees half a game from a finished call."""
+    import os
+
+    blob = b"".join(f if isinstance(f, (bytes, bytearray)) else pack_game(f) for f in finished)
+    if not blob:
+        return 0
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, "ab" if append else "wb") as fh:
+        fh.write(blob)
+        fh.flush()
+        os.fsync(fh.fileno())
+    return len(blob)
+
+
+def scan_games(buf) -> List[Tuple[int, int, int, int]]:
+    """(game_id, n_plies, byte offset, byte length) of every complete game in a compact buffer -- headers only, nothing unpacked
+    (a truncated tail, e.g. from a killed writer, ends the scan)."""
+    out, off, mv = [], 0, memoryview(buf)
+    while off + 24 <= len(mv):
+        head = np.frombuffer(mv[off:off + 24], dtype=np.int32)
+        if head[0] != MAGIC:
+            break
+        n, nent = int(head[2]), int(head[5])
+        size = 24 + POS_BYTES * (n + 1) + 4 * n + 4 * (n + 1) + 8 * nent
+        if n < 0 or nent < 0 or off + size > len(mv):
+            break
+        out.append((int(head[1]), n, off, size))
+        off += size
+    return out
+
+
+def load_games(path: str) -> List[dict]:
+    """Every complete game of a compact file (a truncated tail is ignored, as by scan_games)."""
+    with open(path, "rb") as fh:
+        buf = fh.read()
+    idx = scan_games(buf)
+    return unpack_games(buf[:idx[-1][2] + idx[-1][3]]) if idx else []
+
+
+def game_ids_on_disk(data_dir: str, iteration: int) -> set:
+    """Ids of the games of `iteration` that already have a compact record in any games_rank*.bog (resume, main.py:26-36)."""
+    import glob
+    import os
+
+    ids = set()
+    for p in glob.glob(os.path.join(data_dir, f"iter_{iteration}", f"games_rank*{COMPACT_SUFFIX}")):
+        with open(p, "rb") as fh:
+            ids.update(g[0] for g in scan_games(fh.read()))
+    return ids
+
+
+class CompactDataset(torch.utils.data.Dataset):
+    """torch Dataset over compact game files: item i = the i-th ply of the concatenated games, as the triple
+    ChessDataset.__getitem__ returns (train.py:179-184): (state float32 [120,8,8], policy float32 tensor [4672], value float32
+    tensor [1]) -- bit-identical to what the reference's pickle of the same game yields.  A game's planes are re-expanded on
+    `device` by the engine's encode kernel (bo_records_encode: history blocks, END-of-game repetition counts, self_play.py:200-208)
+    the first time one of its plies is asked for, and the last `cache_games` expanded games are kept (a DataLoader that walks
+    the plies in order, or shuffles within a window of games, expands each game once)."""
+
+    def __init__(self, paths: Sequence[str], device="cuda:0", cache_games: int = 64):
+        self.device, self.cache_games = device, max(1, int(cache_games))
+        self._blobs, self._index = [], []  # file contents; per game (blob, offset, length, plies)
+        for p in ([paths] if isinstance(paths, str) else list(paths)):
+            with open(p, "rb") as fh:
+                b = fh.read()
+            self._blobs.append(b)
+            self._index.extend((len(self._blobs) - 1, off, size, n) for _gid, n, off, size in scan_games(b) if n > 0)
+        self._first = np.zeros(len(self._index) + 1, dtype=np.int64)  # first item of each game
+        np.cumsum([g[3] for g in self._index], out=self._first[1:])
+        self._cache = {}  # game number -> dense records (insertion-ordered: oldest first)
+
+    def __len__(self) -> int:
+        return int(self._first[-1])
+
+    def game_of(self, i: int) -> Tuple[int, int]:
+        g = int(np.searchsorted(self._first, i, side="right")) - 1
+        return g, i - int(self._first[g])
+
+    def _expand(self, g: int):
+        recs = self._cache.get(g)
+        if recs is None:
+            blob, off, size, _n = self._index[g]
+            recs = expand_game(unpack_games(self._blobs[blob][off:off + size])[0], self.device)
+            self._cache[g] = recs
+            while len(self._cache) > self.cache_games:
+                self._cache.pop(next(iter(self._cache)))
+        return recs
+
+    def __getitem__(self, i: int):
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        g, k = self.game_of(i)
+        state, policy, value = self._expand(g)[k]
+        return state, torch.from_numpy(policy).float(), torch.tensor([value], dtype=torch.float32)  # train.py:181-184
+
+
 def all_gather_bytes(payload: bytes, device: Optional[torch.device] = None, group=None) -> List[bytes]:
     """One exchange step: every rank contributes `payload`, every rank receives all payloads.
     Two collectives: sizes (int64 all_gather), then the padded payload (uint8 all_gather) -- RCCL over

@@ -537,6 +537,17 @@ class Rollout:
         if nxt is not None:
             self.start_games([g], [nxt[0]], [nxt[1]], [nxt[2]])  # its first search is begun by the next play_ply
 
+    def swap_model(self, model: torch.nn.Module) -> None:
+        """Replace the evaluate stage between two plies (weights handed over by the training side, main.py:147-148): every
+        evaluation from the next play_ply on runs `model`; the captured graphs hold the old module's kernels and weight
+        addresses, so they are dropped and re-captured on first use.  Searches already begun keep their trees."""
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)  # nothing of the old graphs is in flight when they are released
+        self.model = model
+        self._graph = self._fgraph = None
+        self._graphs_n = {}
+        self._logits = self._value = None
+
     def close(self):
         self._graph = self._fgraph = None
         self._graphs_n = {}

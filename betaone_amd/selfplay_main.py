@@ -29,33 +29,93 @@ def game_seed(iteration: int, game_id: int) -> int:
     return (iteration * 1_000_003 + game_id * 7919 + 12345) & 0xFFFFFFFF
 
 
-def pending_game_ids(data_dir: str, iteration: int, n_games: int) -> List[int]:
+def pending_game_ids(data_dir: str, iteration: int, n_games: int, records: str = "pickle") -> List[int]:
+    """Game ids of the iteration with no result on disk yet (main.py:26-36): no game_{j}.pkl and, when compact records are
+    written, no record in any games_rank*.bog either."""
     d = os.path.join(data_dir, f"iter_{iteration}")
-    return [j for j in range(n_games) if not os.path.exists(os.path.join(d, f"game_{j}.pkl"))]
+    have = set()
+    if records in ("compact", "both"):
+        from betaone_amd import records as R
+
+        have = R.game_ids_on_disk(data_dir, iteration)
+    return [j for j in range(n_games) if j not in have and not os.path.exists(os.path.join(d, f"game_{j}.pkl"))]
+
+
+class ModelFileWatcher:
+    """Weights hot-swap inside a living process (main.py:147-148 saves best_model.pth at the top of every iteration and each of
+    its one-game workers loads it, main.py:47-49): poll() returns a freshly loaded PolicyValueNet when the file's (mtime, size)
+    changed since the last look, else None.  A file caught in the middle of being written fails to load and is retried at the
+    next poll."""
+
+    def __init__(self, path: str, make_model: Callable[[], object], device, every: int = 8):
+        self.path, self.make_model, self.device, self.every = path, make_model, device, max(1, int(every))
+        self._calls, self.n_reloads = 0, 0
+        self._seen = self._stamp()
+
+    def _stamp(self):
+        try:
+            st = os.stat(self.path)
+            return (st.st_mtime_ns, st.st_size)
+        except OSError:
+            return None
+
+    def poll(self):
+        self._calls += 1
+        if self._calls % self.every:
+            return None
+        now = self._stamp()
+        if now is None or now == self._seen:
+            return None
+        import torch
+
+        try:
+            sd = torch.load(self.path, map_location=self.device)
+            model = self.make_model().to(self.device)
+            model.load_state_dict(sd)
+        except Exception as ex:  # half-written file: try again next time
+            print(f"[selfplay] {self.path} changed but could not be loaded yet ({type(ex).__name__})")
+            return None
+        self._seen = now
+        self.n_reloads += 1
+        return model.eval()
 
 
 def run_iteration(model, iteration: int, n_games: int, n_slots: int, rank: int = 0, world: int = 1,
-                  log: Callable[[str], None] = print) -> Dict[int, int]:
-    """Play the games of `iteration` that are not on disk yet and save each as the reference's pickle.
+                  log: Callable[[str], None] = print, records: str = "pickle", reload_model=None) -> Dict[int, int]:
+    """Play the games of `iteration` that are not on disk yet.  records: "pickle" = the reference's one pickle per game
+    (self_play.py:220-231), "compact" = ~100 B/ply records appended to DATA_DIR/iter_{i}/games_rank{rank}.bog
+    (betaone_amd.records, read back by records.CompactDataset with ChessDataset's item contract), "both".
     Returns {game_id: plies}."""
     from betaone_amd import dropin
 
     dropin.install()
     import config
     import self_play
+    from betaone_amd import records as R
 
-    todo = [j for j in pending_game_ids(config.DATA_DIR, iteration, n_games) if j % world == rank]
+    assert records in ("pickle", "compact", "both")
+    todo = [j for j in pending_game_ids(config.DATA_DIR, iteration, n_games, records) if j % world == rank]
     if not todo:
         log(f"[rank {rank}] iteration {iteration}: nothing to do")
         return {}
     t0 = time.time()
+    done: Dict[int, int] = {}
+    path = R.compact_path(config.DATA_DIR, iteration, rank)
+
+    def on_game(fin):  # one append per finished game: a killed run keeps every game it finished
+        done[fin.game_id] = len(fin.pis)
+        if records != "pickle" and len(fin.pis):
+            R.save_games(path, [fin])
+
     results = self_play.run_self_play_games(model, todo, seeds=[game_seed(iteration, j) for j in todo],
-                                            n_slots=min(n_slots, len(todo)))
-    done = {}
+                                            n_slots=min(n_slots, len(todo)), on_game=on_game, dense=records != "compact",
+                                            reload_model=reload_model)
     for j, data in results.items():
-        if data:
+        if data is None:
+            done.pop(j, None)  # aborted game (self_play.py:167): no record
+        elif records != "compact" and data:
             self_play.save_game_data(data, iteration, j)
-            done[j] = len(data)
+    done = {j: n for j, n in done.items() if n}
     dt = time.time() - t0
     plies = sum(done.values())
     log(f"[rank {rank}] iteration {iteration}: {len(done)} games, {plies} plies in {dt:.1f} s "
@@ -87,6 +147,9 @@ def main(argv: Optional[List[str]] = None):
     ap.add_argument("--slots", type=int, default=256, help="concurrent games per GPU")
     ap.add_argument("--model", default=None, help="state_dict file (default SAVE_DIR/best_model.pth)")
     ap.add_argument("--gpus", type=int, default=1, help="ranks to start on this node (ignored under torchrun)")
+    ap.add_argument("--records", default="pickle", choices=["pickle", "compact", "both"],
+                    help="pickle: the reference's game_{id}.pkl; compact: games_rank{r}.bog (~100 B/ply, records.CompactDataset); both")
+    ap.add_argument("--watch-model", action="store_true", help="reload the state_dict file whenever it changes on disk (checked every 8 plies)")
     args = ap.parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, ["-m", "betaone_amd.selfplay_main"] + list(sys.argv[1:] if argv is None else argv)))
@@ -110,7 +173,11 @@ def main(argv: Optional[List[str]] = None):
     else:
         print(f"[rank {rank}] warning: {path} not found, playing with a randomly initialised net")
     model.eval()
-    run_iteration(model, args.iteration, args.games or config.GAMES_MINIMUM, args.slots, rank, world)
+    watcher = ModelFileWatcher(path, network.PolicyValueNet, config.DEVICE) if args.watch_model else None
+    run_iteration(model, args.iteration, args.games or config.GAMES_MINIMUM, args.slots, rank, world, records=args.records,
+                  reload_model=watcher.poll if watcher else None)
+    if watcher:
+        print(f"[rank {rank}] weights reloaded {watcher.n_reloads} time(s) from {path}")
 
 
 if __name__ == "__main__":

@@ -87,7 +87,8 @@ def _check_games_against_oracle(ro, rec, watch, sims, plies):
     st = ro.eng.status()
     assert (st["evals"] >= plies * 2).all() and (st["flushes"] >= plies).all()
     for step in range(ro._step):  # size-independent invariants for EVERY game: pi is a distribution over <= 2 moves (E2)
-        n, idx, val = ro._hist[step]
+        went, n, idx, val = ro._hist[step]
+        assert went.all()
         assert (n >= 1).all() and (n <= 2).all()
         sums = np.array([val[g, :n[g]].sum() for g in range(G)])
         assert np.abs(sums - 1.0).max() < 1e-6
@@ -100,6 +101,103 @@ def _check_games_against_oracle(ro, rec, watch, sims, plies):
             assert sorted(np.nonzero(rpi)[0].tolist()) == sorted(idx.tolist())
             for i, v in zip(idx, val):
                 assert np.float32(rpi[i]).view(np.uint32) == np.float32(v).view(np.uint32)
+
+
+LATE_GAME_FENS = [
+    "6k1/5ppp/8/8/8/8/5PPP/3R2K1 w - - 0 40",          # back-rank mate in one: terminal bursts from the first search on
+    "7k/5Q2/5K2/8/8/8/8/8 w - - 10 70",                 # several mates in one side by side, stalemating moves among them
+    "8/8/4k3/8/8/3K4/8/6R1 w - - 98 80",                # halfmove clock 98: claimable fifty-move draws in the tree
+    "k7/8/1K6/8/8/8/8/7R w - - 96 60",                  # mate in one AND the 50-move claim close
+    "8/5k2/8/8/8/2K5/8/4R3 b - - 90 75",                # black to move, long reversible chains (repetition claims)
+]
+
+
+def _bench_like_run(net, G, sims, max_game_moves, preroll, steps, watch, record):
+    """bench.py's own step loop (bench.Driver: staggered pre-roll, finished games exported and their slots refilled on the side
+    stream inside the run, n-iteration graphs, native RNG), with every 8th refilled game starting from a late-game position.
+    record=True: the same run with the evaluate stage launched one iteration at a time and the seam of the `watch` slots read
+    back.  Returns (finished games by id, start FEN by id, recorder)."""
+    import bench
+    from betaone_amd.rollout import Rollout
+
+    ro = Rollout(net, G, num_simulations=sims, mcts_batch_size=96, device="cuda:0", use_graph=True, rng_mode="native",
+                 policy_kind="probs", max_game_moves=max_game_moves)
+    rec = SeamRecorder(ro, watch) if record else None
+    fens = {}
+
+    class Drv(bench.Driver):
+        def refill(self, _slot):
+            i = self.new_id()
+            fens[i] = LATE_GAME_FENS[(i // 8) % len(LATE_GAME_FENS)] if i % 8 == 5 else None
+            return i, i, fens[i]
+
+    drv = Drv(ro, 0, 1, None)
+    fins = {}
+    drv.on_finished = lambda f: fins.__setitem__(f.game_id, f)
+    drv.preroll(preroll, G)
+    for _ in range(steps):
+        drv.step()
+    ro.eng.check_status()
+    slot_of = {gid: f.slot for gid, f in fins.items()}
+    n_graphs = len(ro._graphs_n)
+    ro.close()
+    return fins, fens, rec, slot_of, n_graphs
+
+
+def test_bench_steady_state_path_with_refills_and_late_game_positions_matches_oracle(env):
+    """The timed region of bench.py, oracle-checked at size: 256 slots x 800 sims x 8+2 x 128 on the Winograd tower, hipGraph
+    on, native RNG, staggered starts, games ending (move limit 28, mates, claimed draws) and their slots refilled on the side
+    stream while the others search, refilled slots' first searches begun without a host round trip, late-game start positions
+    (terminal bursts and the 96-simulation yield at 800 sims with the real net).
+      (1) the product path (n-iteration graphs) and the same run launched one iteration at a time finish the SAME games, bit
+          for bit, for every game id;
+      (2) every game that passed through a watched slot -- first occupants and games that entered through a refill alike --
+          replayed through the CPU oracle from the recorded seam: moves, pi bits, z (with its sign), terminal code."""
+    import torch
+    import network
+    from betaone_amd import engine as E
+    from betaone_amd.fused_net import FusedPolicyValueNet
+    from oracle import oracle as O
+
+    config = env
+    config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 8, 2, 128
+    G, SIMS, LIMIT, PREROLL, STEPS, WATCH = 256, 800, 28, 40, 36, (0, 5, 13, 101, 255)
+    torch.manual_seed(0)
+    net = FusedPolicyValueNet(network.PolicyValueNet().to("cuda:0").eval(), conv="tower_wg").to("cuda:0")
+    prod, fens_p, _, slot_p, n_graphs = _bench_like_run(net, G, SIMS, LIMIT, PREROLL, STEPS, WATCH, record=False)
+    assert n_graphs > 0  # the product run did replay n-iteration graphs
+    recd, fens_r, rec, slot_r, _ = _bench_like_run(net, G, SIMS, LIMIT, PREROLL, STEPS, WATCH, record=True)
+    # (1) same games on both launch forms
+    assert sorted(prod) == sorted(recd) and len(prod) >= G and fens_p == fens_r and slot_p == slot_r
+    assert sum(1 for f in prod.values() if f.terminal != 0) >= 8          # games did end by the rules, not only by the move limit
+    assert sum(1 for gid in prod if gid >= G) >= G // 2                     # games that entered through a refill finished too
+    for gid, a in prod.items():
+        b = recd[gid]
+        assert a.moves == b.moves and a.terminal == b.terminal and a.outcome == b.outcome, gid
+        assert len(a.pis) == len(b.pis) == len(a.moves) - a.first_ply, gid
+        for (ia, va), (ib, vb) in zip(a.pis, b.pis):
+            assert ia.tolist() == ib.tolist() and va.view(np.uint32).tolist() == vb.view(np.uint32).tolist(), gid
+    # (2) the watched slots' games against the oracle
+    watched = [gid for gid, sl in slot_r.items() if sl in WATCH]
+    assert sum(1 for gid in watched if gid >= G) >= 4 and sum(1 for gid in watched if fens_r.get(gid)) >= 1
+    late = [gid for gid in watched if fens_r.get(gid)]
+    n_checked = 0
+    for gid in watched:
+        fin = recd[gid]
+        ref = O.self_play(rec.eval_fn, np.random.RandomState(gid), O.default_config(num_simulations=SIMS, max_game_moves=LIMIT),
+                          start_fen=fens_r.get(gid) or "")
+        assert [O.move_to_uci(m) for m in ref["moves"]] == [E.move_to_uci(m) for m in fin.moves], gid
+        term = 0 if ref["termination"] == 0 else (1 if ref["termination"] == 1 else 2)
+        assert term == fin.terminal and ref["outcome"] == fin.outcome, gid
+        assert len(ref["records"]) == len(fin.pis), gid
+        for i, ((_, rpi, rz), (idx, val)) in enumerate(zip(ref["records"], fin.pis)):
+            assert sorted(np.nonzero(rpi)[0].tolist()) == sorted(idx.tolist()), gid
+            for j, v in zip(idx, val):
+                assert np.float32(rpi[j]).view(np.uint32) == np.float32(v).view(np.uint32), gid
+            z = fin.z(i)
+            assert rz == z and np.signbit(rz) == np.signbit(z), gid
+        n_checked += 1
+    assert n_checked >= 8 and late, (n_checked, late)
 
 
 def test_iterations_in_one_graph_launch_play_the_same_games(env):

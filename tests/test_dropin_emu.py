@@ -236,6 +236,108 @@ def test_selfplay_orchestration_writes_reference_pickles_and_resumes(tmp_path):
     assert all(torch.equal(x[0], y[0]) and np.array_equal(x[1], y[1]) for x, y in zip(a, b))
 
 
+def test_compact_records_on_disk_yield_what_the_reference_pickles_yield(tmp_path):
+    """Row f3 on disk: selfplay_main --records both writes the reference's pickles AND ~100 B/ply compact records
+    (games_rank0.bog); records.CompactDataset over the compact file yields, item by item, the triple
+    ChessDataset.__getitem__ (train.py:179-184) yields over the pickled lists -- bit for bit (planes, pi, z with its sign).
+    Resume knows the compact files; a truncated tail (killed writer) is ignored."""
+    import pickle
+    from betaone_amd import records as R
+    from betaone_amd import selfplay_main as M
+
+    config.NUM_SIMULATIONS, config.MCTS_BATCH_SIZE, config.MAX_GAME_MOVES = 30, 16, 6
+    config.DATA_DIR = str(tmp_path / "data")
+    model = FakeNet(scale=2.0, salt=4)
+    done = M.run_iteration(model, 3, n_games=5, n_slots=2, log=lambda s: None, records="both")
+    assert sorted(done) == [0, 1, 2, 3, 4]
+    path = R.compact_path(config.DATA_DIR, 3, 0)
+    size = os.path.getsize(path)
+    plies = sum(done.values())
+    assert size < 400 * plies  # ~100-250 B per ply against 49.4 KB per ply in the pickles
+    games = R.load_games(path)
+    assert sorted(g["game_id"] for g in games) == [0, 1, 2, 3, 4]
+    ds = R.CompactDataset([path], device="cpu", cache_games=2)
+    assert len(ds) == plies
+    k = 0
+    for g in games:  # the dataset walks the games in file order
+        dense = pickle.load(open(tmp_path / "data" / "iter_3" / f"game_{g['game_id']}.pkl", "rb"))
+        assert len(dense) == g["n_plies"]
+        for state, policy, value in dense:  # ChessDataset.__getitem__ of the reference over this list (train.py:179-184)
+            want = (state, torch.from_numpy(policy).float(), torch.tensor([value], dtype=torch.float32))
+            got = ds[k]
+            assert got[0].dtype == torch.float32 and torch.equal(got[0], want[0])
+            assert torch.equal(got[1], want[1]) and got[1].dtype == torch.float32
+            assert torch.equal(got[2], want[2]) and np.signbit(got[2].numpy()[0]) == np.signbit(want[2].numpy()[0])
+            k += 1
+    assert k == len(ds) and torch.equal(ds[-1][0], ds[len(ds) - 1][0])
+    with pytest.raises(IndexError):
+        ds[len(ds)]
+    # resume: compact-only mode skips what is in the file; a half-written game at the end is not counted
+    assert M.pending_game_ids(config.DATA_DIR, 3, 7, records="compact") == [5, 6]
+    with open(path, "ab") as fh:
+        fh.write(open(path, "rb").read()[:100])
+    assert len(R.load_games(path)) == 5 and R.game_ids_on_disk(config.DATA_DIR, 3) == {0, 1, 2, 3, 4}
+    config.DATA_DIR = str(tmp_path / "data_c")
+    only = M.run_iteration(model, 3, n_games=3, n_slots=3, log=lambda s: None, records="compact")
+    assert sorted(only) == [0, 1, 2] and not list((tmp_path / "data_c" / "iter_3").glob("*.pkl"))
+    a = {g["game_id"]: g for g in R.load_games(R.compact_path(config.DATA_DIR, 3, 0))}
+    b = {g["game_id"]: g for g in games}
+    for j in (0, 1, 2):  # the same games, whichever record form was asked for
+        assert a[j]["moves"].tolist() == b[j]["moves"].tolist() and bytes(a[j]["positions"]) == bytes(b[j]["positions"])
+
+
+def test_weights_are_swapped_inside_a_living_process(tmp_path):
+    """Row f4: main.py:147-148 hands new weights to its workers through best_model.pth.  ModelFileWatcher notices the changed file,
+    run_self_play_games swaps the evaluate stage between two plies (Rollout.swap_model): plies before the swap are those of the
+    old weights, plies after it those of the new ones -- checked against two runs that never swap."""
+    import time as _time
+    from betaone_amd import selfplay_main as M
+
+    config.NUM_SIMULATIONS, config.MCTS_BATCH_SIZE, config.MAX_GAME_MOVES = 30, 16, 8
+
+    class Net(torch.nn.Module):  # a FakeNet with a state_dict: the salt is its one "weight"
+        def __init__(self, salt=1):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.tensor([float(salt)]), requires_grad=False)
+
+        def forward(self, x):
+            return FakeNet(scale=3.0, salt=int(self.w.item()))(x)
+
+    path = tmp_path / "best_model.pth"
+    torch.save(Net(1).state_dict(), path)
+    old = Net(1)
+    old.load_state_dict(torch.load(path))
+    calls = [0]
+    watcher = M.ModelFileWatcher(str(path), Net, "cpu", every=1)
+
+    def reload_model():
+        calls[0] += 1
+        if calls[0] == 4:  # the training side writes new weights while the games are at their 4th ply
+            _time.sleep(0.01)
+            torch.save(Net(2).state_dict(), path)
+        return watcher.poll()
+
+    mixed = self_play.run_self_play_games(old, [0, 1, 2], seeds=[5, 6, 7], n_slots=3, reload_model=reload_model)
+    assert watcher.n_reloads == 1
+    only_old = self_play.run_self_play_games(Net(1), [0, 1, 2], seeds=[5, 6, 7], n_slots=3)
+    differs = 0
+    for j in (0, 1, 2):
+        assert len(mixed[j]) == len(only_old[j]) == 8
+        for k in range(3):  # plies searched before the swap: the old weights' (state, pi)
+            assert torch.equal(mixed[j][k][0], only_old[j][k][0]) and np.array_equal(mixed[j][k][1], only_old[j][k][1])
+        differs += any(not np.array_equal(mixed[j][k][1], only_old[j][k][1]) or not torch.equal(mixed[j][k][0], only_old[j][k][0])
+                       for k in range(3, 8))
+    assert differs >= 1  # ... and the new weights took over afterwards
+    # an unchanged file is not reloaded; a file that cannot be loaded yet is retried
+    w2 = M.ModelFileWatcher(str(path), Net, "cpu", every=1)
+    assert w2.poll() is None
+    _time.sleep(0.01)
+    path.write_bytes(b"half a file")
+    assert w2.poll() is None and w2.n_reloads == 0
+    torch.save(Net(3).state_dict(), path)
+    assert int(w2.poll().w.item()) == 3 and w2.n_reloads == 1
+
+
 def test_one_overlong_game_does_not_end_the_others():
     """config.ENGINE_MAX_PLIES smaller than the games: a slot whose position stack is full stops THAT game like the
     reference's move limit (self_play.py:186: records of the moves played are kept) and every other game -- running or

@@ -306,7 +306,7 @@ def test_full_size_config_parity_with_real_net(backend):
         assert (st["evals"] >= PLIES * 2).all() and (st["flushes"] >= PLIES).all()
         games = {g: ro._finish(g, 0) for g in WATCH}
         for st_ in range(ro._step):
-            n, idx, val = ro._hist[st_]
+            _went, n, idx, val = ro._hist[st_]
             assert (n >= 1).all() and (n <= 2).all()
             sums = np.array([val[g, :n[g]].sum() for g in range(G)])
             assert np.abs(sums - 1.0).max() < 1e-6
