@@ -77,7 +77,8 @@ def parse():
     ap.add_argument("--select-games-per-halfwave", type=int, default=None, help="FAST mode: bo_fast_options games_per_halfwave (2 or 4)")
     ap.add_argument("--select-flags", type=int, default=None, help="FAST mode: bo_fast_options select_flags (1 nt, 2 root in registers, 4 dense)")
     ap.add_argument("--select-sweep", action="store_true", help="FAST mode: time every variant of the select + backup kernel on this run's trees")
-    ap.add_argument("--roofline-plies", type=int, default=2, help="FAST mode: plies played eagerly for the select kernel's event timing")
+    ap.add_argument("--roofline-steps", type=int, default=48, help="FAST mode: evaluate -> step iterations run eagerly for the select kernel's event timing")
+    ap.add_argument("--arena-granules-per-expansion", type=int, default=12, help="FAST mode: arena size per game = this x (sims + leaves + 2) granules of 128 B")
     ap.add_argument("--max-game-moves", type=int, default=None, help="config.MAX_GAME_MOVES (small values make games finish: record path; default 16384, --fast: 510)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 path on one GPU")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with WORLD_SIZE=1")
@@ -86,12 +87,12 @@ def parse():
     # --fast is priced on its own workload: enough resident games for the select + backup kernel to be
     # bandwidth-bound (a descent is a chain of dependent reads), a small fp16 net so that the evaluate stage does not starve it
     d_ref = dict(games=256, sims=800, net="10x128", net_dtype="fp32", preroll=640, max_game_moves=16384)
-    d_fast = dict(games=32768, sims=128, net="10x128", net_dtype="fp16", preroll=10, max_game_moves=510)
+    d_fast = dict(games=32768, sims=800, net="10x128", net_dtype="fp16", preroll=3, max_game_moves=510)
     for k, v in (d_fast if args.fast else d_ref).items():
         if getattr(args, k) is None:
             setattr(args, k, v)
     if args.fast and args.steps == 20 and args.warmup == 3:
-        args.steps, args.warmup = 3, 1
+        args.steps, args.warmup = 1, 0  # (a ply of 32768 games x 800 simulations is 26 M evaluations: ~12 s)
     return args
 
 
@@ -259,18 +260,21 @@ def _fast_counters(eng):
                 gran=int(fs["granules_read"].sum()), pnodes=int(fs["path_nodes"].sum()), arena=int(fs["arena_granules"].astype(np.int64).sum()))
 
 
-def fast_select_measure(ro, drv, plies):
-    """`plies` more plies played eagerly (same engine, same games, no graph) with HIP events around every launch of the select +
-    backup kernel on its stream; bytes from the engine's own counters over the same launches."""
+def fast_select_measure(ro, drv, steps):
+    """`steps` more evaluate -> step iterations of the searches in progress, launched eagerly (same engine, same games, no graph)
+    with HIP events around every launch of the select + backup kernel on its stream; bytes from the engine's own counters over the
+    same launches.  (The searches were begun by the last ply's turn; the next ply simply finds them that much further along.  When
+    they would run out of simulations before `steps` launches, a ply is played first.)"""
+    if getattr(drv, "extra_steps", 0) + steps > ro.expected_evals - 8:
+        drv.step()
+        drv.extra_steps = 0
+    drv.extra_steps = getattr(drv, "extra_steps", 0) + steps
     eng = ro.eng
     c0 = _fast_counters(eng)
     eng.fast_stats(time_select=1)
-    graph = ro.use_graph
-    ro.use_graph = False
-    for _ in range(plies):
-        drv.step()
+    for _ in range(steps):
+        ro._eval_and_step_eager()
     torch.cuda.synchronize(ro.device)
-    ro.use_graph = graph
     fs1 = eng.fast_stats(time_select=0)
     c1 = _fast_counters(eng)
     launches = int(fs1["select_launches"])
@@ -284,11 +288,11 @@ def fast_select_measure(ro, drv, plies):
                 kids=d["kids"] / launches, pnodes=d["pnodes"] / launches, arena_bytes=c1["arena"] * eng.GRANULE_BYTES)
 
 
-def fast_select_roofline(ro, drv, plies, label=""):
+def fast_select_roofline(ro, drv, steps, label=""):
     """FAST mode: the select + backup kernel (csrc/bo_fastw.h: bo_k_fw_select) on the trees the searches of this run grew --
     no synthetic topology; virtual loss and backup included (SURVEY.md section 8d: 12 B per child scanned + 8 B per level;
     backup 16 B per path node)."""
-    m = fast_select_measure(ro, drv, plies)
+    m = fast_select_measure(ro, drv, steps)
     if m is None:
         return None
     ach = m["alg"] / m["t"] / 1e9
@@ -304,13 +308,14 @@ def fast_select_roofline(ro, drv, plies, label=""):
             "moved_GBps": round(m["moved"] / m["t"] / 1e9, 1)}
 
 
-def fast_select_sweep(ro, drv):
-    """Every variant of the select + backup kernel over one more ply each of this run's trees (they keep growing meanwhile)."""
+def fast_select_sweep(ro, drv, steps=12):
+    """Every variant of the select + backup kernel over `steps` more launches each on this run's trees (they keep growing meanwhile;
+    when the searches run out of simulations a ply is played in between)."""
     out = []
     for ut in (4, 2):
         for fl in range(8):
             ro.eng.fast_options(games_per_halfwave=ut, select_flags=fl)
-            r = fast_select_roofline(ro, drv, 1, f" u{ut} flags{fl}")
+            r = fast_select_roofline(ro, drv, steps, f" u{ut} flags{fl}")
             if r:
                 out.append({k: r[k] for k in ("kernel", "frac", "achieved", "avg_launch_us", "moved_GBps", "moved_over_algorithmic", "launches_timed",
                                               "levels_per_descent", "children_per_level")})
@@ -419,6 +424,7 @@ class Driver:
         return i, i, None  # game id -> rank = id mod world; RandomState(seed = game id) stream
 
     def step(self):
+        self.extra_steps = 0  # (evaluate -> step iterations run by a measurement since the last ply)
         self.ro.play_ply(on_finished=self.on_finished, refill=self.refill, while_searching=self.hand_over)
 
     def hand_over(self):
@@ -486,7 +492,10 @@ def main():
     G = args.games
     ro = Rollout(net, G, num_simulations=args.sims, mcts_batch_size=args.batch, device=str(device), use_graph=not args.no_graph,
                  rng_mode="native", max_game_moves=args.max_game_moves, fast=args.fast, leaves_per_step=args.leaves,
+                 fast_arena_granules=(args.arena_granules_per_expansion * (args.sims + args.leaves + 2) if args.fast else 0),
                  policy_kind="probs" if args.softmax == "torch" else "logits")
+    if args.fast and G * args.leaves > 65536:
+        ro.MAX_GRAPH_ITERATIONS = 4  # (every iteration of a captured graph keeps its own logits / probabilities: 6.5 GB at 131072 rows)
     if args.fast and (args.select_games_per_halfwave is not None or args.select_flags is not None):
         ro.eng.fast_options(games_per_halfwave=args.select_games_per_halfwave, select_flags=args.select_flags)
     exchange = records.PeriodicGameExchange(device, every=args.exchange_every) if dist is not None else None
@@ -566,7 +575,7 @@ def main():
             best = max(sweep, key=lambda r: r["frac"]) if sweep else None
             if best:  # (kernel label = " u<games per half-wave> flags<n>")
                 ro.eng.fast_options(games_per_halfwave=int(best["kernel"].split(" u")[1][0]), select_flags=int(best["kernel"].split("flags")[1]))
-        fast_roof = fast_select_roofline(ro, drv, args.roofline_plies)
+        fast_roof = fast_select_roofline(ro, drv, args.roofline_steps)
         if fast_roof is not None and args.select_sweep:
             fast_roof["variants"] = sweep
     if rank == 0 and not args.no_roofline and not args.fast and args.net_dtype == "fp32":

@@ -258,20 +258,18 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
         // from the previous search: room for 24 granules (3 KB) per possible expansion of this and of the previous search.
         // A run that still does not fit is refused (status bit) -- the search goes on with that leaf unexpanded.
         const size_t expansions = (size_t)c.S + L + 2;
-        f.NG = (int)((6 * expansions + 8) * (32 / BO_FW_GR));
+        f.NG = cfg->fast_arena_granules > 0 ? cfg->fast_arena_granules : (int)((6 * expansions + 8) * (32 / BO_FW_GR));
+        if (f.NG < 64 || f.NG > BO_FW_LINK_MASK) { bo_engine_destroy(e); return fail(BO_E_ARG, "fast_arena_granules out of range (64 .. 2^24 - 1)"); }
         const size_t NR = (size_t)f.NG * BO_FW_GR;
         rc |= e->alloc(&f.arena, G * 2 * NR); rc |= e->alloc(&f.amove, G * 2 * NR);
-        rc |= e->alloc(&f.cur, G); rc |= e->alloc(&f.top, G); rc |= e->alloc(&f.n_rows, G); rc |= e->alloc(&f.n_step, G);
-        rc |= e->alloc(&f.played_now, G); rc |= e->alloc(&f.stat_gran, G); rc |= e->alloc(&f.stat_path_nodes, G);
-        rc |= e->alloc(&f.row_slot, G * L); rc |= e->alloc(&f.row_plink, G * L); rc |= e->alloc(&f.row_nlegal, G * L);
-        rc |= e->alloc(&f.row_term, G * L); rc |= e->alloc(&f.row_sim, G * L); rc |= e->alloc(&f.row_pos, G * L);
+        f.CS = (FWC_HEAD + FWR_FIELDS * (int)L + 31) / 32 * 32;
+        rc |= e->alloc(&f.ctl, G * (size_t)f.CS);
+        rc |= e->alloc(&f.played_now, G); rc |= e->alloc(&f.row_pos, G * L);
         rc |= e->alloc(&f.row_moves, G * L * BO_MAX_MOVES);
-        rc |= e->alloc(&f.sim_row, G * L); rc |= e->alloc(&f.sim_plen, G * L); rc |= e->alloc(&f.sim_path, G * L * BO_FW_PATH_CAP);
+        rc |= e->alloc(&f.sim_path, G * L * BO_FW_PATH_CAP);
         if (!rc) {
-            int *zero[] = {f.cur, f.top, f.n_rows, f.n_step, f.played_now};
-            for (int *p : zero) rt_memset(p, 0, G * 4, nullptr);
-            rt_memset(f.stat_gran, 0, G * 8, nullptr); rt_memset(f.stat_path_nodes, 0, G * 8, nullptr);
-            rt_memset(f.row_term, 0, G * L * 4, nullptr); rt_memset(f.row_nlegal, 0, G * L * 4, nullptr);
+            rt_memset(f.ctl, 0, G * (size_t)f.CS * 4, nullptr);
+            rt_memset(f.played_now, 0, G * 4, nullptr);
             d.played_now = f.played_now;
         }
     }
@@ -899,9 +897,10 @@ extern "C" int bo_debug_tree(bo_engine *e, int slot, bo_node *out, int32_t cap, 
     RT(rt_sync(stream));
     if (e->fast) {  // child-block arena (bo_fastw.h): nodes in breadth-first order, children in record order
         const FastW &f = e->f;
-        int cur = 0, top = 0;
-        RT(rt_d2h(&cur, f.cur + slot, 4, stream)); RT(rt_d2h(&top, f.top + slot, 4, stream));
+        int head[FWC_HEAD];
+        RT(rt_d2h(head, f.ctl + (size_t)slot * f.CS, sizeof(head), stream));
         RT(rt_sync(stream));
+        const int cur = head[FWC_CUR], top = head[FWC_TOP];
         std::vector<WRec> A((size_t)top * BO_FW_GR);
         std::vector<bo_mv> M((size_t)top * BO_FW_GR);
         const size_t aoff = ((size_t)slot * 2 + (size_t)cur) * (size_t)f.NG * BO_FW_GR;
@@ -953,6 +952,19 @@ extern "C" int bo_debug_tree(bo_engine *e, int slot, bo_node *out, int32_t cap, 
     return BO_OK;
 }
 
+extern "C" int bo_debug_fast(bo_engine *e, int slot, int32_t *ctl_out, int32_t ctl_cap, int32_t *paths_out, void *stream) {
+    if (!e || slot < 0 || slot >= e->d.c.G) return fail(BO_E_ARG, "bad arguments");
+    if (!e->fast) return fail(BO_E_CONFIG, "bo_debug_fast: fast-mode engines only");
+    const FastW &f = e->f;
+    if (ctl_out) {
+        if (ctl_cap < f.CS) return fail(BO_E_ARG, "control block buffer too small");
+        RT(rt_d2h(ctl_out, f.ctl + (size_t)slot * f.CS, (size_t)f.CS * 4, stream));
+    }
+    if (paths_out) RT(rt_d2h(paths_out, f.sim_path + (size_t)slot * f.L * BO_FW_PATH_CAP, (size_t)f.L * BO_FW_PATH_CAP * 4, stream));
+    RT(rt_sync(stream));
+    return BO_OK;
+}
+
 extern "C" int bo_fast_options(bo_engine *e, int32_t tree_reuse, int32_t games_per_halfwave, int32_t select_flags) {
     if (!e) return fail(BO_E_ARG, "null engine");
     if (!e->fast) return fail(BO_E_CONFIG, "bo_fast_options: fast-mode engines only");
@@ -969,9 +981,16 @@ extern "C" int bo_fast_stats(bo_engine *e, uint64_t *granules_read, uint64_t *pa
     if (!e) return fail(BO_E_ARG, "null engine");
     if (!e->fast) return fail(BO_E_CONFIG, "bo_fast_stats: fast-mode engines only");
     const size_t G = (size_t)e->d.c.G;
-    if (granules_read) RT(rt_d2h(granules_read, e->f.stat_gran, G * 8, stream));
-    if (path_nodes) RT(rt_d2h(path_nodes, e->f.stat_path_nodes, G * 8, stream));
-    if (arena_granules) RT(rt_d2h(arena_granules, e->f.top, G * 4, stream));
+    std::vector<int32_t> tmp(2 * G);
+    const size_t pitch = (size_t)e->f.CS * 4;
+    if (granules_read) RT(rt_d2h_2d(tmp.data(), 4, e->f.ctl + FWC_GRAN, pitch, 4, G, stream));
+    if (path_nodes) RT(rt_d2h_2d(tmp.data() + G, 4, e->f.ctl + FWC_PNODES, pitch, 4, G, stream));
+    if (arena_granules) RT(rt_d2h_2d(arena_granules, 4, e->f.ctl + FWC_TOP, pitch, 4, G, stream));
+    RT(rt_sync(stream));
+    for (size_t g = 0; g < G; g++) {  // (32-bit counters per game on the device: 2^31 granules are 256 GB through one game's select path)
+        if (granules_read) granules_read[g] = (uint64_t)(uint32_t)tmp[g];
+        if (path_nodes) path_nodes[g] = (uint64_t)(uint32_t)tmp[G + g];
+    }
     RT(rt_sync(stream));
 #if !defined(BO_WAVE_EMU)
     if (e->sel_pending) {
@@ -997,9 +1016,16 @@ extern "C" int bo_engine_status(bo_engine *e, int32_t *status, int32_t *evals, i
     if (status) RT(rt_d2h(status, e->d.status, G * 4, stream));
     if (evals) RT(rt_d2h(evals, e->d.stat_evals, G * 4, stream));
     if (flushes) RT(rt_d2h(flushes, e->d.stat_flushes, G * 4, stream));
-    if (term_sims) RT(rt_d2h(term_sims, e->d.stat_term_sims, G * 4, stream));
-    if (levels) RT(rt_d2h(levels, e->d.stat_levels, G * 4, stream));
-    if (children_scanned) RT(rt_d2h(children_scanned, e->d.stat_children_scanned, G * 4, stream));
+    if (e->fast) {  // the fast mode keeps these counters in the games' control blocks (bo_fastw.h)
+        const size_t pitch = (size_t)e->f.CS * 4;
+        if (term_sims) RT(rt_d2h_2d(term_sims, 4, e->f.ctl + FWC_TERM, pitch, 4, G, stream));
+        if (levels) RT(rt_d2h_2d(levels, 4, e->f.ctl + FWC_LEVELS, pitch, 4, G, stream));
+        if (children_scanned) RT(rt_d2h_2d(children_scanned, 4, e->f.ctl + FWC_KIDS, pitch, 4, G, stream));
+    } else {
+        if (term_sims) RT(rt_d2h(term_sims, e->d.stat_term_sims, G * 4, stream));
+        if (levels) RT(rt_d2h(levels, e->d.stat_levels, G * 4, stream));
+        if (children_scanned) RT(rt_d2h(children_scanned, e->d.stat_children_scanned, G * 4, stream));
+    }
     RT(rt_sync(stream));
     return BO_OK;
 }

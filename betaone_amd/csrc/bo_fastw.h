@@ -73,26 +73,43 @@ struct alignas(16) FwHead {  // in front of a run's records
     int pad[3];
 };
 
+// Per-game control block of the fast mode: ONE contiguous row of f.CS ints per game, so that the select + backup kernel fetches a
+// game's whole per-launch state with one coalesced request per half-wave (as separate [G] / [G][L] arrays it was ~25 dependent
+// 4-byte reads per game: the kernel's time was its bookkeeping, not the tree).
+//   [FWC_*] scalars | row_slot[L] | row_plink[L] | row_nlegal[L] | row_term[L] | row_sim[L] | sim_row[L] | sim_plen[L]
+enum { FWC_NROWS = 0,   // NN rows of the step in flight
+       FWC_NSTEP = 1,   // simulations of the step in flight
+       FWC_CUR = 2,     // live arena (0 / 1)
+       FWC_TOP = 3,     // granules in use
+       FWC_LEVELS = 4, FWC_KIDS = 5, FWC_GRAN = 6, FWC_PNODES = 7, FWC_TERM = 8,  // counters: levels descended, children scanned,
+                        // record granules requested (x 16 * GR = bytes the select path moved), path nodes updated by the backup (x 16 B
+                        // algorithmic), terminal simulations
+       FWC_HEAD = 16 };
+enum { FWR_SLOT = 0,    // leaf record of row r
+       FWR_PLINK = 1,   // link of the run the leaf lives in (= its parent's children)
+       FWR_NLEGAL = 2, FWR_TERM = 3,
+       FWR_SIM = 4,     // the simulation whose path materialises the row's position
+       FWS_ROW = 5,     // row whose value simulation s backs up (FW_SIM_*: known terminal)
+       FWS_PLEN = 6,    // its path length
+       FWR_FIELDS = 7 };
+#define FWC_F(L, field, i) (FWC_HEAD + (field) * (L) + (i))
+
 struct FastW {
-    int L, NG;                 // leaves per game per step; granules per arena
+    int L, NG, CS;             // leaves per game per step; granules per arena; ints per control block (a multiple of 32)
     int sel_ut, sel_flags;     // bo_k_fw_select: games per half-wave (1, 2 or 4); FW_SEL_*
     WRec *arena;               // [G][2][NG * GR]   (two arenas per game, side by side: re-rooting compacts from one into the other)
     bo_mv *amove;              // [G][2][NG * GR]   move of each record
-    int *cur, *top;            // [G] live arena; granules in use
-    int *n_rows, *n_step;      // [G] NN rows / simulations of the step in flight
-    int *row_slot, *row_plink, *row_nlegal, *row_term, *row_sim;  // [G][L]  leaf record, link of the run it lives in, ...
+    int *ctl;                  // [G][CS] control blocks
     DPos *row_pos;             // [G][L] position of row r's leaf
     bo_mv *row_moves;          // [G][L][256] its legal moves (python-chess order)
-    int *sim_row, *sim_plen;   // [G][L] row whose value simulation s backs up (FW_SIM_*: known terminal); its path length
     int *sim_path;             // [G][L][PATH_CAP] record ids root..leaf (record id = granule * GR + index)
     int *played_now;           // [G] move played by the last bo_k_play (0: none); the same array as Eng::played_now
-    unsigned long long *stat_gran;        // [G] record granules requested by descents (x 16 * GR = bytes the select path moved)
-    unsigned long long *stat_path_nodes;  // [G] path nodes written by the backup (x 16 B algorithmic)
 };
 
+BO_DEV int *fw_ctl(const FastW &f, int g) { return f.ctl + (size_t)g * f.CS; }
 BO_DEV size_t fw_arena_off(const FastW &f, int g, int which) { return ((size_t)g * 2 + (size_t)which) * (size_t)f.NG * BO_FW_GR; }
-BO_DEV WRec *fw_arena(const FastW &f, int g) { return f.arena + fw_arena_off(f, g, f.cur[g]); }
-BO_DEV bo_mv *fw_moves(const FastW &f, int g) { return f.amove + fw_arena_off(f, g, f.cur[g]); }
+BO_DEV WRec *fw_arena(const FastW &f, int g) { return f.arena + fw_arena_off(f, g, fw_ctl(f, g)[FWC_CUR]); }
+BO_DEV bo_mv *fw_moves(const FastW &f, int g) { return f.amove + fw_arena_off(f, g, fw_ctl(f, g)[FWC_CUR]); }
 BO_DEV int fw_first(int link) { return link & BO_FW_LINK_MASK; }
 BO_DEV int fw_ngran(int link) { return ((link >> 24) & 127) + 1; }
 BO_DEV int fw_link(int first, int ngran) { return first | ((ngran - 1) << 24); }
@@ -111,15 +128,19 @@ typedef int fw_i4 __attribute__((ext_vector_type(4)));
 typedef int fw_i2 __attribute__((ext_vector_type(2)));
 template <bool NT> BO_DEV WRec fw_ld(const WRec *p) {
     const fw_i4 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const fw_i4 *>(p)) : *reinterpret_cast<const fw_i4 *>(p);
+    // (elements into scalars first: __builtin_bit_cast applied to a vector ELEMENT read element 0 whatever the index -- clang 19 /
+    //  ROCm 7.2 -- so every score ignored the priors; found by the lock-step probe against the emulator build)
+    const int i0 = v[0], i1 = v[1], i2 = v[2], i3 = v[3];
     WRec r;
-    r.n = v[0]; r.w = __builtin_bit_cast(float, v[1]); r.prior = __builtin_bit_cast(float, v[2]); r.link = v[3];
+    r.n = i0; r.w = __builtin_bit_cast(float, i1); r.prior = __builtin_bit_cast(float, i2); r.link = i3;
     return r;
 }
 struct fw_nw { int n; float w; };
 BO_DEV fw_nw fw_ld_nw(const WRec *p) {
     const fw_i2 v = *reinterpret_cast<const fw_i2 *>(p);
+    const int i0 = v[0], i1 = v[1];
     fw_nw r;
-    r.n = v[0]; r.w = __builtin_bit_cast(float, v[1]);
+    r.n = i0; r.w = __builtin_bit_cast(float, i1);
     return r;
 }
 BO_DEV void fw_st_nw(WRec *p, int n, float w) {
@@ -151,15 +172,16 @@ BO_DEV int fw_row_need(int term, int nlegal) { return term == 0 ? BO_FW_HG + fw_
 BO_KERNEL void bo_k_fw_apply(Eng e, FastW f, const float *policy, int kind) {
     BO_SHARED float pv[BO_MAX_MOVES];
     const int L = f.L, g = bo_block() / L, r = bo_block() % L, lane = bo_lane();
-    if (e.phase[g] != PH_RUN || r >= f.n_rows[g]) return;
+    const int *ctl = fw_ctl(f, g);
+    if (e.phase[g] != PH_RUN || r >= ctl[FWC_NROWS]) return;
     const size_t ro = (size_t)g * L + r;
     WRec *A = fw_arena(f, g);
-    const int slot = f.row_slot[ro], t = f.row_term[ro];
+    const int slot = ctl[FWC_F(L, FWR_SLOT, r)], t = ctl[FWC_F(L, FWR_TERM, r)];
     if (t > 0) {  // found terminal at its first visit: remember it, no children
         if (lane == 0) A[slot].link = t == 1 ? FW_MATE : FW_DRAW;
         return;
     }
-    const int n = f.row_nlegal[ro];
+    const int n = ctl[FWC_F(L, FWR_NLEGAL, r)];
     const bo_mv *mv = f.row_moves + ro * BO_MAX_MOVES;
     const float *prow = policy + ro * BO_NUM_ACTIONS;
     if (kind == POLICY_PROBS) {
@@ -183,9 +205,9 @@ BO_KERNEL void bo_k_fw_apply(Eng e, FastW f, const float *policy, int kind) {
         bo_sync();
     }
     // this row's run starts behind the runs of the rows before it (rows of one game are applied by different waves)
-    int first = f.top[g];
+    int first = ctl[FWC_TOP];
     for (int q = 0; q < r; q++) {
-        const int need = fw_row_need(f.row_term[(size_t)g * L + q], f.row_nlegal[(size_t)g * L + q]);
+        const int need = fw_row_need(ctl[FWC_F(L, FWR_TERM, q)], ctl[FWC_F(L, FWR_NLEGAL, q)]);
         if (first + need <= f.NG) first += need;  // (a run that does not fit is refused; bo_k_fw_select advances `top` by the same rule)
     }
     const int ngran = fw_gran_for(n);
@@ -210,67 +232,6 @@ BO_KERNEL void bo_k_fw_apply(Eng e, FastW f, const float *policy, int kind) {
 }
 
 // ---- select + backup ----------------------------------------------------------------------------------------------------
-// Backup of the step in flight for ONE game, executed by the 32 lanes of its half-wave; lane c owns path depths c and c + 32
-// (a record sits at one depth only, so all updates of a record are made by one lane, in simulation order: no cross-lane
-// ordering is needed).  CH simulations are fetched at once and chained in registers where their paths share a record, so a
-// step's backup costs one memory round trip per CH simulations, not one per simulation.
-// Returns the number of known-terminal / found-terminal simulations among them.
-#define BO_FW_BK_CH 4
-BO_DEV int fw_backup_game(WRec *A, const int *sim_row, const int *sim_plen, const int *sim_path, const int *row_term, const float *vrow,
-                          int n_step, int c) {
-    int term_sims = 0;
-    for (int s0 = 0; s0 < n_step; s0 += BO_FW_BK_CH) {
-        float v[BO_FW_BK_CH];
-        int plen[BO_FW_BK_CH];
-        int maxlen = 0;
-        BO_UNROLL
-        for (int j = 0; j < BO_FW_BK_CH; j++) {
-            const int s = s0 + j;
-            const bool ok = s < n_step;
-            const int q = ok ? sim_row[s] : FW_SIM_DRAW;
-            plen[j] = ok ? sim_plen[s] : 0;
-            if (q >= 0) {  // value[] is from the leaf's side to move; the player who moved into the leaf sees -v; a found terminal has its exact value
-                const int t = row_term[q];
-                v[j] = t > 0 ? (t == 1 ? 1.0f : 0.0f) : -vrow[q];
-                term_sims += (ok && t > 0) ? 1 : 0;
-            } else {
-                v[j] = q == FW_SIM_MATE ? 1.0f : 0.0f;
-                term_sims += ok ? 1 : 0;
-            }
-            maxlen = plen[j] > maxlen ? plen[j] : maxlen;
-        }
-        for (int k = c; k < maxlen; k += 32) {  // (second pass only for paths deeper than 32)
-            int rec[BO_FW_BK_CH];
-            bool val[BO_FW_BK_CH];
-            fw_nw x[BO_FW_BK_CH];
-            BO_UNROLL
-            for (int j = 0; j < BO_FW_BK_CH; j++) {
-                val[j] = k >= 1 && k < plen[j];  // the root (k = 0) only counts visits: done by the caller
-                rec[j] = val[j] ? sim_path[(size_t)(s0 + j) * BO_FW_PATH_CAP + k] : 0;
-            }
-            BO_UNROLL
-            for (int j = 0; j < BO_FW_BK_CH; j++) {
-                x[j].n = 0; x[j].w = 0.0f;
-                if (val[j]) x[j] = fw_ld_nw(A + rec[j]);
-            }
-            BO_UNROLL
-            for (int j = 0; j < BO_FW_BK_CH; j++) {
-                if (!val[j]) continue;
-                BO_UNROLL
-                for (int i = 0; i < j; i++)
-                    if (val[i] && rec[i] == rec[j]) x[j] = x[i];  // (the latest earlier simulation through the same record wins)
-                const float sgn = ((plen[j] - 1 - k) & 1) ? -v[j] : v[j];
-                x[j].n = x[j].n + 1;
-                x[j].w = x[j].w + sgn;
-            }
-            BO_UNROLL
-            for (int j = 0; j < BO_FW_BK_CH; j++)
-                if (val[j]) fw_st_nw(A + rec[j], x[j].n, x[j].w);
-        }
-    }
-    return term_sims;
-}
-
 // first maximum in child order within a half-wave: (score, index) through four DPP row rounds and one cross-row exchange
 #define BO_FW_ARGMAX(os_expr, oi_expr)                                                      \
     {                                                                                       \
@@ -286,89 +247,212 @@ template <> struct FwMask<16> { typedef unsigned T; };
 BO_DEV int fw_ctz(unsigned m) { return __builtin_ctz(m); }
 BO_DEV int fw_ctz(unsigned long long m) { return __builtin_ctzll(m); }
 
-// NT: runs below the root are requested non-temporally (read once per launch); the root's run, read by every descent of the
-// step, takes the cached path.  ROOTC: the first 64 records of the root's run stay in registers for the whole launch.
+// Half a wave per game, UT games interleaved per half-wave.  NT: runs below the root are requested non-temporally (read once per
+// launch); the root's run, read by every descent of the step, takes the cached path.  ROOTC: the first 64 records of the root's
+// run stay in registers for the whole launch.
+//   1. every game's control block, the step's values and the Eng scalars: one round trip for all 2 * UT games of the wave, into LDS
+//   2. backup of the step in flight: lane c owns path depth c (a record sits at one depth only, so all updates of a record are
+//      made by ONE lane, in simulation order: no cross-lane ordering is needed); the paths of BO_FW_BK_CH simulations of every
+//      game are fetched together, then their records, and simulations that share a record are chained in registers -- a step's
+//      backup costs three dependent round trips for the whole wave, not one per simulation and game
+//   3. L descents per game over the read-only tree; rows / simulations are noted in the LDS copy of the control block
+//   4. the control blocks go back with one coalesced store per game
 template <int UT, int LCAP, bool NT, bool ROOTC>
 BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int kind) {
     typedef typename FwMask<LCAP>::T mask_t;
-    BO_SHARED unsigned char s_idx[2 * UT][LCAP][BO_FW_PATH_CAP];  // child index chosen at depth d by descent s of the step
-    BO_SHARED int s_rowslot[2 * UT][LCAP];                         // leaf record of the step's NN rows
+    constexpr int CSL = FWC_HEAD + FWR_FIELDS * LCAP, NCR = (CSL + 31) / 32, NVR = (LCAP + 31) / 32;
+    constexpr int BO_FW_BK_CH = UT >= 4 ? 2 : 4;  // simulations of a game whose backups are fetched together and chained in registers
+    BO_SHARED int s_ctl[2 * UT][NCR * 32];                         // the games' control blocks
+    BO_SHARED float s_val[2 * UT][NVR * 32];                       // values of the step's rows
+    BO_SHARED unsigned char s_idx[2 * UT][LCAP][BO_FW_PATH_CAP];   // child index chosen at depth d by descent s of the step
     BO_SHARED int s_path[2 * UT][BO_FW_PATH_CAP];                  // record ids of the descent in progress
     const int lane = bo_lane(), half = lane >> 5, c = lane & 31, hb = half << 5;
-    const int L = f.L, S = e.c.S;
+    const int L = f.L, S = e.c.S, G = e.c.G;
     const float cpuct = e.c.cpuct;
     // the 2 * UT games of a workgroup are consecutive: their arenas are addressed as one uniform base + a 32-bit offset
     const int g0 = bo_block() * 2 * UT;
     WRec *const base = f.arena + fw_arena_off(f, g0, 0);
     unsigned aoff[UT];  // records from `base` to the game's live arena
     int sims[UT], n_rows[UT], n_step[UT], root_n[UT], root_link[UT];
-    int link[UT], pn[UT], d[UT], cur[UT], lastlink[UT];
-    int lg[UT], kids[UT];  // levels | record granules requested << 12; children scanned (this lane's share)
+    int link[UT], pn[UT], d[UT];
     mask_t M[UT];
     bool on[UT], busy[UT], done[UT];
     WRec rr0[ROOTC ? UT : 1], rr1[ROOTC ? UT : 1];
 #define FW_G(u) (g0 + half * UT + (u))
 #define FW_A(u) (base + aoff[u])
+#define FW_SLOT(u) (half * UT + (u))
+#define FW_C(u, i) s_ctl[FW_SLOT(u)][(i)]
 
-    // ---- 1. the previous step's rows have been applied: back their values up ---------------------------------------------
-    BO_UNROLL
-    for (int u = 0; u < UT; u++) {
-        on[u] = FW_G(u) < e.c.G && e.phase[FW_G(u)] == PH_RUN;
-        const int gg = on[u] ? FW_G(u) : g0;
-        aoff[u] = (unsigned)(((size_t)(gg - g0) * 2 + (size_t)f.cur[gg]) * (size_t)f.NG * BO_FW_GR);
-        sims[u] = e.sims_done[gg]; n_rows[u] = f.n_rows[gg]; n_step[u] = f.n_step[gg];
-        lg[u] = kids[u] = 0;
-        busy[u] = done[u] = false;
-        link[u] = -1; pn[u] = 1; d[u] = 1; cur[u] = 0; lastlink[u] = -1; M[u] = 0;
-        root_n[u] = 0; root_link[u] = -1;
-        if (on[u] && n_rows[u] > 0 && kind == POLICY_NONE) on[u] = false;  // (rows waiting for an evaluation that has not been made)
-        if (on[u]) root_n[u] = FW_A(u)[0].n;
-        if (on[u] && n_rows[u] > 0) {
-            const size_t go = (size_t)gg * L;
-            int top = f.top[gg];
+    // ---- 1. control blocks, values, Eng scalars -> LDS: one round trip for the whole wave --------------------------------
+    {
+        int creg[UT][NCR], ph[UT], top0[UT];
+        float vreg[UT][NVR];
+        BO_UNROLL
+        for (int u = 0; u < UT; u++) {
+            const bool in = FW_G(u) < G;
+            const int gg = in ? FW_G(u) : g0;
+            const int *ctl = fw_ctl(f, gg);
+            BO_UNROLL
+            for (int k = 0; k < NCR; k++) creg[u][k] = c + 32 * k < f.CS ? ctl[c + 32 * k] : 0;
+            BO_UNROLL
+            for (int k = 0; k < NVR; k++) vreg[u][k] = (kind != POLICY_NONE && c + 32 * k < L) ? value[(size_t)gg * L + c + 32 * k] : 0.0f;
+            ph[u] = in ? e.phase[gg] : PH_IDLE;
+            sims[u] = e.sims_done[gg];
+            done[u] = e.root_term[gg] != 0;
+        }
+        BO_UNROLL
+        for (int u = 0; u < UT; u++) {
+            BO_UNROLL
+            for (int k = 0; k < NCR; k++) FW_C(u, c + 32 * k) = creg[u][k];
+            BO_UNROLL
+            for (int k = 0; k < NVR; k++) s_val[FW_SLOT(u)][c + 32 * k] = vreg[u][k];
+        }
+        bo_wave_sync();
+        BO_UNROLL
+        for (int u = 0; u < UT; u++) {
+            const int gg = FW_G(u) < G ? FW_G(u) : g0;
+            n_rows[u] = FW_C(u, FWC_NROWS); n_step[u] = FW_C(u, FWC_NSTEP); top0[u] = FW_C(u, FWC_TOP);
+            on[u] = ph[u] == PH_RUN && !(n_rows[u] > 0 && kind == POLICY_NONE);  // (rows waiting for an evaluation that has not been made)
+            aoff[u] = (unsigned)(((size_t)(gg - g0) * 2 + (size_t)FW_C(u, FWC_CUR)) * (size_t)f.NG * BO_FW_GR);
+            busy[u] = false;
+            link[u] = -1; pn[u] = 1; d[u] = 1; M[u] = 0;
+            root_n[u] = 0; root_link[u] = -1;
+        }
+        // ---- 2. the previous step's rows have been applied: back their values up ------------------------------------------
+        WRec rootrec[UT];
+        bool bk[UT];
+        int maxstep = 0;
+        BO_UNROLL
+        for (int u = 0; u < UT; u++) {
+            rootrec[u].n = 0; rootrec[u].w = 0.0f; rootrec[u].prior = 0.0f; rootrec[u].link = FW_UNVISITED;
+            if (on[u]) rootrec[u] = fw_ld<false>(FW_A(u));  // (n is not touched by the backup below: the root only counts visits)
+            bk[u] = on[u] && n_rows[u] > 0;
+            if (bk[u] && n_step[u] > maxstep) maxstep = n_step[u];
+        }
+        int term_sims[UT], deep[UT];
+        BO_UNROLL
+        for (int u = 0; u < UT; u++) term_sims[u] = deep[u] = 0;
+        for (int s0 = 0; s0 < maxstep; s0 += BO_FW_BK_CH) {
+            int rec[UT][BO_FW_BK_CH];
+            bool val[UT][BO_FW_BK_CH];
+            float sgn[UT][BO_FW_BK_CH];
+            fw_nw x[UT][BO_FW_BK_CH];
+            BO_UNROLL
+            for (int u = 0; u < UT; u++) {
+                const int *sp = f.sim_path + (size_t)FW_G(u) * L * BO_FW_PATH_CAP;
+                BO_UNROLL
+                for (int j = 0; j < BO_FW_BK_CH; j++) {
+                    const int s = s0 + j;
+                    const bool ok = bk[u] && s < n_step[u];
+                    const int q = ok ? FW_C(u, FWC_F(L, FWS_ROW, s)) : FW_SIM_DRAW;
+                    const int plen = ok ? FW_C(u, FWC_F(L, FWS_PLEN, s)) : 0;
+                    float v;
+                    if (q >= 0) {  // value[] is from the leaf's side to move; the player who moved into the leaf sees -v; a found terminal has its exact value
+                        const int t = FW_C(u, FWC_F(L, FWR_TERM, q));
+                        v = t > 0 ? (t == 1 ? 1.0f : 0.0f) : -s_val[FW_SLOT(u)][q];
+                        term_sims[u] += (ok && t > 0) ? 1 : 0;
+                    } else {
+                        v = q == FW_SIM_MATE ? 1.0f : 0.0f;
+                        term_sims[u] += ok ? 1 : 0;
+                    }
+                    if (plen > 32) deep[u] = 1;
+                    val[u][j] = c >= 1 && c < plen;  // the root (depth 0) only counts visits
+                    sgn[u][j] = ((plen - 1 - c) & 1) ? -v : v;
+                    rec[u][j] = val[u][j] ? sp[(size_t)s * BO_FW_PATH_CAP + c] : 0;
+                }
+            }
+            BO_UNROLL
+            for (int u = 0; u < UT; u++) {
+                BO_UNROLL
+                for (int j = 0; j < BO_FW_BK_CH; j++) {
+                    x[u][j].n = 0; x[u][j].w = 0.0f;
+                    if (val[u][j]) x[u][j] = fw_ld_nw(FW_A(u) + rec[u][j]);
+                }
+            }
+            BO_UNROLL
+            for (int u = 0; u < UT; u++) {
+                BO_UNROLL
+                for (int j = 0; j < BO_FW_BK_CH; j++) {
+                    if (!val[u][j]) continue;
+                    BO_UNROLL
+                    for (int i = 0; i < j; i++)
+                        if (val[u][i] && rec[u][i] == rec[u][j]) x[u][j] = x[u][i];  // (the latest earlier simulation through the same record wins)
+                    x[u][j].n = x[u][j].n + 1;
+                    x[u][j].w = x[u][j].w + sgn[u][j];
+                }
+                BO_UNROLL
+                for (int j = 0; j < BO_FW_BK_CH; j++)
+                    if (val[u][j]) fw_st_nw(FW_A(u) + rec[u][j], x[u][j].n, x[u][j].w);
+            }
+        }
+        BO_UNROLL
+        for (int u = 0; u < UT; u++) {
+            root_n[u] = rootrec[u].n; root_link[u] = rootrec[u].link;
+            if (!bk[u]) continue;
+            if (deep[u]) {  // path depths 32..63 (rare): one simulation at a time
+                const int *sp = f.sim_path + (size_t)FW_G(u) * L * BO_FW_PATH_CAP;
+                for (int s = 0; s < n_step[u]; s++) {
+                    const int q = FW_C(u, FWC_F(L, FWS_ROW, s)), plen = FW_C(u, FWC_F(L, FWS_PLEN, s)), k = c + 32;
+                    if (k >= plen) continue;
+                    float v;
+                    if (q >= 0) { const int t = FW_C(u, FWC_F(L, FWR_TERM, q)); v = t > 0 ? (t == 1 ? 1.0f : 0.0f) : -s_val[FW_SLOT(u)][q]; }
+                    else v = q == FW_SIM_MATE ? 1.0f : 0.0f;
+                    WRec *R = FW_A(u) + sp[(size_t)s * BO_FW_PATH_CAP + k];
+                    const fw_nw y = fw_ld_nw(R);
+                    fw_st_nw(R, y.n + 1, y.w + (((plen - 1 - k) & 1) ? -v : v));
+                }
+            }
+            int top = top0[u];
             for (int q = 0; q < n_rows[u]; q++) {
-                const int need = fw_row_need(f.row_term[go + q], f.row_nlegal[go + q]);
+                const int need = fw_row_need(FW_C(u, FWC_F(L, FWR_TERM, q)), FW_C(u, FWC_F(L, FWR_NLEGAL, q)));
                 if (top + need <= f.NG) top += need;  // (bo_k_fw_apply refused the runs that do not fit, in the same order)
             }
-            if (f.row_slot[go] == 0 && n_step[u] == 0) root_n[u] = 1;  // the root's own evaluation counts as its first visit
-            const int ts = fw_backup_game(FW_A(u), f.sim_row + go, f.sim_plen + go, f.sim_path + go * BO_FW_PATH_CAP, f.row_term + go, value + go,
-                                          n_step[u], c);
+            if (FW_C(u, FWC_F(L, FWR_SLOT, 0)) == 0 && n_step[u] == 0) root_n[u] = 1;  // the root's own evaluation counts as its first visit
             root_n[u] += n_step[u];
             sims[u] += n_step[u];
             n_rows[u] = n_step[u] = 0;
-            if (c == 0) { f.top[gg] = top; e.stat_term_sims[gg] += ts; }
+            if (c == 0) { FW_C(u, FWC_TOP) = top; FW_C(u, FWC_TERM) += term_sims[u]; }
         }
     }
     bo_sync();  // the backup's stores are complete before any descent reads the tree
 
-    // ---- 2. up to L descents per game; the tree is read-only from here on ------------------------------------------------
+    // ---- 3. up to L descents per game; the tree is read-only from here on ------------------------------------------------
+    // What changes once per level lives in registers (link, visits of the node being expanded, depth, the in-flight mask); what
+    // changes once per descent lives in LDS (the control block's row / simulation lists and the words below): ~13 registers per
+    // game in the loop, so that more games fit a SIMD's register file (bandwidth = runs in flight).
+    enum { ST_SIMS = 0, ST_ROOTN, ST_ROOTLINK, ST_LEVELS, ST_GRAN, ST_KIDS, ST_LASTLINK, ST_WORDS };
+    BO_SHARED int s_st[2 * UT][ST_WORDS];
+#define FW_ST(u, i) s_st[FW_SLOT(u)][(i)]
     BO_UNROLL
     for (int u = 0; u < UT; u++) {
+        if (c == 0) {
+            FW_ST(u, ST_SIMS) = sims[u]; FW_ST(u, ST_ROOTN) = root_n[u]; FW_ST(u, ST_ROOTLINK) = root_link[u];
+            FW_ST(u, ST_LEVELS) = 0; FW_ST(u, ST_GRAN) = 0; FW_ST(u, ST_KIDS) = 0; FW_ST(u, ST_LASTLINK) = -1;
+            FW_C(u, FWC_NROWS) = n_rows[u]; FW_C(u, FWC_NSTEP) = n_step[u];
+        }
         if (!on[u]) continue;
-        const int gg = FW_G(u);
-        root_link[u] = FW_A(u)[0].link;
-        if (e.root_term[gg] != 0 || (root_link[u] >= 0 && sims[u] >= S)) {
+        if (done[u] || (root_link[u] >= 0 && sims[u] >= S)) {
             done[u] = true;
         } else if (root_link[u] < 0) {  // root not expanded yet: its evaluation is row 0 (no simulation attached)
             if (c == 0) {
-                f.row_slot[(size_t)gg * L] = 0; f.row_plink[(size_t)gg * L] = -1; f.row_sim[(size_t)gg * L] = -1;
-                s_rowslot[half * UT + u][0] = 0;
+                FW_C(u, FWC_F(L, FWR_SLOT, 0)) = 0; FW_C(u, FWC_F(L, FWR_PLINK, 0)) = -1; FW_C(u, FWC_F(L, FWR_SIM, 0)) = -1;
+                FW_C(u, FWC_NROWS) = 1;
             }
-            n_rows[u] = 1;
         } else {
             busy[u] = true;
             link[u] = root_link[u]; pn[u] = root_n[u] + 1;
-            if (c == 0) s_path[half * UT + u][0] = 0;
+            if (c == 0) s_path[FW_SLOT(u)][0] = 0;
             if (ROOTC) {
                 const int nrec = fw_ngran(root_link[u]) * BO_FW_GR;
                 const WRec *R = FW_A(u) + (size_t)fw_first(root_link[u]) * BO_FW_GR;
                 WRec pad; pad.n = -1; pad.w = 0.0f; pad.prior = 0.0f; pad.link = FW_UNVISITED;
                 rr0[u] = c < nrec ? fw_ld<false>(R + c) : pad;
                 rr1[u] = c + 32 < nrec ? fw_ld<false>(R + c + 32) : pad;
-                lg[u] += fw_ngran(root_link[u]) << 12;
+                if (c == 0) FW_ST(u, ST_GRAN) = fw_ngran(root_link[u]);
             }
         }
     }
+    bo_wave_sync();
     bool any = false;
     BO_UNROLL
     for (int u = 0; u < UT; u++) any = any || busy[u];
@@ -395,7 +479,7 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
         any = false;
         BO_UNROLL
         for (int u = 0; u < UT; u++) {
-            const int slot = half * UT + u;
+            const int slot = FW_SLOT(u);
             const bool lv = busy[u];
             const int ngran = fw_ngran(link[u]), nrec = ngran * BO_FW_GR, first = fw_first(link[u]);
             const int dd = d[u] < BO_FW_PATH_CAP ? d[u] : BO_FW_PATH_CAP - 1;
@@ -420,19 +504,23 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
                 const float uu = t2 / (float)(1 + ne);                                                          \
                 const float qv = ne > 0 ? we / (float)ne : 0.0f;                                                \
                 const float sc = qv + uu;                                                                       \
-                kids[u]++;                                                                                      \
                 if (sc > best) { best = sc; bi = (idx); bne = ne; bl = (rec).link; }                            \
             }
             BO_FW_CAND(r0[u], c, cnt0)
             BO_FW_CAND(r1[u], c + 32, cnt1)
+            const uint64_t k0 = bo_ballot(lv && r0[u].n >= 0), k1 = bo_ballot(lv && r1[u].n >= 0);
+            int nk = __builtin_popcount((unsigned)(k0 >> hb)) + __builtin_popcount((unsigned)(k1 >> hb));  // children scanned at this level
             if (lv && nrec > 64) {  // a run of more than 64 records (rare: > 64 legal moves)
                 const WRec *R = FW_A(u) + (size_t)first * BO_FW_GR;
+                int extra = 0;
                 for (int i = 64 + c; i < nrec; i += 32) {
                     const WRec rx = fw_ld<false>(R + i);
                     int cntx = 0;
                     for (mask_t m = M[u]; m; m &= m - 1) cntx += s_idx[slot][fw_ctz(m)][dd] == i ? 1 : 0;
+                    extra += rx.n >= 0 ? 1 : 0;
                     BO_FW_CAND(rx, i, cntx)
                 }
+                if (extra) bo_atomic_add(&FW_ST(u, ST_KIDS), extra);
             }
 #undef BO_FW_CAND
             BO_FW_ARGMAX(__builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, best), 0)), BO_ROW_XCHG(bi, 0))
@@ -456,14 +544,18 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
                     const int b = fw_ctz(m);
                     if (s_idx[slot][b][dd] != (unsigned char)bi) M[u] &= ~((mask_t)1 << b);
                 }
-                lastlink[u] = link[u];
-                cur[u] = first * BO_FW_GR + bi;
-                if (c == 0) { s_idx[slot][n_step[u]][dd] = (unsigned char)bi; s_path[slot][dd] = cur[u]; }
-                lg[u] += 1 + ((ROOTC && d[u] == 1) ? 0 : (ngran << 12));
+                if (c == 0) {
+                    s_idx[slot][FW_C(u, FWC_NSTEP)][dd] = (unsigned char)bi;
+                    s_path[slot][dd] = first * BO_FW_GR + bi;
+                    FW_ST(u, ST_LASTLINK) = link[u];
+                    FW_ST(u, ST_LEVELS) += 1; FW_ST(u, ST_KIDS) += nk;
+                    if (!(ROOTC && d[u] == 1)) FW_ST(u, ST_GRAN) += ngran;
+                }
                 pn[u] = w_ne + 1;
                 d[u]++;
                 link[u] = w_l;
             }
+            bo_wave_sync();  // lane 0's words above are read by the other lanes below and in later iterations
             // ---- end of a descent? -----------------------------------------------------------------------------------
             const bool ended = lv && (link[u] < 0 || d[u] >= BO_FW_PATH_CAP);
             if (ended && link[u] >= 0) {  // path buffer full: the visit counts as a draw
@@ -472,11 +564,13 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
             }
             // a leaf another descent of this step already selected shares that descent's row
             const bool fresh = ended && link[u] == FW_UNVISITED;
-            const uint64_t h0 = bo_ballot(fresh && c < n_rows[u] && s_rowslot[slot][c < LCAP ? c : 0] == cur[u]);
-            const uint64_t h1 = LCAP > 32 ? bo_ballot(fresh && c + 32 < n_rows[u] && s_rowslot[slot][c + 32 < LCAP ? c + 32 : 0] == cur[u]) : 0ull;
+            // (every lane reads the words lane 0 rewrites below BEFORE the ballots: lock-step on the GPU, and the emulator's lanes run
+            //  one after another between two rendezvous)
+            const int n_rows_l = FW_C(u, FWC_NROWS), s = FW_C(u, FWC_NSTEP), lastlink_l = FW_ST(u, ST_LASTLINK);
+            const int leaf = s_path[slot][d[u] - 1 < BO_FW_PATH_CAP ? d[u] - 1 : BO_FW_PATH_CAP - 1];
+            const uint64_t h0 = bo_ballot(fresh && c < n_rows_l && FW_C(u, FWC_F(L, FWR_SLOT, c < LCAP ? c : 0)) == leaf);
+            const uint64_t h1 = LCAP > 32 ? bo_ballot(fresh && c + 32 < n_rows_l && FW_C(u, FWC_F(L, FWR_SLOT, c + 32 < LCAP ? c + 32 : 0)) == leaf) : 0ull;
             if (ended) {
-                const int gg = FW_G(u);
-                const size_t go = (size_t)gg * L;
                 const unsigned m0 = (unsigned)(h0 >> hb), m1 = (unsigned)(h1 >> hb);
                 int q;
                 if (link[u] == FW_MATE) q = FW_SIM_MATE;
@@ -484,71 +578,87 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
                 else if (m0) q = __builtin_ctz(m0);
                 else if (m1) q = 32 + __builtin_ctz(m1);
                 else {  // becomes NN row n_rows
-                    q = n_rows[u];
+                    q = n_rows_l;
                     if (c == 0) {
-                        s_rowslot[slot][q] = cur[u];
-                        f.row_slot[go + q] = cur[u]; f.row_plink[go + q] = lastlink[u]; f.row_sim[go + q] = n_step[u];
+                        FW_C(u, FWC_F(L, FWR_SLOT, q)) = leaf; FW_C(u, FWC_F(L, FWR_PLINK, q)) = lastlink_l; FW_C(u, FWC_F(L, FWR_SIM, q)) = s;
+                        FW_C(u, FWC_NROWS) = q + 1;
                     }
-                    n_rows[u]++;
                 }
-                const int s = n_step[u];
-                if (c == 0) { f.sim_row[go + s] = q; f.sim_plen[go + s] = d[u]; }
-                int *path = f.sim_path + (go + s) * BO_FW_PATH_CAP;
+                if (c == 0) { FW_C(u, FWC_F(L, FWS_ROW, s)) = q; FW_C(u, FWC_F(L, FWS_PLEN, s)) = d[u]; FW_C(u, FWC_NSTEP) = s + 1; }
+                int *path = f.sim_path + ((size_t)FW_G(u) * L + s) * BO_FW_PATH_CAP;
                 if (c < d[u]) path[c] = s_path[slot][c];
                 if (c + 32 < d[u]) path[c + 32] = s_path[slot][c + 32];
-                n_step[u] = s + 1;
-                if (n_step[u] < L && sims[u] + n_step[u] < S) {  // the game's next descent starts at the root
-                    link[u] = root_link[u]; pn[u] = root_n[u] + n_step[u] + 1; d[u] = 1; cur[u] = 0;
-                    M[u] = (mask_t)(((mask_t)1 << n_step[u]) - 1);
+                if (s + 1 < L && FW_ST(u, ST_SIMS) + s + 1 < S) {  // the game's next descent starts at the root
+                    link[u] = FW_ST(u, ST_ROOTLINK); pn[u] = FW_ST(u, ST_ROOTN) + s + 2; d[u] = 1;
+                    M[u] = (mask_t)(((mask_t)1 << (s + 1)) - 1);
                 } else {
                     busy[u] = false;
                 }
             }
+            bo_wave_sync();  // (the row / simulation lists in LDS)
             any = any || busy[u];
         }
     }
 
-    // ---- 3. a step of known-terminal hits only needs no evaluation: account for it now -----------------------------------
-    int pnodes[UT];
+    // ---- a step of known-terminal hits only needs no evaluation: account for it now ---------------------------------------
     bool allterm = false;
     BO_UNROLL
-    for (int u = 0; u < UT; u++) {
-        pnodes[u] = (lg[u] & 0xFFF) + n_step[u];  // a path holds the root and one node per level
-        allterm = allterm || (on[u] && n_rows[u] == 0 && n_step[u] > 0);
-    }
+    for (int u = 0; u < UT; u++) allterm = allterm || (on[u] && FW_C(u, FWC_NROWS) == 0 && FW_C(u, FWC_NSTEP) > 0);
     if (bo_ballot(allterm) != 0) {
         bo_sync();  // the paths written above are complete
         BO_UNROLL
         for (int u = 0; u < UT; u++) {
-            if (!(on[u] && n_rows[u] == 0 && n_step[u] > 0)) continue;
-            const size_t go = (size_t)FW_G(u) * L;
-            const int ts = fw_backup_game(FW_A(u), f.sim_row + go, f.sim_plen + go, f.sim_path + go * BO_FW_PATH_CAP, f.row_term + go, value + go,
-                                          n_step[u], c);
-            root_n[u] += n_step[u];
-            sims[u] += n_step[u];
-            n_step[u] = 0;
-            if (sims[u] >= S) done[u] = true;
-            if (c == 0) e.stat_term_sims[FW_G(u)] += ts;
-        }
-    }
-    BO_UNROLL
-    for (int u = 0; u < UT; u++) {
-        int k = kids[u];
-        for (int m = 1; m < 32; m <<= 1) k += bo_shfl_xor(k, m);
-        if (on[u] && c == 0) {
-            const int gg = FW_G(u);
-            FW_A(u)[0].n = root_n[u];
-            e.sims_done[gg] = sims[u]; e.phase[gg] = done[u] ? PH_DONE : PH_RUN;
-            f.n_rows[gg] = n_rows[u]; f.n_step[gg] = n_step[u];
-            e.req_node[gg] = n_rows[u] > 0 ? s_rowslot[half * UT + u][0] : -1;
-            if (lg[u]) {
-                e.stat_levels[gg] += lg[u] & 0xFFF; e.stat_children_scanned[gg] += k;
-                f.stat_gran[gg] += (unsigned long long)(lg[u] >> 12); f.stat_path_nodes[gg] += (unsigned long long)pnodes[u];
+            const int ns = FW_C(u, FWC_NSTEP);
+            const bool at = on[u] && FW_C(u, FWC_NROWS) == 0 && ns > 0;
+            if (at) {
+                const int *sp = f.sim_path + (size_t)FW_G(u) * L * BO_FW_PATH_CAP;
+                for (int s = 0; s < ns; s++) {  // (every simulation of the step hit a known terminal: exact values, no rows)
+                    const int q = FW_C(u, FWC_F(L, FWS_ROW, s)), plen = FW_C(u, FWC_F(L, FWS_PLEN, s));
+                    const float v = q == FW_SIM_MATE ? 1.0f : 0.0f;
+                    for (int k = c; k < plen; k += 32) {
+                        if (k == 0) continue;
+                        WRec *R = FW_A(u) + sp[(size_t)s * BO_FW_PATH_CAP + k];
+                        const fw_nw y = fw_ld_nw(R);
+                        fw_st_nw(R, y.n + 1, y.w + (((plen - 1 - k) & 1) ? -v : v));
+                    }
+                }
+                if (FW_ST(u, ST_SIMS) + ns >= S) done[u] = true;
+            }
+            bo_wave_sync();  // (every lane has read the words lane 0 rewrites now)
+            if (at && c == 0) {
+                FW_C(u, FWC_TERM) += ns; FW_C(u, FWC_PNODES) += ns;  // (their path nodes: counted with the levels below + one root each)
+                FW_ST(u, ST_ROOTN) += ns; FW_ST(u, ST_SIMS) += ns;
+                FW_C(u, FWC_NSTEP) = 0;
             }
         }
     }
+    // ---- 4. the control blocks go back ------------------------------------------------------------------------------------
+    BO_UNROLL
+    for (int u = 0; u < UT; u++) {
+        if (on[u] && c == 0) {
+            const int gg = FW_G(u), nr = FW_C(u, FWC_NROWS);
+            FW_A(u)[0].n = FW_ST(u, ST_ROOTN);
+            e.sims_done[gg] = FW_ST(u, ST_SIMS); e.phase[gg] = done[u] ? PH_DONE : PH_RUN;
+            e.req_node[gg] = nr > 0 ? FW_C(u, FWC_F(L, FWR_SLOT, 0)) : -1;
+            FW_C(u, FWC_LEVELS) += FW_ST(u, ST_LEVELS); FW_C(u, FWC_KIDS) += FW_ST(u, ST_KIDS);
+            FW_C(u, FWC_GRAN) += FW_ST(u, ST_GRAN);
+            FW_C(u, FWC_PNODES) += FW_ST(u, ST_LEVELS) + FW_C(u, FWC_NSTEP);  // a path holds the root and one node per level
+        }
+    }
+    bo_wave_sync();
+    BO_UNROLL
+    for (int u = 0; u < UT; u++) {
+        if (!on[u]) continue;
+        int *ctl = fw_ctl(f, FW_G(u));
+        BO_UNROLL
+        for (int k = 0; k < NCR; k++)
+            if (c + 32 * k < FWC_HEAD + FWR_FIELDS * L) ctl[c + 32 * k] = FW_C(u, c + 32 * k);
+    }
+#undef FW_ST
 #undef FW_G
 #undef FW_A
+#undef FW_SLOT
+#undef FW_C
 }
 #undef BO_FW_ARGMAX
 
@@ -579,25 +689,26 @@ BO_KERNEL void bo_k_fw_leaf(Eng e, FastW f, float *nn_in) {
     BO_SHARED int s_hg[BO_FW_PATH_CAP];
     BO_SHARED unsigned s_flags[BO_FW_PATH_CAP];
     const int L = f.L, g = bo_block() / L, r = bo_block() % L, lane = bo_lane();
-    if (e.phase[g] != PH_RUN || r >= f.n_rows[g]) return;
+    int *ctl = fw_ctl(f, g);
+    if (e.phase[g] != PH_RUN || r >= ctl[FWC_NROWS]) return;
     const size_t ro = (size_t)g * L + r;
     const WRec *A = fw_arena(f, g);
-    const int slot = f.row_slot[ro];
+    const int slot = ctl[FWC_F(L, FWR_SLOT, r)];
     float *row = nn_in + ro * BO_ROW;
     if (slot == 0) {  // the root: position, legal moves and outcome were prepared with the game stack (root_prepare)
         const DPos P = e.gpos[(size_t)g * e.c.PLY_CAP + e.ply[g]];
         const int n = e.root_nlegal[g];
         for (int j = lane; j < n; j += 64) f.row_moves[ro * BO_MAX_MOVES + j] = e.root_moves[(size_t)g * BO_MAX_MOVES + j];
-        if (lane == 0) { f.row_pos[ro] = P; f.row_nlegal[ro] = n; f.row_term[ro] = 0; bo_atomic_add(&e.stat_evals[g], 1); }
+        if (lane == 0) { f.row_pos[ro] = P; ctl[FWC_F(L, FWR_NLEGAL, r)] = n; ctl[FWC_F(L, FWR_TERM, r)] = 0; bo_atomic_add(&e.stat_evals[g], 1); }
         encode_leaf(e, g, row, P);
         return;
     }
-    const DPos P = make_move(fw_head(A, f.row_plink[ro])->pos, fw_moves(f, g)[slot]);
+    const DPos P = make_move(fw_head(A, ctl[FWC_F(L, FWR_PLINK, r)])->pos, fw_moves(f, g)[slot]);
     bool chk;
     const int n = bo_movegen(P, sh.moves, &chk);
-    const int s = f.row_sim[ro];
+    const int s = ctl[FWC_F(L, FWR_SIM, r)];
     const int *path = f.sim_path + ((size_t)g * L + s) * BO_FW_PATH_CAP;
-    const int d = f.sim_plen[(size_t)g * L + s] - 1;  // path[0..d], path[d] = this leaf
+    const int d = ctl[FWC_F(L, FWS_PLEN, s)] - 1;  // path[0..d], path[d] = this leaf
     const auto pos_of = [A](int ref) { return fw_head_at(A, ref)->pos; };  // chain refs >= 0: header granule of an ancestor's run
     const int t = terminal_eval_with(e, g, pos_of, P, sh.moves, n, chk, sh.moves2, sh.chain, [&]() {
         // ancestors path[k], k < d, are expanded: their positions head their runs.  Included while every move between
@@ -625,7 +736,7 @@ BO_KERNEL void bo_k_fw_leaf(Eng e, FastW f, float *nn_in) {
         bo_sync();
         return cnt;
     });
-    if (lane == 0) { f.row_pos[ro] = P; f.row_nlegal[ro] = n; f.row_term[ro] = t; }
+    if (lane == 0) { f.row_pos[ro] = P; ctl[FWC_F(L, FWR_NLEGAL, r)] = n; ctl[FWC_F(L, FWR_TERM, r)] = t; }
     if (t == 0) {
         for (int j = lane; j < n; j += 64) f.row_moves[ro * BO_MAX_MOVES + j] = sh.moves[j];
         encode_leaf(e, g, row, P);
@@ -649,7 +760,7 @@ BO_KERNEL void bo_k_fw_search_begin(Eng e, FastW f, const int *go, float *nn_in)
             c->prior = (float)((double)a + e.c.eps * nz[j]);
         }
     }
-    if (lane == 0) { e.phase[g] = PH_RUN; e.sims_done[g] = 0; f.n_rows[g] = 0; f.n_step[g] = 0; }
+    if (lane == 0) { e.phase[g] = PH_RUN; e.sims_done[g] = 0; fw_ctl(f, g)[FWC_NROWS] = 0; fw_ctl(f, g)[FWC_NSTEP] = 0; }
 }
 
 // fresh tree (one unexpanded root record in granule 0) for the game slots that were (re)set up
@@ -661,7 +772,11 @@ BO_KERNEL void bo_k_fw_reset(Eng e, FastW f, const int *slots) {
         c.n = lane == 0 ? 0 : -1; c.w = 0.0f; c.prior = lane == 0 ? 1.0f : 0.0f; c.link = FW_UNVISITED;
         A[lane] = c;
     }
-    if (lane == 0) { f.cur[g] = 0; f.top[g] = 1; f.n_rows[g] = 0; f.n_step[g] = 0; f.played_now[g] = 0; }
+    if (lane == 0) {
+        int *ctl = fw_ctl(f, g);
+        ctl[FWC_CUR] = 0; ctl[FWC_TOP] = 1; ctl[FWC_NROWS] = 0; ctl[FWC_NSTEP] = 0;
+        f.played_now[g] = 0;
+    }
     (void)e;
 }
 
@@ -671,7 +786,7 @@ BO_KERNEL void bo_k_fw_reroot(Eng e, FastW f, int reuse) {
     const int g = bo_block(), lane = bo_lane();
     const bo_mv m = (bo_mv)f.played_now[g];
     if (m == 0) return;
-    const int c0 = f.cur[g];
+    const int c0 = fw_ctl(f, g)[FWC_CUR];
     const WRec *S = f.arena + fw_arena_off(f, g, c0);
     const bo_mv *SM = f.amove + fw_arena_off(f, g, c0);
     WRec *D = f.arena + fw_arena_off(f, g, c0 ^ 1);
@@ -740,7 +855,7 @@ BO_KERNEL void bo_k_fw_reroot(Eng e, FastW f, int reuse) {
         #undef BO_FW_COPY_RUN
     }
     if (lane == 0) {
-        f.cur[g] = c0 ^ 1; f.top[g] = top; f.played_now[g] = 0;
+        fw_ctl(f, g)[FWC_CUR] = c0 ^ 1; fw_ctl(f, g)[FWC_TOP] = top; f.played_now[g] = 0;
         if (flags) e.status[g] |= flags;
     }
 }

@@ -19,6 +19,10 @@ static inline int rt_h2d_2d(void *d, size_t dpitch, const void *h, size_t hpitch
     for (size_t r = 0; r < height; r++) memcpy((char *)d + r * dpitch, (const char *)h + r * hpitch, width);
     return 0;
 }
+static inline int rt_d2h_2d(void *h, size_t hpitch, const void *d, size_t dpitch, size_t width, size_t height, void *) {
+    for (size_t r = 0; r < height; r++) memcpy((char *)h + r * hpitch, (const char *)d + r * dpitch, width);
+    return 0;
+}
 typedef int rt_event;  // (copies are synchronous on the emulator: an event has nothing to wait for)
 static inline int rt_event_create(rt_event *) { return 0; }
 static inline int rt_event_record(rt_event, void *) { return 0; }
@@ -40,6 +44,9 @@ static inline int rt_host_alloc(void **p, size_t n) { return (int)hipHostMalloc(
 static inline void rt_host_free(void *p) { (void)hipHostFree(p); }
 static inline int rt_h2d_2d(void *d, size_t dpitch, const void *h, size_t hpitch, size_t width, size_t height, void *s) {
     return (int)hipMemcpy2DAsync(d, dpitch, h, hpitch, width, height, hipMemcpyHostToDevice, (hipStream_t)s);
+}
+static inline int rt_d2h_2d(void *h, size_t hpitch, const void *d, size_t dpitch, size_t width, size_t height, void *s) {
+    return (int)hipMemcpy2DAsync(h, hpitch, d, dpitch, width, height, hipMemcpyDeviceToHost, (hipStream_t)s);
 }
 typedef hipEvent_t rt_event;
 static inline int rt_event_create(rt_event *ev) { return (int)hipEventCreateWithFlags(ev, hipEventDisableTiming); }

@@ -55,6 +55,18 @@ static inline int bo_row_xchg_emu(int v, int kind) {
 #define BO_ROW_XCHG(v, kind) bo_row_xchg_emu((v), (kind))
 #endif
 
+// A hand-over between lanes of ONE wave through LDS (one lane writes, others read later): the hardware executes a wave's LDS
+// operations in order, so all that is needed is that the compiler does not move the accesses across this point.  (The
+// emulator runs its lanes one after another up to the next rendezvous: there it is one.)  Call in wave-uniform control flow.
+#if defined(BO_WAVE_EMU)
+BO_DEV void bo_wave_sync() { bo_emu::rendezvous(); }
+#else
+BO_DEV void bo_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+#endif
+
 // ---- derived primitives (identical in both builds) ---------------------------------------------
 BO_DEV float bo_shfl_f(float v, int src) { return __builtin_bit_cast(float, bo_shfl(__builtin_bit_cast(int, v), src)); }
 BO_DEV float bo_shfl_xor_f(float v, int m) { return __builtin_bit_cast(float, bo_shfl_xor(__builtin_bit_cast(int, v), m)); }

@@ -40,7 +40,7 @@ class BoConfig(C.Structure):
     _fields_ = [("n_games", C.c_int32), ("num_simulations", C.c_int32), ("mcts_batch_size", C.c_int32),
                 ("max_plies", C.c_int32), ("cpuct", C.c_double), ("widen_coeff", C.c_double),
                 ("dirichlet_alpha", C.c_double), ("dirichlet_epsilon", C.c_double), ("mode", C.c_int32),
-                ("leaves_per_step", C.c_int32)]
+                ("leaves_per_step", C.c_int32), ("fast_arena_granules", C.c_int32)]
 
 
 class BoPosition(C.Structure):
@@ -85,6 +85,7 @@ _SYMBOLS = {
     "bo_selfplay_begin": (C.c_int, [C.c_void_p, _I32P, C.c_void_p, _I32P, _I32P, _I32P, C.c_void_p]),
     "bo_records_encode": (C.c_int, [C.c_int, C.POINTER(BoPosition), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bo_debug_tree": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BoNode), C.c_int32, _I32P, C.c_void_p]),
+    "bo_debug_fast": (C.c_int, [C.c_void_p, C.c_int, _I32P, C.c_int32, _I32P, C.c_void_p]),
     "bo_fast_options": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "bo_fast_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _I32P, C.c_int32, _F64P, C.POINTER(C.c_int64),
                                C.c_void_p]),
@@ -195,12 +196,12 @@ class Engine:
 
     def __init__(self, n_games: int, num_simulations: int = 250, mcts_batch_size: int = 96, cpuct: float = 1.0,
                  widen_coeff: float = 1.5, dirichlet_alpha: float = 0.1, dirichlet_epsilon: float = 0.25,
-                 max_plies: int = 1024, device: int = 0, fast: bool = False, leaves_per_step: int = 8):
+                 max_plies: int = 1024, device: int = 0, fast: bool = False, leaves_per_step: int = 8, fast_arena_granules: int = 0):
         self.lib = load_hip_library()
         self.G = int(n_games)
         self.fast, self.L = bool(fast), int(leaves_per_step) if fast else 1
         self.cfg = BoConfig(n_games, num_simulations, mcts_batch_size, max_plies, cpuct, widen_coeff, dirichlet_alpha,
-                            dirichlet_epsilon, 1 if fast else 0, self.L)
+                            dirichlet_epsilon, 1 if fast else 0, self.L, int(fast_arena_granules))
         self.rows = self.G * self.L  # rows of the NN tensors
         self.num_simulations, self.dirichlet_alpha = num_simulations, dirichlet_alpha
         h = C.c_void_p()
@@ -399,6 +400,19 @@ class Engine:
                                              -1 if select_flags is None else int(select_flags)))
 
     SEL_NT, SEL_ROOT_IN_REGS, SEL_DENSE = 1, 2, 4
+    def debug_fast(self, slot: int, stream: int = 0):
+        """(control block of game `slot` as a dict of its fields, paths [L, 64] of the step's simulations) -- bo_debug_fast."""
+        L = self.L
+        cs = (16 + 7 * L + 31) // 32 * 32
+        ctl, paths = np.zeros(cs, np.int32), np.zeros((L, 64), np.int32)
+        self._check(self.lib.bo_debug_fast(self.h, slot, _p(ctl), cs, _p(paths), stream))
+        names = ["row_slot", "row_plink", "row_nlegal", "row_term", "row_sim", "sim_row", "sim_plen"]
+        out = dict(n_rows=int(ctl[0]), n_step=int(ctl[1]), cur=int(ctl[2]), top=int(ctl[3]), levels=int(ctl[4]), kids=int(ctl[5]),
+                   granules=int(ctl[6]), path_nodes=int(ctl[7]), term_sims=int(ctl[8]))
+        for i, nm in enumerate(names):
+            out[nm] = ctl[16 + i * L:16 + (i + 1) * L].copy()
+        return out, paths
+
     GRANULE_BYTES = 128  # BO_FAST_GRANULE_BYTES
 
     def fast_stats(self, stream: int = 0, time_select: int = -1) -> Dict[str, np.ndarray]:

@@ -101,7 +101,8 @@ class Rollout:
                  cpuct: float = 1.0, widen_coeff: float = 1.5, dirichlet_alpha: float = 0.1,
                  dirichlet_epsilon: float = 0.25, max_plies: Optional[int] = None, max_game_moves: int = 16384,
                  temperature=(30, 1.0, 0.1), device: str = "cuda:0", use_graph: bool = True, autocast: bool = False,
-                 rng_mode: str = "python", policy_kind: str = "logits", fast: bool = False, leaves_per_step: int = 16):
+                 rng_mode: str = "python", policy_kind: str = "logits", fast: bool = False, leaves_per_step: int = 16,
+                 fast_arena_granules: int = 0):
         self.device = E.runtime_device(device)  # 'cuda' -> cuda:<current device>: engine, NN rows and model on ONE GPU
         self.G = int(n_games)
         self.S, self.B = int(num_simulations), int(mcts_batch_size)
@@ -115,7 +116,7 @@ class Rollout:
         dev_index = self.device.index if self.device.index is not None else 0
         self.eng = E.Engine(self.G, num_simulations=self.S, mcts_batch_size=self.B, cpuct=cpuct, widen_coeff=widen_coeff,
                             dirichlet_alpha=dirichlet_alpha, dirichlet_epsilon=dirichlet_epsilon, max_plies=max_plies,
-                            device=dev_index, fast=fast, leaves_per_step=leaves_per_step)
+                            device=dev_index, fast=fast, leaves_per_step=leaves_per_step, fast_arena_granules=fast_arena_granules)
         # fast=True: csrc/bo_fast.h (virtual loss, L leaves per game per step) -- NOT the reference's search semantics
         self.fast, self.L = bool(fast), self.eng.L
         self.nn_in = torch.zeros((self.G * self.L, E.INPUT_CHANNELS, 8, 8), dtype=torch.float32, device=self.device)

@@ -67,6 +67,9 @@ typedef struct {
                                  * virtual loss, leaves_per_step distinct leaves per game per step, full-width
                                  * expansion -- NOT the reference's semantics */
     int32_t leaves_per_step;    /* FAST mode: L (1..64); NN tensors then have n_games*L rows, row = g*L + r */
+    int32_t fast_arena_granules;/* FAST mode: 128-byte granules per game arena (there are two per game); 0 = default, 24 per possible
+                                 * expansion of this and the previous search (3 KB; a chess node's run takes ~6).  A run that does
+                                 * not fit is refused (BO_ST_NODE_OVERFLOW) and the search goes on with that leaf unexpanded. */
 } bo_config;
 
 /* A position as plain data.  bb: pawns, knights, bishops, rooks, queens, kings, white, black. */
@@ -219,6 +222,11 @@ int bo_fast_options(bo_engine *e, int32_t tree_reuse, int32_t games_per_halfwave
  * these are the algorithmic bytes of SURVEY.md section 8d), granules in use in the game's arena. */
 int bo_fast_stats(bo_engine *e, uint64_t *granules_read, uint64_t *path_nodes, int32_t *arena_granules, int32_t time_select, double *select_ms,
                   int64_t *select_launches, void *stream);
+/* FAST mode introspection (tests, profiling): game `slot`'s control block -- ctl_out [ctl_cap >= 16 + 7 * L rounded up to 32]:
+ * [0] rows, [1] simulations of the step in flight, [2] live arena, [3] granules in use, [4..8] counters, then from index 16
+ * seven arrays of L: row_slot, row_plink, row_nlegal, row_term, row_sim, sim_row, sim_plen (csrc/bo_fastw.h) -- and the paths of
+ * the step's simulations, paths_out [L][64] record ids root..leaf.  Either pointer may be NULL.  Synchronises. */
+int bo_debug_fast(bo_engine *e, int slot, int32_t *ctl_out, int32_t ctl_cap, int32_t *paths_out, void *stream);
 /* time_select: 1 / 0 switches timing of the select + backup kernel (bo_k_fw_select) with HIP events on its launch stream
  * on / off for the following EAGER bo_step calls (not while the stream is being captured), -1 leaves it as it is;
  * select_ms / select_launches return the time and the number of launches accumulated since it was switched on.  Any out
