@@ -267,7 +267,16 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
         rc |= e->alloc(&f.played_now, G); rc |= e->alloc(&f.row_pos, G * L);
         rc |= e->alloc(&f.row_moves, G * L * BO_MAX_MOVES);
         rc |= e->alloc(&f.sim_path, G * L * BO_FW_PATH_CAP);
+        float *st = nullptr, *rt = nullptr;
+        rc |= e->alloc(&st, (size_t)BO_FW_SQRT_TAB); rc |= e->alloc(&rt, (size_t)BO_FW_RCP_TAB);
         if (!rc) {
+            // RN(sqrt(n)) and RN(1 / k): the double result rounded once more is the correctly rounded binary32 one (53 >= 2 * 24 + 2)
+            std::vector<float> hs2(BO_FW_SQRT_TAB), hr2(BO_FW_RCP_TAB, 0.0f);
+            for (int n = 0; n < BO_FW_SQRT_TAB; n++) hs2[n] = (float)sqrt((double)n);
+            for (int k = 1; k < BO_FW_RCP_TAB; k++) hr2[k] = (float)(1.0 / (double)k);
+            rt_h2d(st, hs2.data(), hs2.size() * sizeof(float), nullptr); rt_h2d(rt, hr2.data(), hr2.size() * sizeof(float), nullptr);
+            rt_sync(nullptr);
+            f.sqrt_tab = st; f.rcp_tab = rt;
             rt_memset(f.ctl, 0, G * (size_t)f.CS * 4, nullptr);
             rt_memset(f.played_now, 0, G * 4, nullptr);
             d.played_now = f.played_now;

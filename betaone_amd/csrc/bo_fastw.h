@@ -54,6 +54,8 @@
 #define BO_FW_PATH_CAP 64     // deepest path of one descent
 #define BO_FW_LMAX 64         // leaves per game per step
 #define BO_FW_LINK_MASK 0xFFFFFF
+#define BO_FW_SQRT_TAB 4096   // FastW::sqrt_tab: RN(sqrt(n)) for the visit counts a PUCT scan usually sees
+#define BO_FW_RCP_TAB 256     // FastW::rcp_tab: RN(1 / k)
 #define FW_UNVISITED (-1)
 #define FW_MATE (-2)          // known terminal: the player who moved into the node delivered mate
 #define FW_DRAW (-3)
@@ -100,6 +102,7 @@ struct FastW {
     WRec *arena;               // [G][2][NG * GR]   (two arenas per game, side by side: re-rooting compacts from one into the other)
     bo_mv *amove;              // [G][2][NG * GR]   move of each record
     int *ctl;                  // [G][CS] control blocks
+    const float *sqrt_tab, *rcp_tab;  // [BO_FW_SQRT_TAB] RN(sqrt(n)); [BO_FW_RCP_TAB] RN(1 / k), entry 0 = 0
     DPos *row_pos;             // [G][L] position of row r's leaf
     bo_mv *row_moves;          // [G][L][256] its legal moves (python-chess order)
     int *sim_path;             // [G][L][PATH_CAP] record ids root..leaf (record id = granule * GR + index)
@@ -264,7 +267,9 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
     constexpr int BO_FW_BK_CH = UT >= 4 ? 2 : 4;  // simulations of a game whose backups are fetched together and chained in registers
     BO_SHARED int s_ctl[2 * UT][NCR * 32];                         // the games' control blocks
     BO_SHARED float s_val[2 * UT][NVR * 32];                       // values of the step's rows
-    BO_SHARED unsigned char s_idx[2 * UT][LCAP][BO_FW_PATH_CAP];   // child index chosen at depth d by descent s of the step
+    constexpr int NW = (LCAP + 3) / 4;
+    BO_SHARED unsigned s_idx[2 * UT][BO_FW_PATH_CAP][NW];         // child index chosen at depth d by descent s of the step: byte s of the depth's words
+    BO_SHARED float s_rcp[BO_FW_RCP_TAB];                          // RN(1 / k)
     BO_SHARED int s_path[2 * UT][BO_FW_PATH_CAP];                  // record ids of the descent in progress
     const int lane = bo_lane(), half = lane >> 5, c = lane & 31, hb = half << 5;
     const int L = f.L, S = e.c.S, G = e.c.G;
@@ -284,6 +289,7 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
 #define FW_C(u, i) s_ctl[FW_SLOT(u)][(i)]
 
     // ---- 1. control blocks, values, Eng scalars -> LDS: one round trip for the whole wave --------------------------------
+    for (int i = lane; i < BO_FW_RCP_TAB; i += 64) s_rcp[i] = f.rcp_tab[i];
     {
         int creg[UT][NCR], ph[UT], top0[UT];
         float vreg[UT][NVR];
@@ -456,97 +462,128 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
     bool any = false;
     BO_UNROLL
     for (int u = 0; u < UT; u++) any = any || busy[u];
+    // The level loop is written branch-free (predicated arithmetic, clamped addresses): as divergent if-blocks it compiled to ~850
+    // issued instructions per game and level, two thirds of them exec-mask bookkeeping, and -- worse -- every conditional load was
+    // waited for inside its own block, so the games' runs were fetched one after the other instead of together.
     while (bo_ballot(any) != 0) {
         WRec r0[UT], r1[UT];
-        // every game's run is requested before any is consumed
+        float sqt[UT];
+        // every game's run is requested before any is consumed: unconditional loads from clamped addresses (a lane beyond the run
+        // re-reads its first record: the same cache line, no traffic), the validity masks are applied afterwards
         BO_UNROLL
         for (int u = 0; u < UT; u++) {
-            WRec pad; pad.n = -1; pad.w = 0.0f; pad.prior = 0.0f; pad.link = FW_UNVISITED;
-            r0[u] = pad; r1[u] = pad;
-            if (busy[u]) {
-                const int nrec = fw_ngran(link[u]) * BO_FW_GR;
-                const WRec *R = FW_A(u) + (size_t)fw_first(link[u]) * BO_FW_GR;
-                if (ROOTC && d[u] == 1) { r0[u] = rr0[u]; r1[u] = rr1[u]; }
-                else if (NT && d[u] > 1) {
-                    if (c < nrec) r0[u] = fw_ld<true>(R + c);
-                    if (c + 32 < nrec) r1[u] = fw_ld<true>(R + c + 32);
-                } else {
-                    if (c < nrec) r0[u] = fw_ld<false>(R + c);
-                    if (c + 32 < nrec) r1[u] = fw_ld<false>(R + c + 32);
-                }
-            }
+            const int lk = busy[u] ? link[u] : 0;  // (an idle game: granule 0 of its arena, always there)
+            const int nrec = fw_ngran(lk) * BO_FW_GR;
+            const WRec *R = FW_A(u) + (size_t)(ROOTC && d[u] == 1 ? 0 : fw_first(lk)) * BO_FW_GR;
+            const int i0 = (c < nrec && !(ROOTC && d[u] == 1)) ? c : 0, i1 = (c + 32 < nrec && !(ROOTC && d[u] == 1)) ? c + 32 : 0;
+            r0[u] = fw_ld<NT>(R + i0);
+            r1[u] = fw_ld<NT>(R + i1);
+            sqt[u] = f.sqrt_tab[pn[u] < BO_FW_SQRT_TAB ? pn[u] : 0];
         }
         any = false;
         BO_UNROLL
         for (int u = 0; u < UT; u++) {
             const int slot = FW_SLOT(u);
             const bool lv = busy[u];
-            const int ngran = fw_ngran(link[u]), nrec = ngran * BO_FW_GR, first = fw_first(link[u]);
+            const int lk = lv ? link[u] : 0;
+            const int ngran = fw_ngran(lk), nrec = ngran * BO_FW_GR, first = fw_first(lk);
             const int dd = d[u] < BO_FW_PATH_CAP ? d[u] : BO_FW_PATH_CAP - 1;
-            const float sq = sqrtf((float)pn[u]);
-            float best = -__builtin_inff();
-            int bi = 0x7fffffff, bne = 0, bl = FW_UNVISITED;
-            // descents of this step in flight through this lane's candidates (those that share the whole path so far)
+            if (ROOTC && d[u] == 1) { r0[u] = rr0[u]; r1[u] = rr1[u]; }
+            float sq = sqt[u];
+            if (pn[u] >= BO_FW_SQRT_TAB) sq = sqrtf((float)pn[u]);  // (beyond the table: rare)
+            // descents of this step in flight through this lane's candidates: those that share the whole path so far (mask M) and
+            // chose this lane's child at this depth (one byte per descent and depth, LCAP bytes = NW words per depth)
+            unsigned iw[NW];
+            BO_UNROLL
+            for (int w = 0; w < NW; w++) iw[w] = s_idx[slot][dd][w];
             int cnt0 = 0, cnt1 = 0;
-            if (lv)
-                for (mask_t m = M[u]; m; m &= m - 1) {
-                    const int b = s_idx[slot][fw_ctz(m)][dd];
-                    cnt0 += b == c ? 1 : 0;
-                    cnt1 += b == c + 32 ? 1 : 0;
-                }
-            // one candidate record: its statistics with the descents in flight through it, its PUCT score
-#define BO_FW_CAND(rec, idx, cnt)                                                                               \
-            if (lv && (rec).n >= 0) {                                                                           \
-                const int ne = (rec).n + (cnt);                                                                 \
+            BO_UNROLL
+            for (int sp = 0; sp < LCAP - 1; sp++) {
+                const int b = (int)((iw[sp >> 2] >> (8 * (sp & 3))) & 255u), in = (int)((M[u] >> sp) & 1);
+                cnt0 += in & (b == c ? 1 : 0);
+                cnt1 += in & (b == c + 32 ? 1 : 0);
+            }
+            // a candidate's PUCT score from its statistics with the descents in flight through it: q + u,
+            //   q = W_eff * rcp(n_eff)   u = (cpuct * P * sqrt(N)) * rcp(1 + n_eff)     rcp(k) = RN(1 / k): a table up to 255
+#define BO_FW_SCORE(rec, cnt, ok, sc, ne)                                                                       \
+            const int ne = (rec).n + (cnt);                                                                     \
+            float sc;                                                                                           \
+            {                                                                                                   \
                 const float we = (rec).w - (float)(cnt);                                                        \
+                float rq, ru;                                                                                   \
+                if (ne < BO_FW_RCP_TAB - 1) { rq = s_rcp[ne >= 0 ? ne : 0]; ru = s_rcp[ne >= 0 ? ne + 1 : 1]; } \
+                else { rq = 1.0f / (float)ne; ru = 1.0f / (float)(1 + ne); }                                    \
                 const float t1 = cpuct * (rec).prior;                                                           \
                 const float t2 = t1 * sq;                                                                       \
-                const float uu = t2 / (float)(1 + ne);                                                          \
-                const float qv = ne > 0 ? we / (float)ne : 0.0f;                                                \
-                const float sc = qv + uu;                                                                       \
-                if (sc > best) { best = sc; bi = (idx); bne = ne; bl = (rec).link; }                            \
+                const float uu = t2 * ru;                                                                       \
+                const float qv = ne > 0 ? we * rq : 0.0f;                                                       \
+                sc = qv + uu;                                                                                   \
+                sc = ((ok) && sc == sc) ? sc : -__builtin_inff();                                               \
             }
-            BO_FW_CAND(r0[u], c, cnt0)
-            BO_FW_CAND(r1[u], c + 32, cnt1)
-            const uint64_t k0 = bo_ballot(lv && r0[u].n >= 0), k1 = bo_ballot(lv && r1[u].n >= 0);
-            int nk = __builtin_popcount((unsigned)(k0 >> hb)) + __builtin_popcount((unsigned)(k1 >> hb));  // children scanned at this level
-            if (lv && nrec > 64) {  // a run of more than 64 records (rare: > 64 legal moves)
-                const WRec *R = FW_A(u) + (size_t)first * BO_FW_GR;
-                int extra = 0;
-                for (int i = 64 + c; i < nrec; i += 32) {
-                    const WRec rx = fw_ld<false>(R + i);
-                    int cntx = 0;
-                    for (mask_t m = M[u]; m; m &= m - 1) cntx += s_idx[slot][fw_ctz(m)][dd] == i ? 1 : 0;
-                    extra += rx.n >= 0 ? 1 : 0;
-                    BO_FW_CAND(rx, i, cntx)
+            const bool ok0 = lv && c < nrec && r0[u].n >= 0, ok1 = lv && c + 32 < nrec && r1[u].n >= 0;
+            BO_FW_SCORE(r0[u], cnt0, ok0, sc0, ne0)
+            BO_FW_SCORE(r1[u], cnt1, ok1, sc1, ne1)
+            float best = sc0;
+            int bi = c, bne = ne0, bl = r0[u].link;
+            if (sc1 > best) { best = sc1; bi = c + 32; bne = ne1; bl = r1[u].link; }
+            const uint64_t k0 = bo_ballot(ok0), k1 = bo_ballot(ok1);
+            const int nk = __builtin_popcount((unsigned)(k0 >> hb)) + __builtin_popcount((unsigned)(k1 >> hb));  // children scanned at this level
+            if (bo_ballot(lv && nrec > 64) != 0) {  // a run of more than 64 records somewhere in the wave (rare: > 64 legal moves)
+                if (lv && nrec > 64) {
+                    const WRec *R = FW_A(u) + (size_t)first * BO_FW_GR;
+                    int extra = 0;
+                    for (int i = 64 + c; i < nrec; i += 32) {
+                        const WRec rx = fw_ld<false>(R + i);
+                        int cntx = 0;
+                        BO_UNROLL
+                        for (int sp = 0; sp < LCAP - 1; sp++)
+                            cntx += (int)((M[u] >> sp) & 1) & ((int)((iw[sp >> 2] >> (8 * (sp & 3))) & 255u) == i ? 1 : 0);
+                        const bool okx = rx.n >= 0;
+                        extra += okx ? 1 : 0;
+                        BO_FW_SCORE(rx, cntx, okx, scx, nex)
+                        if (scx > best) { best = scx; bi = i; bne = nex; bl = rx.link; }
+                    }
+                    if (extra) bo_atomic_add(&FW_ST(u, ST_KIDS), extra);
                 }
-                if (extra) bo_atomic_add(&FW_ST(u, ST_KIDS), extra);
             }
-#undef BO_FW_CAND
-            BO_FW_ARGMAX(__builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, best), 0)), BO_ROW_XCHG(bi, 0))
-            BO_FW_ARGMAX(__builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, best), 1)), BO_ROW_XCHG(bi, 1))
-            BO_FW_ARGMAX(__builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, best), 2)), BO_ROW_XCHG(bi, 2))
-            BO_FW_ARGMAX(__builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, best), 3)), BO_ROW_XCHG(bi, 3))
-            BO_FW_ARGMAX(bo_shfl_xor_f(best, 16), bo_shfl_xor(bi, 16))
-            bool nan_all = false;
-            if (bi >= nrec) {  // every score was NaN: take the first child (it exists: a run is never empty)
-                nan_all = true;
-                bi = 0;
-                if (c == 0) { bne = r0[u].n; bl = r0[u].link; }  // (in-flight visits are not added here: the search is broken anyway)
+#undef BO_FW_SCORE
+            // first maximum in child order within the half-wave: the maximum by four DPP row rounds and one cross-row exchange, then
+            // the lowest child index among the lanes that hold it (a lane's index is lane + 32 * pass: lowest pass first, then lowest lane)
+            float mx = best;
+            BO_UNROLL
+            for (int kind_ = 0; kind_ < 4; kind_++) {
+                const float o = __builtin_bit_cast(float, kind_ == 0 ? BO_ROW_XCHG(__builtin_bit_cast(int, mx), 0) : kind_ == 1 ? BO_ROW_XCHG(__builtin_bit_cast(int, mx), 1)
+                                                                : kind_ == 2 ? BO_ROW_XCHG(__builtin_bit_cast(int, mx), 2) : BO_ROW_XCHG(__builtin_bit_cast(int, mx), 3));
+                mx = o > mx ? o : mx;
             }
-            // the winner's statistics come from the lane that scored it (index bi belongs to lane bi & 31, whose own best it is)
-            const int src = hb + (bi & 31);
+            { const float o = bo_shfl_xor_f(mx, 16); mx = o > mx ? o : mx; }
+            const bool top_ = lv && best == mx && mx > -__builtin_inff();
+            int win = -1;
+            {
+                const unsigned b0 = (unsigned)(bo_ballot(top_ && bi < 32) >> hb), b1 = (unsigned)(bo_ballot(top_ && bi < 64) >> hb);
+                if (b0) win = __builtin_ctz(b0);
+                else if (b1) win = 32 + __builtin_ctz(b1);
+            }
+            if (bo_ballot(lv && nrec > 64 && win < 0) != 0) {  // (the maximum sits beyond record 63)
+                for (int p = 2; p < 8; p++) {
+                    const unsigned bp = (unsigned)(bo_ballot(top_ && (bi >> 5) == p) >> hb);
+                    if (win < 0 && bp) win = 32 * p + __builtin_ctz(bp);
+                }
+            }
+            const bool nan_all = lv && win < 0;  // every score was NaN: take the first child (it exists: a run is never empty)
+            if (nan_all) { win = 0; if (c == 0) { bi = 0; bne = r0[u].n; bl = r0[u].link; } }  // (in-flight visits are not added here: the search is broken anyway)
+            // the winner's statistics come from the lane that scored it (index win belongs to lane win & 31, whose own best it is)
+            const int src = hb + (win & 31);
             const int w_ne = bo_shfl(bne, src);
             const int w_l = bo_shfl(bl, src);
             if (lv) {
                 if (nan_all && c == 0) bo_atomic_or(&e.status[FW_G(u)], ST_NAN_SCORE);
-                for (mask_t m = M[u]; m; m &= m - 1) {  // earlier descents that went elsewhere no longer share the path
-                    const int b = fw_ctz(m);
-                    if (s_idx[slot][b][dd] != (unsigned char)bi) M[u] &= ~((mask_t)1 << b);
-                }
+                BO_UNROLL
+                for (int sp = 0; sp < LCAP - 1; sp++)  // earlier descents that went elsewhere no longer share the path
+                    if ((int)((iw[sp >> 2] >> (8 * (sp & 3))) & 255u) != win) M[u] &= ~((mask_t)1 << sp);
                 if (c == 0) {
-                    s_idx[slot][FW_C(u, FWC_NSTEP)][dd] = (unsigned char)bi;
-                    s_path[slot][dd] = first * BO_FW_GR + bi;
+                    reinterpret_cast<unsigned char *>(&s_idx[slot][dd][0])[FW_C(u, FWC_NSTEP)] = (unsigned char)win;
+                    s_path[slot][dd] = first * BO_FW_GR + win;
                     FW_ST(u, ST_LASTLINK) = link[u];
                     FW_ST(u, ST_LEVELS) += 1; FW_ST(u, ST_KIDS) += nk;
                     if (!(ROOTC && d[u] == 1)) FW_ST(u, ST_GRAN) += ngran;
@@ -558,44 +595,47 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
             bo_wave_sync();  // lane 0's words above are read by the other lanes below and in later iterations
             // ---- end of a descent? -----------------------------------------------------------------------------------
             const bool ended = lv && (link[u] < 0 || d[u] >= BO_FW_PATH_CAP);
-            if (ended && link[u] >= 0) {  // path buffer full: the visit counts as a draw
-                link[u] = FW_DRAW;
-                if (c == 0) bo_atomic_or(&e.status[FW_G(u)], ST_DEPTH_OVERFLOW);
-            }
-            // a leaf another descent of this step already selected shares that descent's row
-            const bool fresh = ended && link[u] == FW_UNVISITED;
-            // (every lane reads the words lane 0 rewrites below BEFORE the ballots: lock-step on the GPU, and the emulator's lanes run
-            //  one after another between two rendezvous)
-            const int n_rows_l = FW_C(u, FWC_NROWS), s = FW_C(u, FWC_NSTEP), lastlink_l = FW_ST(u, ST_LASTLINK);
-            const int leaf = s_path[slot][d[u] - 1 < BO_FW_PATH_CAP ? d[u] - 1 : BO_FW_PATH_CAP - 1];
-            const uint64_t h0 = bo_ballot(fresh && c < n_rows_l && FW_C(u, FWC_F(L, FWR_SLOT, c < LCAP ? c : 0)) == leaf);
-            const uint64_t h1 = LCAP > 32 ? bo_ballot(fresh && c + 32 < n_rows_l && FW_C(u, FWC_F(L, FWR_SLOT, c + 32 < LCAP ? c + 32 : 0)) == leaf) : 0ull;
-            if (ended) {
-                const unsigned m0 = (unsigned)(h0 >> hb), m1 = (unsigned)(h1 >> hb);
-                int q;
-                if (link[u] == FW_MATE) q = FW_SIM_MATE;
-                else if (link[u] == FW_DRAW) q = FW_SIM_DRAW;
-                else if (m0) q = __builtin_ctz(m0);
-                else if (m1) q = 32 + __builtin_ctz(m1);
-                else {  // becomes NN row n_rows
-                    q = n_rows_l;
-                    if (c == 0) {
-                        FW_C(u, FWC_F(L, FWR_SLOT, q)) = leaf; FW_C(u, FWC_F(L, FWR_PLINK, q)) = lastlink_l; FW_C(u, FWC_F(L, FWR_SIM, q)) = s;
-                        FW_C(u, FWC_NROWS) = q + 1;
+            if (bo_ballot(ended) != 0) {
+                if (ended && link[u] >= 0) {  // path buffer full: the visit counts as a draw
+                    link[u] = FW_DRAW;
+                    if (c == 0) bo_atomic_or(&e.status[FW_G(u)], ST_DEPTH_OVERFLOW);
+                }
+                // a leaf another descent of this step already selected shares that descent's row
+                // (every lane reads the words lane 0 rewrites below BEFORE the ballots: lock-step on the GPU, and the emulator's lanes
+                //  run one after another between two rendezvous)
+                const bool fresh = ended && link[u] == FW_UNVISITED;
+                const int n_rows_l = FW_C(u, FWC_NROWS), s = FW_C(u, FWC_NSTEP), lastlink_l = FW_ST(u, ST_LASTLINK);
+                const int leaf = s_path[slot][d[u] - 1 < BO_FW_PATH_CAP ? d[u] - 1 : BO_FW_PATH_CAP - 1];
+                const int sims_l = FW_ST(u, ST_SIMS), rootlink_l = FW_ST(u, ST_ROOTLINK), rootn_l = FW_ST(u, ST_ROOTN);
+                const uint64_t h0 = bo_ballot(fresh && c < n_rows_l && FW_C(u, FWC_F(L, FWR_SLOT, c < LCAP ? c : 0)) == leaf);
+                const uint64_t h1 = LCAP > 32 ? bo_ballot(fresh && c + 32 < n_rows_l && FW_C(u, FWC_F(L, FWR_SLOT, c + 32 < LCAP ? c + 32 : 0)) == leaf) : 0ull;
+                if (ended) {
+                    const unsigned m0 = (unsigned)(h0 >> hb), m1 = (unsigned)(h1 >> hb);
+                    int q;
+                    if (link[u] == FW_MATE) q = FW_SIM_MATE;
+                    else if (link[u] == FW_DRAW) q = FW_SIM_DRAW;
+                    else if (m0) q = __builtin_ctz(m0);
+                    else if (m1) q = 32 + __builtin_ctz(m1);
+                    else {  // becomes NN row n_rows
+                        q = n_rows_l;
+                        if (c == 0) {
+                            FW_C(u, FWC_F(L, FWR_SLOT, q)) = leaf; FW_C(u, FWC_F(L, FWR_PLINK, q)) = lastlink_l; FW_C(u, FWC_F(L, FWR_SIM, q)) = s;
+                            FW_C(u, FWC_NROWS) = q + 1;
+                        }
+                    }
+                    if (c == 0) { FW_C(u, FWC_F(L, FWS_ROW, s)) = q; FW_C(u, FWC_F(L, FWS_PLEN, s)) = d[u]; FW_C(u, FWC_NSTEP) = s + 1; }
+                    int *path = f.sim_path + ((size_t)FW_G(u) * L + s) * BO_FW_PATH_CAP;
+                    if (c < d[u]) path[c] = s_path[slot][c];
+                    if (c + 32 < d[u]) path[c + 32] = s_path[slot][c + 32];
+                    if (s + 1 < L && sims_l + s + 1 < S) {  // the game's next descent starts at the root
+                        link[u] = rootlink_l; pn[u] = rootn_l + s + 2; d[u] = 1;
+                        M[u] = (mask_t)(((mask_t)1 << (s + 1)) - 1);
+                    } else {
+                        busy[u] = false;
                     }
                 }
-                if (c == 0) { FW_C(u, FWC_F(L, FWS_ROW, s)) = q; FW_C(u, FWC_F(L, FWS_PLEN, s)) = d[u]; FW_C(u, FWC_NSTEP) = s + 1; }
-                int *path = f.sim_path + ((size_t)FW_G(u) * L + s) * BO_FW_PATH_CAP;
-                if (c < d[u]) path[c] = s_path[slot][c];
-                if (c + 32 < d[u]) path[c + 32] = s_path[slot][c + 32];
-                if (s + 1 < L && FW_ST(u, ST_SIMS) + s + 1 < S) {  // the game's next descent starts at the root
-                    link[u] = FW_ST(u, ST_ROOTLINK); pn[u] = FW_ST(u, ST_ROOTN) + s + 2; d[u] = 1;
-                    M[u] = (mask_t)(((mask_t)1 << (s + 1)) - 1);
-                } else {
-                    busy[u] = false;
-                }
+                bo_wave_sync();  // (the row / simulation lists in LDS)
             }
-            bo_wave_sync();  // (the row / simulation lists in LDS)
             any = any || busy[u];
         }
     }

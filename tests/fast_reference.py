@@ -113,8 +113,8 @@ class FastSearcher:
                         ne = ch.n + ch.fl
                         we = F(ch.w - F(ch.fl))
                         t2 = F(F(self.cp * ch.prior) * sq)
-                        u = F(t2 / F(1 + ne))
-                        qv = F(we / F(ne)) if ne > 0 else F(0.0)
+                        u = F(t2 * F(F(1.0) / F(1 + ne)))
+                        qv = F(we * F(F(1.0) / F(ne))) if ne > 0 else F(0.0)
                         sc = F(qv + u)
                         if sc > best:
                             best, bi = sc, ch
