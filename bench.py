@@ -313,7 +313,7 @@ def fast_select_sweep(ro, drv, steps=12):
     when the searches run out of simulations a ply is played in between)."""
     out = []
     for ut in (4, 2):
-        for fl in (0, 1, 2, 3, 4, 5):
+        for fl in (0, 2, 4):
             ro.eng.fast_options(games_per_halfwave=ut, select_flags=fl)
             r = fast_select_roofline(ro, drv, steps, f" u{ut} flags{fl}")
             if r:

@@ -423,19 +423,25 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
     bo_sync();  // the backup's stores are complete before any descent reads the tree
 
     // ---- 3. up to L descents per game; the tree is read-only from here on ------------------------------------------------
-    // What changes once per level lives in registers (link, visits of the node being expanded, depth, the in-flight mask); what
-    // changes once per descent lives in LDS (the control block's row / simulation lists and the words below): ~13 registers per
-    // game in the loop, so that more games fit a SIMD's register file (bandwidth = runs in flight).
-    enum { ST_SIMS = 0, ST_ROOTN, ST_ROOTLINK, ST_LEVELS, ST_GRAN, ST_KIDS, ST_LASTLINK, ST_WORDS };
+    // A launch lasts as long as ONE wave's chain of dependent levels (all waves run side by side), so the chain is kept short:
+    //   * what the next request needs lives in registers (link, visits of the node being expanded, depth, in-flight mask, the
+    //     root's link and visits, descents made / allowed); what only the bookkeeping needs lives in LDS;
+    //   * software pipeline: the moment a game's winner is known, the run behind it (or the root's, for the game's next descent) is
+    //     requested -- BEFORE the level's bookkeeping (path, in-flight bytes, row list, path store), which then runs under the
+    //     memory latency, as do the other games' levels (vmcnt counts in order: a game waits only for its own run);
+    //   * branch-free: predicated arithmetic and clamped addresses (as divergent if-blocks a level compiled to ~850 issued
+    //     instructions, two thirds of them exec-mask bookkeeping, and every conditional load was waited for inside its own block).
+    enum { ST_LEVELS = 0, ST_GRAN, ST_KIDS, ST_WORDS };
     BO_SHARED int s_st[2 * UT][ST_WORDS];
 #define FW_ST(u, i) s_st[FW_SLOT(u)][(i)]
+    int nmax[UT];  // descents this launch may make: min(L, S - sims)
     BO_UNROLL
     for (int u = 0; u < UT; u++) {
         if (c == 0) {
-            FW_ST(u, ST_SIMS) = sims[u]; FW_ST(u, ST_ROOTN) = root_n[u]; FW_ST(u, ST_ROOTLINK) = root_link[u];
-            FW_ST(u, ST_LEVELS) = 0; FW_ST(u, ST_GRAN) = 0; FW_ST(u, ST_KIDS) = 0; FW_ST(u, ST_LASTLINK) = -1;
+            FW_ST(u, ST_LEVELS) = 0; FW_ST(u, ST_GRAN) = 0; FW_ST(u, ST_KIDS) = 0;
             FW_C(u, FWC_NROWS) = n_rows[u]; FW_C(u, FWC_NSTEP) = n_step[u];
         }
+        nmax[u] = S - sims[u] < L ? S - sims[u] : L;
         if (!on[u]) continue;
         if (done[u] || (root_link[u] >= 0 && sims[u] >= S)) {
             done[u] = true;
@@ -459,27 +465,27 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
         }
     }
     bo_wave_sync();
+    WRec r0[UT], r1[UT];
+    float sqt[UT];
+    // request the run behind link[u] (unconditional loads from clamped addresses: a lane beyond the run re-reads its first record,
+    // the same cache line; an idle game reads granule 0 of its arena, always there) and the square root of the visits
+#define BO_FW_ISSUE(u)                                                                                                  \
+    {                                                                                                                   \
+        const bool cached_ = ROOTC && d[u] == 1;                                                                        \
+        const int lk_ = (busy[u] && !cached_) ? link[u] : 0;                                                            \
+        const int nrec_ = fw_ngran(lk_) * BO_FW_GR;                                                                     \
+        const WRec *R_ = FW_A(u) + (size_t)fw_first(lk_) * BO_FW_GR;                                                    \
+        r0[u] = fw_ld<NT>(R_ + (c < nrec_ ? c : 0));                                                                    \
+        r1[u] = fw_ld<NT>(R_ + (c + 32 < nrec_ ? c + 32 : 0));                                                          \
+        sqt[u] = f.sqrt_tab[pn[u] < BO_FW_SQRT_TAB ? pn[u] : 0];                                                        \
+    }
     bool any = false;
     BO_UNROLL
-    for (int u = 0; u < UT; u++) any = any || busy[u];
-    // The level loop is written branch-free (predicated arithmetic, clamped addresses): as divergent if-blocks it compiled to ~850
-    // issued instructions per game and level, two thirds of them exec-mask bookkeeping, and -- worse -- every conditional load was
-    // waited for inside its own block, so the games' runs were fetched one after the other instead of together.
+    for (int u = 0; u < UT; u++) {
+        any = any || busy[u];
+        BO_FW_ISSUE(u)
+    }
     while (bo_ballot(any) != 0) {
-        WRec r0[UT], r1[UT];
-        float sqt[UT];
-        // every game's run is requested before any is consumed: unconditional loads from clamped addresses (a lane beyond the run
-        // re-reads its first record: the same cache line, no traffic), the validity masks are applied afterwards
-        BO_UNROLL
-        for (int u = 0; u < UT; u++) {
-            const int lk = busy[u] ? link[u] : 0;  // (an idle game: granule 0 of its arena, always there)
-            const int nrec = fw_ngran(lk) * BO_FW_GR;
-            const WRec *R = FW_A(u) + (size_t)(ROOTC && d[u] == 1 ? 0 : fw_first(lk)) * BO_FW_GR;
-            const int i0 = (c < nrec && !(ROOTC && d[u] == 1)) ? c : 0, i1 = (c + 32 < nrec && !(ROOTC && d[u] == 1)) ? c + 32 : 0;
-            r0[u] = fw_ld<NT>(R + i0);
-            r1[u] = fw_ld<NT>(R + i1);
-            sqt[u] = f.sqrt_tab[pn[u] < BO_FW_SQRT_TAB ? pn[u] : 0];
-        }
         any = false;
         BO_UNROLL
         for (int u = 0; u < UT; u++) {
@@ -488,9 +494,8 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
             const int lk = lv ? link[u] : 0;
             const int ngran = fw_ngran(lk), nrec = ngran * BO_FW_GR, first = fw_first(lk);
             const int dd = d[u] < BO_FW_PATH_CAP ? d[u] : BO_FW_PATH_CAP - 1;
-            if (ROOTC && d[u] == 1) { r0[u] = rr0[u]; r1[u] = rr1[u]; }
-            float sq = sqt[u];
-            if (pn[u] >= BO_FW_SQRT_TAB) sq = sqrtf((float)pn[u]);  // (beyond the table: rare)
+            const bool atroot = d[u] == 1;
+            if (ROOTC && atroot) { r0[u] = rr0[u]; r1[u] = rr1[u]; }
             // descents of this step in flight through this lane's candidates: those that share the whole path so far (mask M) and
             // chose this lane's child at this depth (one byte per descent and depth, LCAP bytes = NW words per depth)
             unsigned iw[NW];
@@ -504,34 +509,40 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
                 cnt1 += in & (b == c + 32 ? 1 : 0);
             }
             // a candidate's PUCT score from its statistics with the descents in flight through it: q + u,
-            //   q = W_eff * rcp(n_eff)   u = (cpuct * P * sqrt(N)) * rcp(1 + n_eff)     rcp(k) = RN(1 / k): a table up to 255
-#define BO_FW_SCORE(rec, cnt, ok, sc, ne)                                                                       \
-            const int ne = (rec).n + (cnt);                                                                     \
+            //   q = W_eff * rcp(n_eff)   u = (cpuct * P * sqrt(N)) * rcp(1 + n_eff)     rcp(k) = RN(1 / k)
+            // rcp and sqrt come from tables; counts beyond them (rare) take ONE wave-uniform side path with the exact operations
+            const bool ok0 = lv && c < nrec && r0[u].n >= 0, ok1 = lv && c + 32 < nrec && r1[u].n >= 0;
+            const int ne0 = r0[u].n + cnt0, ne1 = r1[u].n + cnt1;
+            const int t0 = ne0 < 0 ? 0 : ne0 > BO_FW_RCP_TAB - 2 ? BO_FW_RCP_TAB - 2 : ne0, t1 = ne1 < 0 ? 0 : ne1 > BO_FW_RCP_TAB - 2 ? BO_FW_RCP_TAB - 2 : ne1;
+            float sq = sqt[u], rq0 = s_rcp[t0], ru0 = s_rcp[t0 + 1], rq1 = s_rcp[t1], ru1 = s_rcp[t1 + 1];
+            if (bo_ballot(lv && (pn[u] >= BO_FW_SQRT_TAB || (ok0 && ne0 > BO_FW_RCP_TAB - 2) || (ok1 && ne1 > BO_FW_RCP_TAB - 2))) != 0) {
+                if (pn[u] >= BO_FW_SQRT_TAB) sq = sqrtf((float)pn[u]);
+                if (ne0 > BO_FW_RCP_TAB - 2) { rq0 = 1.0f / (float)ne0; ru0 = 1.0f / (float)(1 + ne0); }
+                if (ne1 > BO_FW_RCP_TAB - 2) { rq1 = 1.0f / (float)ne1; ru1 = 1.0f / (float)(1 + ne1); }
+            }
+#define BO_FW_SCORE(rec, cnt, ne, rq, ru, ok, sc)                                                               \
             float sc;                                                                                           \
             {                                                                                                   \
                 const float we = (rec).w - (float)(cnt);                                                        \
-                float rq, ru;                                                                                   \
-                if (ne < BO_FW_RCP_TAB - 1) { rq = s_rcp[ne >= 0 ? ne : 0]; ru = s_rcp[ne >= 0 ? ne + 1 : 1]; } \
-                else { rq = 1.0f / (float)ne; ru = 1.0f / (float)(1 + ne); }                                    \
-                const float t1 = cpuct * (rec).prior;                                                           \
-                const float t2 = t1 * sq;                                                                       \
-                const float uu = t2 * ru;                                                                       \
-                const float qv = ne > 0 ? we * rq : 0.0f;                                                       \
+                const float t1_ = cpuct * (rec).prior;                                                          \
+                const float t2_ = t1_ * sq;                                                                     \
+                const float uu = t2_ * (ru);                                                                    \
+                const float qv = (ne) > 0 ? we * (rq) : 0.0f;                                                   \
                 sc = qv + uu;                                                                                   \
                 sc = ((ok) && sc == sc) ? sc : -__builtin_inff();                                               \
             }
-            const bool ok0 = lv && c < nrec && r0[u].n >= 0, ok1 = lv && c + 32 < nrec && r1[u].n >= 0;
-            BO_FW_SCORE(r0[u], cnt0, ok0, sc0, ne0)
-            BO_FW_SCORE(r1[u], cnt1, ok1, sc1, ne1)
-            float best = sc0;
-            int bi = c, bne = ne0, bl = r0[u].link;
-            if (sc1 > best) { best = sc1; bi = c + 32; bne = ne1; bl = r1[u].link; }
+            BO_FW_SCORE(r0[u], cnt0, ne0, rq0, ru0, ok0, sc0)
+            BO_FW_SCORE(r1[u], cnt1, ne1, rq1, ru1, ok1, sc1)
+            const bool second = sc1 > sc0;
+            float best = second ? sc1 : sc0;
+            int bi = second ? c + 32 : c, bne = second ? ne1 : ne0, bl = second ? r1[u].link : r0[u].link;
             const uint64_t k0 = bo_ballot(ok0), k1 = bo_ballot(ok1);
             const int nk = __builtin_popcount((unsigned)(k0 >> hb)) + __builtin_popcount((unsigned)(k1 >> hb));  // children scanned at this level
-            if (bo_ballot(lv && nrec > 64) != 0) {  // a run of more than 64 records somewhere in the wave (rare: > 64 legal moves)
+            const bool wide = bo_ballot(lv && nrec > 64) != 0;  // a run of more than 64 records somewhere in the wave (rare: > 64 legal moves)
+            int extra = 0;
+            if (wide) {
                 if (lv && nrec > 64) {
                     const WRec *R = FW_A(u) + (size_t)first * BO_FW_GR;
-                    int extra = 0;
                     for (int i = 64 + c; i < nrec; i += 32) {
                         const WRec rx = fw_ld<false>(R + i);
                         int cntx = 0;
@@ -539,116 +550,114 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
                         for (int sp = 0; sp < LCAP - 1; sp++)
                             cntx += (int)((M[u] >> sp) & 1) & ((int)((iw[sp >> 2] >> (8 * (sp & 3))) & 255u) == i ? 1 : 0);
                         const bool okx = rx.n >= 0;
+                        const int nex = rx.n + cntx;
+                        const float rqx = nex > 0 ? 1.0f / (float)nex : 0.0f, rux = 1.0f / (float)(1 + nex);
                         extra += okx ? 1 : 0;
-                        BO_FW_SCORE(rx, cntx, okx, scx, nex)
+                        BO_FW_SCORE(rx, cntx, nex, rqx, rux, okx, scx)
                         if (scx > best) { best = scx; bi = i; bne = nex; bl = rx.link; }
                     }
-                    if (extra) bo_atomic_add(&FW_ST(u, ST_KIDS), extra);
                 }
             }
 #undef BO_FW_SCORE
             // first maximum in child order within the half-wave: the maximum by four DPP row rounds and one cross-row exchange, then
             // the lowest child index among the lanes that hold it (a lane's index is lane + 32 * pass: lowest pass first, then lowest lane)
             float mx = best;
-            BO_UNROLL
-            for (int kind_ = 0; kind_ < 4; kind_++) {
-                const float o = __builtin_bit_cast(float, kind_ == 0 ? BO_ROW_XCHG(__builtin_bit_cast(int, mx), 0) : kind_ == 1 ? BO_ROW_XCHG(__builtin_bit_cast(int, mx), 1)
-                                                                : kind_ == 2 ? BO_ROW_XCHG(__builtin_bit_cast(int, mx), 2) : BO_ROW_XCHG(__builtin_bit_cast(int, mx), 3));
-                mx = o > mx ? o : mx;
-            }
+            { const float o = __builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, mx), 0)); mx = o > mx ? o : mx; }
+            { const float o = __builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, mx), 1)); mx = o > mx ? o : mx; }
+            { const float o = __builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, mx), 2)); mx = o > mx ? o : mx; }
+            { const float o = __builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, mx), 3)); mx = o > mx ? o : mx; }
             { const float o = bo_shfl_xor_f(mx, 16); mx = o > mx ? o : mx; }
             const bool top_ = lv && best == mx && mx > -__builtin_inff();
-            int win = -1;
-            {
-                const unsigned b0 = (unsigned)(bo_ballot(top_ && bi < 32) >> hb), b1 = (unsigned)(bo_ballot(top_ && bi < 64) >> hb);
-                if (b0) win = __builtin_ctz(b0);
-                else if (b1) win = 32 + __builtin_ctz(b1);
-            }
-            if (bo_ballot(lv && nrec > 64 && win < 0) != 0) {  // (the maximum sits beyond record 63)
+            const unsigned b0 = (unsigned)(bo_ballot(top_ && bi < 32) >> hb), b1 = (unsigned)(bo_ballot(top_ && bi < 64) >> hb);
+            int win = b0 ? __builtin_ctz(b0) : b1 ? 32 + __builtin_ctz(b1) : -1;
+            if (wide) {  // (the maximum may sit beyond record 63)
                 for (int p = 2; p < 8; p++) {
                     const unsigned bp = (unsigned)(bo_ballot(top_ && (bi >> 5) == p) >> hb);
                     if (win < 0 && bp) win = 32 * p + __builtin_ctz(bp);
                 }
             }
             const bool nan_all = lv && win < 0;  // every score was NaN: take the first child (it exists: a run is never empty)
-            if (nan_all) { win = 0; if (c == 0) { bi = 0; bne = r0[u].n; bl = r0[u].link; } }  // (in-flight visits are not added here: the search is broken anyway)
+            if (bo_ballot(nan_all) != 0) {
+                if (nan_all) {
+                    win = 0;
+                    if (c == 0) { bi = 0; bne = r0[u].n; bl = r0[u].link; bo_atomic_or(&e.status[FW_G(u)], ST_NAN_SCORE); }  // (no in-flight visits added: the search is broken anyway)
+                }
+            }
             // the winner's statistics come from the lane that scored it (index win belongs to lane win & 31, whose own best it is)
             const int src = hb + (win & 31);
             const int w_ne = bo_shfl(bne, src);
-            const int w_l = bo_shfl(bl, src);
-            if (lv) {
-                if (nan_all && c == 0) bo_atomic_or(&e.status[FW_G(u)], ST_NAN_SCORE);
-                BO_UNROLL
-                for (int sp = 0; sp < LCAP - 1; sp++)  // earlier descents that went elsewhere no longer share the path
-                    if ((int)((iw[sp >> 2] >> (8 * (sp & 3))) & 255u) != win) M[u] &= ~((mask_t)1 << sp);
-                if (c == 0) {
-                    reinterpret_cast<unsigned char *>(&s_idx[slot][dd][0])[FW_C(u, FWC_NSTEP)] = (unsigned char)win;
-                    s_path[slot][dd] = first * BO_FW_GR + win;
-                    FW_ST(u, ST_LASTLINK) = link[u];
-                    FW_ST(u, ST_LEVELS) += 1; FW_ST(u, ST_KIDS) += nk;
-                    if (!(ROOTC && d[u] == 1)) FW_ST(u, ST_GRAN) += ngran;
-                }
-                pn[u] = w_ne + 1;
-                d[u]++;
-                link[u] = w_l;
+            int w_l = bo_shfl(bl, src);
+            // ---- what this game requests next, and the request itself --------------------------------------------------------
+            const int old_link = link[u], old_d = d[u], s = n_step[u];
+            const bool over = lv && w_l >= 0 && old_d + 1 >= BO_FW_PATH_CAP;  // path buffer full: the visit counts as a draw
+            if (over) w_l = FW_DRAW;
+            const bool cont = lv && w_l >= 0, ended = lv && !cont, more = ended && s + 1 < nmax[u];
+            mask_t Mn = M[u];
+            BO_UNROLL
+            for (int sp = 0; sp < LCAP - 1; sp++)  // earlier descents that went elsewhere no longer share the path
+                Mn &= ~((mask_t)((int)((iw[sp >> 2] >> (8 * (sp & 3))) & 255u) != win ? 1 : 0) << sp);
+            link[u] = cont ? w_l : more ? root_link[u] : link[u];
+            pn[u] = cont ? w_ne + 1 : root_n[u] + s + 2;  // (a new descent: the root's visits, the step's earlier descents and this one)
+            d[u] = cont ? old_d + 1 : 1;
+            M[u] = cont ? Mn : (mask_t)(((mask_t)1 << (s + 1)) - 1);
+            n_step[u] = ended ? s + 1 : s;
+            busy[u] = cont || more;
+            BO_FW_ISSUE(u)
+            any = any || busy[u];
+            // ---- the level's bookkeeping, under the latency of the request above -------------------------------------------
+            const int leaf = first * BO_FW_GR + win;
+            if (lv && c == 0) {
+                reinterpret_cast<unsigned char *>(&s_idx[slot][dd][0])[s] = (unsigned char)win;
+                s_path[slot][dd] = leaf;
+                FW_ST(u, ST_LEVELS) += 1; FW_ST(u, ST_KIDS) += nk;
+                if (!(ROOTC && atroot)) FW_ST(u, ST_GRAN) += ngran;
             }
+            if (wide && extra) bo_atomic_add(&FW_ST(u, ST_KIDS), extra);
+            if (bo_ballot(over) != 0) { if (over && c == 0) bo_atomic_or(&e.status[FW_G(u)], ST_DEPTH_OVERFLOW); }
             bo_wave_sync();  // lane 0's words above are read by the other lanes below and in later iterations
-            // ---- end of a descent? -----------------------------------------------------------------------------------
-            const bool ended = lv && (link[u] < 0 || d[u] >= BO_FW_PATH_CAP);
-            if (bo_ballot(ended) != 0) {
-                if (ended && link[u] >= 0) {  // path buffer full: the visit counts as a draw
-                    link[u] = FW_DRAW;
-                    if (c == 0) bo_atomic_or(&e.status[FW_G(u)], ST_DEPTH_OVERFLOW);
-                }
+            if (bo_ballot(ended) != 0) {  // ---- end of a descent
                 // a leaf another descent of this step already selected shares that descent's row
                 // (every lane reads the words lane 0 rewrites below BEFORE the ballots: lock-step on the GPU, and the emulator's lanes
                 //  run one after another between two rendezvous)
-                const bool fresh = ended && link[u] == FW_UNVISITED;
-                const int n_rows_l = FW_C(u, FWC_NROWS), s = FW_C(u, FWC_NSTEP), lastlink_l = FW_ST(u, ST_LASTLINK);
-                const int leaf = s_path[slot][d[u] - 1 < BO_FW_PATH_CAP ? d[u] - 1 : BO_FW_PATH_CAP - 1];
-                const int sims_l = FW_ST(u, ST_SIMS), rootlink_l = FW_ST(u, ST_ROOTLINK), rootn_l = FW_ST(u, ST_ROOTN);
+                const bool fresh = ended && w_l == FW_UNVISITED;
+                const int n_rows_l = FW_C(u, FWC_NROWS);
                 const uint64_t h0 = bo_ballot(fresh && c < n_rows_l && FW_C(u, FWC_F(L, FWR_SLOT, c < LCAP ? c : 0)) == leaf);
                 const uint64_t h1 = LCAP > 32 ? bo_ballot(fresh && c + 32 < n_rows_l && FW_C(u, FWC_F(L, FWR_SLOT, c + 32 < LCAP ? c + 32 : 0)) == leaf) : 0ull;
                 if (ended) {
                     const unsigned m0 = (unsigned)(h0 >> hb), m1 = (unsigned)(h1 >> hb);
+                    const int plen = old_d + 1;
                     int q;
-                    if (link[u] == FW_MATE) q = FW_SIM_MATE;
-                    else if (link[u] == FW_DRAW) q = FW_SIM_DRAW;
+                    if (w_l == FW_MATE) q = FW_SIM_MATE;
+                    else if (w_l == FW_DRAW) q = FW_SIM_DRAW;
                     else if (m0) q = __builtin_ctz(m0);
                     else if (m1) q = 32 + __builtin_ctz(m1);
                     else {  // becomes NN row n_rows
                         q = n_rows_l;
                         if (c == 0) {
-                            FW_C(u, FWC_F(L, FWR_SLOT, q)) = leaf; FW_C(u, FWC_F(L, FWR_PLINK, q)) = lastlink_l; FW_C(u, FWC_F(L, FWR_SIM, q)) = s;
+                            FW_C(u, FWC_F(L, FWR_SLOT, q)) = leaf; FW_C(u, FWC_F(L, FWR_PLINK, q)) = old_link; FW_C(u, FWC_F(L, FWR_SIM, q)) = s;
                             FW_C(u, FWC_NROWS) = q + 1;
                         }
                     }
-                    if (c == 0) { FW_C(u, FWC_F(L, FWS_ROW, s)) = q; FW_C(u, FWC_F(L, FWS_PLEN, s)) = d[u]; FW_C(u, FWC_NSTEP) = s + 1; }
+                    if (c == 0) { FW_C(u, FWC_F(L, FWS_ROW, s)) = q; FW_C(u, FWC_F(L, FWS_PLEN, s)) = plen; FW_C(u, FWC_NSTEP) = s + 1; }
                     int *path = f.sim_path + ((size_t)FW_G(u) * L + s) * BO_FW_PATH_CAP;
-                    if (c < d[u]) path[c] = s_path[slot][c];
-                    if (c + 32 < d[u]) path[c + 32] = s_path[slot][c + 32];
-                    if (s + 1 < L && sims_l + s + 1 < S) {  // the game's next descent starts at the root
-                        link[u] = rootlink_l; pn[u] = rootn_l + s + 2; d[u] = 1;
-                        M[u] = (mask_t)(((mask_t)1 << (s + 1)) - 1);
-                    } else {
-                        busy[u] = false;
-                    }
+                    if (c < plen) path[c] = s_path[slot][c];
+                    if (c + 32 < plen) path[c + 32] = s_path[slot][c + 32];
                 }
                 bo_wave_sync();  // (the row / simulation lists in LDS)
             }
-            any = any || busy[u];
         }
     }
+#undef BO_FW_ISSUE
 
     // ---- a step of known-terminal hits only needs no evaluation: account for it now ---------------------------------------
     bool allterm = false;
     BO_UNROLL
-    for (int u = 0; u < UT; u++) allterm = allterm || (on[u] && FW_C(u, FWC_NROWS) == 0 && FW_C(u, FWC_NSTEP) > 0);
+    for (int u = 0; u < UT; u++) allterm = allterm || (on[u] && FW_C(u, FWC_NROWS) == 0 && n_step[u] > 0);
     if (bo_ballot(allterm) != 0) {
         bo_sync();  // the paths written above are complete
         BO_UNROLL
         for (int u = 0; u < UT; u++) {
-            const int ns = FW_C(u, FWC_NSTEP);
+            const int ns = n_step[u];
             const bool at = on[u] && FW_C(u, FWC_NROWS) == 0 && ns > 0;
             if (at) {
                 const int *sp = f.sim_path + (size_t)FW_G(u) * L * BO_FW_PATH_CAP;
@@ -662,14 +671,11 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
                         fw_st_nw(R, y.n + 1, y.w + (((plen - 1 - k) & 1) ? -v : v));
                     }
                 }
-                if (FW_ST(u, ST_SIMS) + ns >= S) done[u] = true;
+                root_n[u] += ns; sims[u] += ns; n_step[u] = 0;
+                if (sims[u] >= S) done[u] = true;
             }
             bo_wave_sync();  // (every lane has read the words lane 0 rewrites now)
-            if (at && c == 0) {
-                FW_C(u, FWC_TERM) += ns; FW_C(u, FWC_PNODES) += ns;  // (their path nodes: counted with the levels below + one root each)
-                FW_ST(u, ST_ROOTN) += ns; FW_ST(u, ST_SIMS) += ns;
-                FW_C(u, FWC_NSTEP) = 0;
-            }
+            if (at && c == 0) { FW_C(u, FWC_TERM) += ns; FW_C(u, FWC_PNODES) += ns; FW_C(u, FWC_NSTEP) = 0; }  // (their path nodes: one root each + the levels counted below)
         }
     }
     // ---- 4. the control blocks go back ------------------------------------------------------------------------------------
@@ -677,12 +683,12 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
     for (int u = 0; u < UT; u++) {
         if (on[u] && c == 0) {
             const int gg = FW_G(u), nr = FW_C(u, FWC_NROWS);
-            FW_A(u)[0].n = FW_ST(u, ST_ROOTN);
-            e.sims_done[gg] = FW_ST(u, ST_SIMS); e.phase[gg] = done[u] ? PH_DONE : PH_RUN;
+            FW_A(u)[0].n = root_n[u];
+            e.sims_done[gg] = sims[u]; e.phase[gg] = done[u] ? PH_DONE : PH_RUN;
             e.req_node[gg] = nr > 0 ? FW_C(u, FWC_F(L, FWR_SLOT, 0)) : -1;
             FW_C(u, FWC_LEVELS) += FW_ST(u, ST_LEVELS); FW_C(u, FWC_KIDS) += FW_ST(u, ST_KIDS);
             FW_C(u, FWC_GRAN) += FW_ST(u, ST_GRAN);
-            FW_C(u, FWC_PNODES) += FW_ST(u, ST_LEVELS) + FW_C(u, FWC_NSTEP);  // a path holds the root and one node per level
+            FW_C(u, FWC_PNODES) += FW_ST(u, ST_LEVELS) + n_step[u];  // a path holds the root and one node per level
         }
     }
     bo_wave_sync();
