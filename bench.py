@@ -271,11 +271,21 @@ def fast_select_measure(ro, drv, steps):
     drv.extra_steps = getattr(drv, "extra_steps", 0) + steps
     eng = ro.eng
     c0 = _fast_counters(eng)
+    prof = os.environ.get("BO_SELECT_PROFILE", "0") not in ("", "0")
+    if prof:
+        eng.profile(0, read=False)
+        eng.profile(1, read=False)  # (0 -> 1 clears the counters)
     eng.fast_stats(time_select=1)
     for _ in range(steps):
         ro._eval_and_step_eager()
     torch.cuda.synchronize(ro.device)
     fs1 = eng.fast_stats(time_select=0)
+    if prof:  # per-wave shader cycles of the kernel's phases (csrc/bo_fastw.h), averaged over the waves of these launches
+        pr = eng.profile(0).astype(np.float64).sum(axis=0)
+        w = max(1.0, pr[5])
+        print("[select profile] waves/launch %.0f  cycles per wave: ctl+backup %.0f | wait for the backup's stores %.0f | descents %.0f | tail %.0f | "
+              "level-loop iterations %.1f (%.0f cycles each)" % (w / max(1, steps), pr[0] / w, pr[1] / w, pr[2] / w, pr[3] / w, pr[4] / w, pr[2] / max(1.0, pr[4])),
+              file=sys.stderr, flush=True)
     c1 = _fast_counters(eng)
     launches = int(fs1["select_launches"])
     if launches == 0:

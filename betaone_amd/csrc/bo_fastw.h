@@ -288,6 +288,11 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
 #define FW_SLOT(u) (half * UT + (u))
 #define FW_C(u, i) s_ctl[FW_SLOT(u)][(i)]
 
+    // (bo_debug_profile: shader cycles of this wave's phases, added up per workgroup row: [0] control blocks + backup, [1] the wait for
+    //  the backup's stores, [2] descents, [3] tail, [4] level-loop iterations, [5] waves)
+    const unsigned long long t_0 = e.c.profile ? bo_clock() : 0ull;
+    unsigned long long t_1 = 0ull, t_2 = 0ull, t_3 = 0ull;
+    int n_iter = 0;
     // ---- 1. control blocks, values, Eng scalars -> LDS: one round trip for the whole wave --------------------------------
     for (int i = lane; i < BO_FW_RCP_TAB; i += 64) s_rcp[i] = f.rcp_tab[i];
     {
@@ -420,7 +425,9 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
             if (c == 0) { FW_C(u, FWC_TOP) = top; FW_C(u, FWC_TERM) += term_sims[u]; }
         }
     }
+    if (e.c.profile) t_1 = bo_clock();
     bo_sync();  // the backup's stores are complete before any descent reads the tree
+    if (e.c.profile) t_2 = bo_clock();
 
     // ---- 3. up to L descents per game; the tree is read-only from here on ------------------------------------------------
     // A launch lasts as long as ONE wave's chain of dependent levels (all waves run side by side), so the chain is kept short:
@@ -487,6 +494,7 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
     }
     while (bo_ballot(any) != 0) {
         any = false;
+        n_iter++;
         BO_UNROLL
         for (int u = 0; u < UT; u++) {
             const int slot = FW_SLOT(u);
@@ -648,6 +656,7 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
         }
     }
 #undef BO_FW_ISSUE
+    if (e.c.profile) t_3 = bo_clock();
 
     // ---- a step of known-terminal hits only needs no evaluation: account for it now ---------------------------------------
     bool allterm = false;
@@ -699,6 +708,11 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
         BO_UNROLL
         for (int k = 0; k < NCR; k++)
             if (c + 32 * k < FWC_HEAD + FWR_FIELDS * L) ctl[c + 32 * k] = FW_C(u, c + 32 * k);
+    }
+    if (e.c.profile && lane == 0) {
+        unsigned long long *pp = e.prof + (size_t)g0 * BO_PROF_SLOTS;
+        const unsigned long long t_4 = bo_clock();
+        pp[0] += t_1 - t_0; pp[1] += t_2 - t_1; pp[2] += t_3 - t_2; pp[3] += t_4 - t_3; pp[4] += (unsigned long long)n_iter; pp[5] += 1ull;
     }
 #undef FW_ST
 #undef FW_G
