@@ -465,6 +465,11 @@ extern "C" int bo_search_begin(bo_engine *e, const int32_t *go, const double *no
 static int launch_fw_select(bo_engine *e, const float *value_dev, int kind, void *stream) {
     const FastW &f = e->f;
     const int G = e->d.c.G, L = f.L;
+    if (L <= 4 && (f.sel_flags & FW_SEL_LANE)) {  // one lane per game (bo_fastw.h)
+        const int blocks = (G + 63) / 64;
+        if (f.sel_flags & FW_SEL_NT) return RT_LAUNCH(bo_k_fw_select_lane_nt, blocks, stream, e->d, e->f, value_dev, kind);
+        return RT_LAUNCH(bo_k_fw_select_lane, blocks, stream, e->d, e->f, value_dev, kind);
+    }
     const int ut = L > 16 ? 1 : (L > 8 && f.sel_ut > 2) ? 2 : L > 4 ? (L > 8 ? 2 : 4) : f.sel_ut;
     const int grid = (G + 2 * ut - 1) / (2 * ut);
 #define SEL(K) return RT_LAUNCH(K, grid, stream, e->d, e->f, value_dev, kind)
@@ -981,7 +986,7 @@ extern "C" int bo_fast_options(bo_engine *e, int32_t tree_reuse, int32_t games_p
         return fail(BO_E_ARG, "bo_fast_options: games_per_halfwave must be 1, 2 or 4");
     if (tree_reuse >= 0) e->fast_reuse = tree_reuse ? 1 : 0;
     if (games_per_halfwave >= 0) e->f.sel_ut = games_per_halfwave == 1 ? 2 : games_per_halfwave;  // (one game per half-wave is the form for more than 16 leaves per step)
-    if (select_flags >= 0) e->f.sel_flags = select_flags & (FW_SEL_NT | FW_SEL_ROOT_IN_REGS | FW_SEL_DENSE);
+    if (select_flags >= 0) e->f.sel_flags = select_flags & (FW_SEL_NT | FW_SEL_ROOT_IN_REGS | FW_SEL_DENSE | FW_SEL_LANE);
     return BO_OK;
 }
 

@@ -61,7 +61,7 @@
 #define FW_DRAW (-3)
 #define FW_SIM_MATE (-2)      // sim_row codes of simulations that ended in a known terminal (no NN row)
 #define FW_SIM_DRAW (-3)
-enum { FW_SEL_NT = 1, FW_SEL_ROOT_IN_REGS = 2, FW_SEL_DENSE = 4 };  // FastW::sel_flags
+enum { FW_SEL_NT = 1, FW_SEL_ROOT_IN_REGS = 2, FW_SEL_DENSE = 4, FW_SEL_LANE = 8 };  // FastW::sel_flags
 
 struct alignas(16) WRec {
     int n;        // visits; -1 = padding of a run's last granule, never selected
@@ -721,6 +721,265 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
 #undef FW_C
 }
 #undef BO_FW_ARGMAX
+
+// ---- select + backup, ONE LANE PER GAME (leaves_per_step <= 4) ---------------------------------------------------------------
+// Measured on the half-wave form above (bo_debug_profile, 32768 games x 4 descents on trees of 800 simulations per move): its
+// time is instruction issue, not memory -- ~250 issued instructions per game and level (cross-lane reductions, ballots, LDS
+// hand-overs between lanes, exec-mask bookkeeping) of which each serves two games.  Here a lane owns a game: no cross-lane
+// operation at all, a level's records are scored in a straight line of ~20 instructions each that serve 64 games at once (~16
+// issued instructions per game and level), 64 independent chains of dependent reads per wave, and -- every access to a game's
+// tree coming from one lane -- program order alone keeps the backup's stores in front of the descents' loads.  A lane reads a run
+// as 16-byte records of its own 128-byte granules: 64 lanes = 64 different lines per instruction, every line requested once
+// (the granule's eight loads are issued back to back and merge in the L1's miss queue).
+// The level loop is flat: every pass of the loop scores the next BO_FW_LANE_CH granules of each lane's current run; a lane
+// whose run is finished picks the winner, notes the level (path, in-flight byte) and goes on to the next run / the next
+// descent at once, whatever the other lanes are doing.  Same arithmetic and results as the half-wave form (same tests).
+#define BO_FW_LANE_CH 4  // granules (x 8 records x 4 registers) scored per pass
+template <bool NT>
+BO_DEV void fw_select_lane_body(const Eng &e, const FastW &f, const float *value, int kind) {
+    constexpr int LC = 4, NREC = BO_FW_LANE_CH * BO_FW_GR;
+    BO_SHARED unsigned s_idx[BO_FW_PATH_CAP][64];  // [depth][lane]: byte s = the child index descent s of the step chose at that depth
+    BO_SHARED float s_rcp[BO_FW_RCP_TAB];          // RN(1 / k)
+    const int lane = bo_lane(), L = f.L, S = e.c.S;
+    const int g = bo_block() * 64 + lane;
+    const unsigned long long t_0 = e.c.profile ? bo_clock() : 0ull;
+    for (int i = lane; i < BO_FW_RCP_TAB; i += 64) s_rcp[i] = f.rcp_tab[i];
+    bo_sync();
+    bool on = g < e.c.G && e.phase[g < e.c.G ? g : 0] == PH_RUN;
+    const int gg = g < e.c.G ? g : 0;
+    int *ctl = fw_ctl(f, gg);
+    int n_rows = ctl[FWC_NROWS], n_step = ctl[FWC_NSTEP];
+    if (n_rows > 0 && kind == POLICY_NONE) on = false;  // (rows waiting for an evaluation that has not been made)
+    WRec *A = f.arena + fw_arena_off(f, gg, ctl[FWC_CUR]);
+    int *sp = f.sim_path + (size_t)gg * L * BO_FW_PATH_CAP;
+    int sims = e.sims_done[gg], root_n = 0, root_link = FW_UNVISITED;
+    bool done = e.root_term[gg] != 0;
+    int rs[LC];  // leaf records of the step's rows
+    BO_UNROLL
+    for (int q = 0; q < LC; q++) rs[q] = -1;
+    int levels = 0, grans = 0, kids = 0, n_iter = 0;
+    unsigned long long t_1 = 0ull;
+    if (on) {
+        const WRec root = fw_ld<false>(A);
+        root_n = root.n; root_link = root.link;
+        // ---- the previous step's rows have been applied: back their values up ------------------------------------------------
+        if (n_rows > 0) {
+            int top = ctl[FWC_TOP], term_sims = 0, maxlen = 0;
+            for (int q = 0; q < n_rows; q++) {
+                const int need = fw_row_need(ctl[FWC_F(L, FWR_TERM, q)], ctl[FWC_F(L, FWR_NLEGAL, q)]);
+                if (top + need <= f.NG) top += need;  // (bo_k_fw_apply refused the runs that do not fit, in the same order)
+            }
+            float v[LC];
+            int plen[LC];
+            BO_UNROLL
+            for (int s = 0; s < LC; s++) {
+                const bool ok = s < n_step;
+                const int q = ok ? ctl[FWC_F(L, FWS_ROW, s < L ? s : 0)] : FW_SIM_DRAW;
+                plen[s] = ok ? ctl[FWC_F(L, FWS_PLEN, s < L ? s : 0)] : 0;
+                if (q >= 0) {  // value[] is from the leaf's side to move; the player who moved into the leaf sees -v; a found terminal has its exact value
+                    const int t = ctl[FWC_F(L, FWR_TERM, q)];
+                    v[s] = t > 0 ? (t == 1 ? 1.0f : 0.0f) : -value[(size_t)gg * L + q];
+                    term_sims += (ok && t > 0) ? 1 : 0;
+                } else {
+                    v[s] = q == FW_SIM_MATE ? 1.0f : 0.0f;
+                    term_sims += ok ? 1 : 0;
+                }
+                maxlen = plen[s] > maxlen ? plen[s] : maxlen;
+            }
+            // depth by depth, four depths at a time: the record ids of all simulations, then their (n, w), then the updates -- two
+            // round trips per four depths; simulations that share a record at a depth are chained in registers
+            for (int k0 = 1; k0 < maxlen; k0 += 4) {
+                int rec[4][LC];
+                bool val[4][LC];
+                fw_nw x[4][LC];
+                BO_UNROLL
+                for (int kk = 0; kk < 4; kk++) {
+                    BO_UNROLL
+                    for (int s = 0; s < LC; s++) {
+                        val[kk][s] = k0 + kk < plen[s];
+                        rec[kk][s] = val[kk][s] ? sp[(size_t)s * BO_FW_PATH_CAP + k0 + kk] : 0;
+                    }
+                }
+                BO_UNROLL
+                for (int kk = 0; kk < 4; kk++) {
+                    BO_UNROLL
+                    for (int s = 0; s < LC; s++) {
+                        x[kk][s].n = 0; x[kk][s].w = 0.0f;
+                        if (val[kk][s]) x[kk][s] = fw_ld_nw(A + rec[kk][s]);
+                    }
+                }
+                BO_UNROLL
+                for (int kk = 0; kk < 4; kk++) {
+                    BO_UNROLL
+                    for (int s = 0; s < LC; s++) {
+                        if (!val[kk][s]) continue;
+                        BO_UNROLL
+                        for (int i = 0; i < s; i++)
+                            if (val[kk][i] && rec[kk][i] == rec[kk][s]) x[kk][s] = x[kk][i];  // (the latest earlier simulation through the same record wins)
+                        x[kk][s].n = x[kk][s].n + 1;
+                        x[kk][s].w = x[kk][s].w + (((plen[s] - 1 - (k0 + kk)) & 1) ? -v[s] : v[s]);
+                    }
+                    BO_UNROLL
+                    for (int s = 0; s < LC; s++)
+                        if (val[kk][s]) fw_st_nw(A + rec[kk][s], x[kk][s].n, x[kk][s].w);
+                }
+            }
+            if (ctl[FWC_F(L, FWR_SLOT, 0)] == 0 && n_step == 0) root_n = 1;  // the root's own evaluation counts as its first visit
+            root_n += n_step;
+            sims += n_step;
+            n_rows = n_step = 0;
+            ctl[FWC_TOP] = top; ctl[FWC_TERM] += term_sims;
+        }
+        if (e.c.profile) t_1 = bo_clock();
+        // ---- up to L descents; this lane's loads below see its stores above (one thread, program order) ----------------------
+        const int nmax = S - sims < L ? S - sims : L;
+        bool busy = false;
+        if (done || (root_link >= 0 && sims >= S)) {
+            done = true;
+        } else if (root_link < 0) {  // root not expanded yet: its evaluation is row 0 (no simulation attached)
+            ctl[FWC_F(L, FWR_SLOT, 0)] = 0; ctl[FWC_F(L, FWR_PLINK, 0)] = -1; ctl[FWC_F(L, FWR_SIM, 0)] = -1;
+            rs[0] = 0;
+            n_rows = 1;
+        } else {
+            busy = true;
+        }
+        // state of the descent in progress
+        int link = root_link, pn = root_n + 1, d = 1, pass0 = 0;  // pass0: first record of the current pass within the run
+        unsigned M = 0u;
+        float best = -__builtin_inff(), sq = 0.0f;
+        int bi = -1, bne = 0, bl = FW_UNVISITED, fl0 = -1, fl1 = -1, fl2 = -1;  // in-flight child indices at this node (-1: none)
+        bool fresh_run = true;
+        if (busy) sp[0] = 0;
+        const float cpuct = e.c.cpuct;
+        while (busy) {
+            n_iter++;
+            const int first = fw_first(link), ngran = fw_ngran(link), nrec = ngran * BO_FW_GR;
+            if (fresh_run) {  // a new node: the descents in flight through its children, the square root of its visits
+                const unsigned iw = s_idx[d][lane];
+                fl0 = (M & 1u) ? (int)(iw & 255u) : -1;
+                fl1 = (M & 2u) ? (int)((iw >> 8) & 255u) : -1;
+                fl2 = (M & 4u) ? (int)((iw >> 16) & 255u) : -1;
+                sq = pn < BO_FW_SQRT_TAB ? f.sqrt_tab[pn] : sqrtf((float)pn);
+                best = -__builtin_inff(); bi = -1; bne = 0; bl = FW_UNVISITED;
+                fresh_run = false;
+            }
+            // this pass's granules, all requested before the first is used (a granule beyond the run: the run's last one again)
+            WRec r[NREC];
+            const WRec *R = A + (size_t)first * BO_FW_GR;
+            BO_UNROLL
+            for (int j = 0; j < NREC; j++) {
+                const int i = pass0 + j;
+                r[j] = fw_ld<NT>(R + (i < nrec ? i : nrec - 1));
+            }
+            BO_UNROLL
+            for (int j = 0; j < NREC; j++) {
+                const int i = pass0 + j;
+                const bool ok = i < nrec && r[j].n >= 0;
+                const int cnt = (i == fl0 ? 1 : 0) + (i == fl1 ? 1 : 0) + (i == fl2 ? 1 : 0);
+                const int ne = r[j].n + cnt;
+                float rq, ru;
+                if (ne < BO_FW_RCP_TAB - 1) { const int t = ne < 0 ? 0 : ne; rq = s_rcp[t]; ru = s_rcp[t + 1]; }
+                else { rq = 1.0f / (float)ne; ru = 1.0f / (float)(1 + ne); }
+                // q + u,  q = W_eff * rcp(n_eff),  u = (cpuct * P * sqrt(N)) * rcp(1 + n_eff),  rcp(k) = RN(1 / k)
+                const float we = r[j].w - (float)cnt;
+                const float t1 = cpuct * r[j].prior;
+                const float t2 = t1 * sq;
+                const float uu = t2 * ru;
+                const float qv = ne > 0 ? we * rq : 0.0f;
+                const float sc = qv + uu;
+                kids += ok ? 1 : 0;
+                if (ok && sc > best) { best = sc; bi = i; bne = ne; bl = r[j].link; }  // first maximum in child order (NaN never wins)
+            }
+            pass0 += NREC;
+            if (pass0 < nrec) continue;  // more of this run
+            // ---- the level is decided -------------------------------------------------------------------------------------
+            if (bi < 0) {  // every score was NaN: take the first child (it exists: a run is never empty)
+                const WRec c0 = fw_ld<false>(R);
+                bi = 0; bne = c0.n; bl = c0.link;  // (no in-flight visits added: the search is broken anyway)
+                bo_atomic_or(&e.status[g], ST_NAN_SCORE);
+            }
+            const int s = n_step, leaf = first * BO_FW_GR + bi;
+            {   // this descent's byte at this depth; earlier descents that went elsewhere no longer share the path
+                const unsigned iw = s_idx[d][lane];
+                if ((int)(iw & 255u) != bi) M &= ~1u;
+                if ((int)((iw >> 8) & 255u) != bi) M &= ~2u;
+                if ((int)((iw >> 16) & 255u) != bi) M &= ~4u;
+                s_idx[d][lane] = (iw & ~(255u << (8 * s))) | ((unsigned)bi << (8 * s));
+            }
+            sp[(size_t)s * BO_FW_PATH_CAP + d] = leaf;
+            levels++; grans += ngran;
+            const int old_link = link;
+            int nl = bl;
+            if (nl >= 0 && d + 1 >= BO_FW_PATH_CAP) {  // path buffer full: the visit counts as a draw
+                nl = FW_DRAW;
+                bo_atomic_or(&e.status[g], ST_DEPTH_OVERFLOW);
+            }
+            pass0 = 0; fresh_run = true;
+            if (nl >= 0) { link = nl; pn = bne + 1; d++; continue; }  // one level down
+            // ---- end of a descent ----------------------------------------------------------------------------------------
+            const int plen = d + 1;
+            int q;
+            if (nl == FW_MATE) q = FW_SIM_MATE;
+            else if (nl == FW_DRAW) q = FW_SIM_DRAW;
+            else {
+                q = -1;
+                BO_UNROLL
+                for (int k = LC - 1; k >= 0; k--)  // a leaf another descent of this step already selected shares that descent's row
+                    if (k < n_rows && rs[k] == leaf) q = k;
+                if (q < 0) {  // becomes NN row n_rows
+                    q = n_rows;
+                    BO_UNROLL
+                    for (int k = 0; k < LC; k++)
+                        if (k == q) rs[k] = leaf;
+                    ctl[FWC_F(L, FWR_SLOT, q)] = leaf; ctl[FWC_F(L, FWR_PLINK, q)] = old_link; ctl[FWC_F(L, FWR_SIM, q)] = s;
+                    n_rows++;
+                }
+            }
+            ctl[FWC_F(L, FWS_ROW, s)] = q; ctl[FWC_F(L, FWS_PLEN, s)] = plen;
+            n_step = s + 1;
+            if (n_step < nmax) {  // the game's next descent starts at the root
+                link = root_link; pn = root_n + n_step + 1; d = 1;
+                M = (1u << n_step) - 1u;
+                sp[(size_t)n_step * BO_FW_PATH_CAP] = 0;
+            } else {
+                busy = false;
+            }
+        }
+        // ---- a step of known-terminal hits only needs no evaluation: account for it now (program order: the paths are this lane's own stores)
+        int pn_add = levels + n_step;  // a path holds the root and one node per level
+        if (n_rows == 0 && n_step > 0) {
+            for (int s = 0; s < n_step; s++) {
+                const int q = ctl[FWC_F(L, FWS_ROW, s)], plen = ctl[FWC_F(L, FWS_PLEN, s)];
+                const float v = q == FW_SIM_MATE ? 1.0f : 0.0f;
+                for (int k = 1; k < plen; k++) {
+                    WRec *R = A + sp[(size_t)s * BO_FW_PATH_CAP + k];
+                    const fw_nw y = fw_ld_nw(R);
+                    fw_st_nw(R, y.n + 1, y.w + (((plen - 1 - k) & 1) ? -v : v));
+                }
+            }
+            ctl[FWC_TERM] += n_step;
+            root_n += n_step; sims += n_step; n_step = 0;
+            if (sims >= S) done = true;
+        }
+        A[0].n = root_n;
+        e.sims_done[g] = sims; e.phase[g] = done ? PH_DONE : PH_RUN;
+        e.req_node[g] = n_rows > 0 ? rs[0] : -1;
+        ctl[FWC_NROWS] = n_rows; ctl[FWC_NSTEP] = n_step;
+        if (levels) { ctl[FWC_LEVELS] += levels; ctl[FWC_KIDS] += kids; ctl[FWC_GRAN] += grans; ctl[FWC_PNODES] += pn_add; }
+    }
+    if (e.c.profile && on) {  // per lane here: [0] backup, [2] descents, [4] passes of the level loop, [5] lanes
+        unsigned long long *pp = e.prof + (size_t)g * BO_PROF_SLOTS;
+        const unsigned long long t_2 = bo_clock();
+        pp[0] += t_1 - t_0; pp[2] += t_2 - t_1; pp[4] += (unsigned long long)n_iter; pp[5] += 1ull;
+    }
+}
+#if defined(BO_WAVE_EMU)
+#define BO_FW_LANE_OCC
+#else
+#define BO_FW_LANE_OCC __attribute__((amdgpu_waves_per_eu(1, 2)))
+#endif
+BO_FW_LANE_OCC BO_KERNEL void bo_k_fw_select_lane(Eng e, FastW f, const float *value, int kind) { fw_select_lane_body<false>(e, f, value, kind); }
+BO_FW_LANE_OCC BO_KERNEL void bo_k_fw_select_lane_nt(Eng e, FastW f, const float *value, int kind) { fw_select_lane_body<true>(e, f, value, kind); }
 
 // One instantiation per (games per half-wave, leaves-per-step capacity of the LDS path bytes, FW_SEL_* flags).  FW_SEL_DENSE:
 // the register allocation is capped so that one more wave fits per SIMD (more runs in flight per CU, some spills).

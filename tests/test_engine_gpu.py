@@ -355,7 +355,7 @@ def test_fast_select_kernel_variants_on_gpu_match_restatement(backend, L, ut):
     capped registers}) with a different position in every game slot: whole trees against tests/fast_reference.py, bit for bit."""
     import test_fast_mode_emu as T
 
-    for flags in range(8):
+    for flags in range(10):  # (8, 9: the one-lane-per-game kernel, plain / non-temporal loads)
         T.check_multi("hip", L, 80, dict(games_per_halfwave=ut, select_flags=flags))
 
 
