@@ -322,7 +322,7 @@ def fast_select_sweep(ro, drv, steps=12):
     """Every variant of the select + backup kernel over `steps` more launches each on this run's trees (they keep growing meanwhile;
     when the searches run out of simulations a ply is played in between)."""
     out = []
-    for ut, fl in ((4, 8), (4, 9), (2, 0), (4, 0), (2, 2)):  # (flags 8 / 9: one lane per game, plain / non-temporal loads)
+    for ut, fl in ((4, 8), (4, 9), (2, 0)):  # (flags 8 / 9: one lane per game, plain / non-temporal loads)
         if True:
             ro.eng.fast_options(games_per_halfwave=ut, select_flags=fl)
             r = fast_select_roofline(ro, drv, steps, f" u{ut} flags{fl}")
@@ -505,7 +505,7 @@ def main():
                  fast_arena_granules=(args.arena_granules_per_expansion * (args.sims + args.leaves + 2) if args.fast else 0),
                  policy_kind="probs" if args.softmax == "torch" else "logits")
     if args.fast and G * args.leaves > 65536:
-        ro.MAX_GRAPH_ITERATIONS = 4  # (every iteration of a captured graph keeps its own logits / probabilities: 6.5 GB at 131072 rows)
+        ro.MAX_GRAPH_ITERATIONS = 4 if G * args.leaves <= 131072 else 2  # (every iteration of a captured graph keeps its own logits / probabilities: 6.5 GB at 131072 rows)
     if args.fast and (args.select_games_per_halfwave is not None or args.select_flags is not None):
         ro.eng.fast_options(games_per_halfwave=args.select_games_per_halfwave, select_flags=args.select_flags)
     exchange = records.PeriodicGameExchange(device, every=args.exchange_every) if dist is not None else None

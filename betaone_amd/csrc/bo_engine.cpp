@@ -465,7 +465,7 @@ extern "C" int bo_search_begin(bo_engine *e, const int32_t *go, const double *no
 static int launch_fw_select(bo_engine *e, const float *value_dev, int kind, void *stream) {
     const FastW &f = e->f;
     const int G = e->d.c.G, L = f.L;
-    if (L <= 4 && (f.sel_flags & FW_SEL_LANE)) {  // one lane per game (bo_fastw.h)
+    if (L == 4 && (f.sel_flags & FW_SEL_LANE)) {  // one lane per game (bo_fastw.h)
         const int blocks = (G + 63) / 64;
         if (f.sel_flags & FW_SEL_NT) return RT_LAUNCH(bo_k_fw_select_lane_nt, blocks, stream, e->d, e->f, value_dev, kind);
         return RT_LAUNCH(bo_k_fw_select_lane, blocks, stream, e->d, e->f, value_dev, kind);

@@ -722,63 +722,89 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
 }
 #undef BO_FW_ARGMAX
 
-// ---- select + backup, ONE LANE PER GAME (leaves_per_step <= 4) ---------------------------------------------------------------
+// ---- select + backup, ONE LANE PER GAME (leaves_per_step == 4) ---------------------------------------------------------------
 // Measured on the half-wave form above (bo_debug_profile, 32768 games x 4 descents on trees of 800 simulations per move): its
 // time is instruction issue, not memory -- ~250 issued instructions per game and level (cross-lane reductions, ballots, LDS
 // hand-overs between lanes, exec-mask bookkeeping) of which each serves two games.  Here a lane owns a game: no cross-lane
-// operation at all, a level's records are scored in a straight line of ~20 instructions each that serve 64 games at once (~16
-// issued instructions per game and level), 64 independent chains of dependent reads per wave, and -- every access to a game's
-// tree coming from one lane -- program order alone keeps the backup's stores in front of the descents' loads.  A lane reads a run
-// as 16-byte records of its own 128-byte granules: 64 lanes = 64 different lines per instruction, every line requested once
-// (the granule's eight loads are issued back to back and merge in the L1's miss queue).
-// The level loop is flat: every pass of the loop scores the next BO_FW_LANE_CH granules of each lane's current run; a lane
-// whose run is finished picks the winner, notes the level (path, in-flight byte) and goes on to the next run / the next
-// descent at once, whatever the other lanes are doing.  Same arithmetic and results as the half-wave form (same tests).
+// operation at all, a level's records are scored in a straight line of ~30 instructions each that serve 64 games at once, 64
+// independent chains of dependent reads per wave, and -- every access to a game's tree coming from one lane -- program order alone
+// keeps the backup's stores in front of the descents' loads.  A lane reads a run as 16-byte records of its own 128-byte
+// granules: 64 lanes = 64 different lines per instruction, every line requested once (a granule's eight loads are issued back
+// to back and merge in the L1's miss queue).  The control block (L = 4: every row / simulation list is one 16-byte vector) is
+// read with eleven loads at once and lives in registers; the backup fetches all paths, then all records, then updates.
+// The level loop is flat: every pass scores the next BO_FW_LANE_CH granules of each lane's current run, branch-free (table
+// reciprocals; a count beyond the table -- rare -- makes the lane redo the pass with exact operations); a lane whose run is
+// finished picks the winner, notes the level (path, in-flight byte) and goes on to the next run / the next descent at once,
+// whatever the other lanes are doing.  Same arithmetic and results as the half-wave form (same tests).
 #define BO_FW_LANE_CH 4  // granules (x 8 records x 4 registers) scored per pass
+#if defined(BO_WAVE_EMU)
+struct fw_v4 { int v[4]; int operator[](int i) const { return v[i]; } int &operator[](int i) { return v[i]; } };
+BO_DEV fw_v4 fw_ld4(const int *p) { fw_v4 r; for (int i = 0; i < 4; i++) r.v[i] = p[i]; return r; }
+BO_DEV void fw_st4(int *p, const fw_v4 &x) { for (int i = 0; i < 4; i++) p[i] = x.v[i]; }
+#else
+typedef fw_i4 fw_v4;
+BO_DEV fw_v4 fw_ld4(const int *p) { return *reinterpret_cast<const fw_i4 *>(p); }
+BO_DEV void fw_st4(int *p, const fw_v4 &x) { *reinterpret_cast<fw_i4 *>(p) = x; }
+#endif
+BO_DEV int fw_pick(const fw_v4 &x, int i) { const int a = x[0], b = x[1], c = x[2], d = x[3]; return i == 0 ? a : i == 1 ? b : i == 2 ? c : d; }
+BO_DEV void fw_put(fw_v4 &x, int i, int val) {
+    const int a = x[0], b = x[1], c = x[2], d = x[3];
+    x[0] = i == 0 ? val : a; x[1] = i == 1 ? val : b; x[2] = i == 2 ? val : c; x[3] = i == 3 ? val : d;
+}
+
 template <bool NT>
 BO_DEV void fw_select_lane_body(const Eng &e, const FastW &f, const float *value, int kind) {
     constexpr int LC = 4, NREC = BO_FW_LANE_CH * BO_FW_GR;
     BO_SHARED unsigned s_idx[BO_FW_PATH_CAP][64];  // [depth][lane]: byte s = the child index descent s of the step chose at that depth
     BO_SHARED float s_rcp[BO_FW_RCP_TAB];          // RN(1 / k)
-    const int lane = bo_lane(), L = f.L, S = e.c.S;
+    const int lane = bo_lane(), S = e.c.S;
     const int g = bo_block() * 64 + lane;
     const unsigned long long t_0 = e.c.profile ? bo_clock() : 0ull;
     for (int i = lane; i < BO_FW_RCP_TAB; i += 64) s_rcp[i] = f.rcp_tab[i];
     bo_sync();
-    bool on = g < e.c.G && e.phase[g < e.c.G ? g : 0] == PH_RUN;
     const int gg = g < e.c.G ? g : 0;
     int *ctl = fw_ctl(f, gg);
-    int n_rows = ctl[FWC_NROWS], n_step = ctl[FWC_NSTEP];
-    if (n_rows > 0 && kind == POLICY_NONE) on = false;  // (rows waiting for an evaluation that has not been made)
-    WRec *A = f.arena + fw_arena_off(f, gg, ctl[FWC_CUR]);
-    int *sp = f.sim_path + (size_t)gg * L * BO_FW_PATH_CAP;
-    int sims = e.sims_done[gg], root_n = 0, root_link = FW_UNVISITED;
+    // the control block: head | counters | .. | row_slot | row_plink | row_nlegal | row_term | row_sim | sim_row | sim_plen
+    const fw_v4 c_head = fw_ld4(ctl + 0), c_stat = fw_ld4(ctl + 4), c_t = fw_ld4(ctl + 8);
+    fw_v4 c_slot = fw_ld4(ctl + FWC_F(LC, FWR_SLOT, 0)), c_plink = fw_ld4(ctl + FWC_F(LC, FWR_PLINK, 0));
+    const fw_v4 c_nlegal = fw_ld4(ctl + FWC_F(LC, FWR_NLEGAL, 0)), c_term = fw_ld4(ctl + FWC_F(LC, FWR_TERM, 0));
+    fw_v4 c_rsim = fw_ld4(ctl + FWC_F(LC, FWR_SIM, 0)), c_srow = fw_ld4(ctl + FWC_F(LC, FWS_ROW, 0)), c_splen = fw_ld4(ctl + FWC_F(LC, FWS_PLEN, 0));
+    const int ph = e.phase[gg];
+    int sims = e.sims_done[gg];
     bool done = e.root_term[gg] != 0;
-    int rs[LC];  // leaf records of the step's rows
-    BO_UNROLL
-    for (int q = 0; q < LC; q++) rs[q] = -1;
-    int levels = 0, grans = 0, kids = 0, n_iter = 0;
+    float val4[LC] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (kind != POLICY_NONE) {
+        BO_UNROLL
+        for (int q = 0; q < LC; q++) val4[q] = value[(size_t)gg * LC + q];
+    }
+    int n_rows = c_head[FWC_NROWS], n_step = c_head[FWC_NSTEP], top = c_head[FWC_TOP], term_total = c_t[0];
+    const bool on = g < e.c.G && ph == PH_RUN && !(n_rows > 0 && kind == POLICY_NONE);  // (rows waiting for an evaluation that has not been made)
+    WRec *A = f.arena + fw_arena_off(f, gg, c_head[FWC_CUR]);
+    int *sp = f.sim_path + (size_t)gg * LC * BO_FW_PATH_CAP;
+    int levels = 0, grans = 0, kids = 0, n_iter = 0, root_n = 0, root_link = FW_UNVISITED;
     unsigned long long t_1 = 0ull;
     if (on) {
         const WRec root = fw_ld<false>(A);
         root_n = root.n; root_link = root.link;
         // ---- the previous step's rows have been applied: back their values up ------------------------------------------------
         if (n_rows > 0) {
-            int top = ctl[FWC_TOP], term_sims = 0, maxlen = 0;
-            for (int q = 0; q < n_rows; q++) {
-                const int need = fw_row_need(ctl[FWC_F(L, FWR_TERM, q)], ctl[FWC_F(L, FWR_NLEGAL, q)]);
-                if (top + need <= f.NG) top += need;  // (bo_k_fw_apply refused the runs that do not fit, in the same order)
-            }
+            int term_sims = 0, maxlen = 0;
             float v[LC];
             int plen[LC];
             BO_UNROLL
+            for (int q = 0; q < LC; q++) {
+                const int need = fw_row_need(c_term[q], c_nlegal[q]);
+                if (q < n_rows && top + need <= f.NG) top += need;  // (bo_k_fw_apply refused the runs that do not fit, in the same order)
+            }
+            BO_UNROLL
             for (int s = 0; s < LC; s++) {
                 const bool ok = s < n_step;
-                const int q = ok ? ctl[FWC_F(L, FWS_ROW, s < L ? s : 0)] : FW_SIM_DRAW;
-                plen[s] = ok ? ctl[FWC_F(L, FWS_PLEN, s < L ? s : 0)] : 0;
+                const int q = ok ? c_srow[s] : FW_SIM_DRAW;
+                plen[s] = ok ? c_splen[s] : 0;
                 if (q >= 0) {  // value[] is from the leaf's side to move; the player who moved into the leaf sees -v; a found terminal has its exact value
-                    const int t = ctl[FWC_F(L, FWR_TERM, q)];
-                    v[s] = t > 0 ? (t == 1 ? 1.0f : 0.0f) : -value[(size_t)gg * L + q];
+                    const int t = fw_pick(c_term, q);
+                    const float vq = q == 0 ? val4[0] : q == 1 ? val4[1] : q == 2 ? val4[2] : val4[3];
+                    v[s] = t > 0 ? (t == 1 ? 1.0f : 0.0f) : -vq;
                     term_sims += (ok && t > 0) ? 1 : 0;
                 } else {
                     v[s] = q == FW_SIM_MATE ? 1.0f : 0.0f;
@@ -786,59 +812,59 @@ BO_DEV void fw_select_lane_body(const Eng &e, const FastW &f, const float *value
                 }
                 maxlen = plen[s] > maxlen ? plen[s] : maxlen;
             }
-            // depth by depth, four depths at a time: the record ids of all simulations, then their (n, w), then the updates -- two
-            // round trips per four depths; simulations that share a record at a depth are chained in registers
-            for (int k0 = 1; k0 < maxlen; k0 += 4) {
-                int rec[4][LC];
-                bool val[4][LC];
-                fw_nw x[4][LC];
+            // eight depths at a time: the record ids of all simulations (two 16-byte reads per path), then their (n, w), then the
+            // updates -- three round trips; simulations that share a record at a depth are chained in registers
+            for (int k0 = 0; k0 < maxlen; k0 += 8) {
+                fw_v4 pa[LC], pb[LC];
                 BO_UNROLL
-                for (int kk = 0; kk < 4; kk++) {
+                for (int s = 0; s < LC; s++) { pa[s] = fw_ld4(sp + s * BO_FW_PATH_CAP + k0); pb[s] = fw_ld4(sp + s * BO_FW_PATH_CAP + k0 + 4); }
+                int rec[8][LC];
+                bool vl[8][LC];
+                fw_nw x[8][LC];
+                BO_UNROLL
+                for (int kk = 0; kk < 8; kk++) {
                     BO_UNROLL
                     for (int s = 0; s < LC; s++) {
-                        val[kk][s] = k0 + kk < plen[s];
-                        rec[kk][s] = val[kk][s] ? sp[(size_t)s * BO_FW_PATH_CAP + k0 + kk] : 0;
+                        vl[kk][s] = k0 + kk >= 1 && k0 + kk < plen[s];  // the root (depth 0) only counts visits
+                        rec[kk][s] = vl[kk][s] ? (kk < 4 ? pa[s][kk & 3] : pb[s][kk & 3]) : 0;
                     }
                 }
                 BO_UNROLL
-                for (int kk = 0; kk < 4; kk++) {
+                for (int kk = 0; kk < 8; kk++) {
                     BO_UNROLL
-                    for (int s = 0; s < LC; s++) {
-                        x[kk][s].n = 0; x[kk][s].w = 0.0f;
-                        if (val[kk][s]) x[kk][s] = fw_ld_nw(A + rec[kk][s]);
-                    }
+                    for (int s = 0; s < LC; s++) x[kk][s] = fw_ld_nw(A + rec[kk][s]);  // (an invalid slot re-reads record 0: the root's line)
                 }
                 BO_UNROLL
-                for (int kk = 0; kk < 4; kk++) {
+                for (int kk = 0; kk < 8; kk++) {
                     BO_UNROLL
                     for (int s = 0; s < LC; s++) {
-                        if (!val[kk][s]) continue;
                         BO_UNROLL
                         for (int i = 0; i < s; i++)
-                            if (val[kk][i] && rec[kk][i] == rec[kk][s]) x[kk][s] = x[kk][i];  // (the latest earlier simulation through the same record wins)
+                            if (vl[kk][i] && vl[kk][s] && rec[kk][i] == rec[kk][s]) x[kk][s] = x[kk][i];  // (the latest earlier simulation through the same record wins)
                         x[kk][s].n = x[kk][s].n + 1;
                         x[kk][s].w = x[kk][s].w + (((plen[s] - 1 - (k0 + kk)) & 1) ? -v[s] : v[s]);
                     }
                     BO_UNROLL
                     for (int s = 0; s < LC; s++)
-                        if (val[kk][s]) fw_st_nw(A + rec[kk][s], x[kk][s].n, x[kk][s].w);
+                        if (vl[kk][s]) fw_st_nw(A + rec[kk][s], x[kk][s].n, x[kk][s].w);
                 }
             }
-            if (ctl[FWC_F(L, FWR_SLOT, 0)] == 0 && n_step == 0) root_n = 1;  // the root's own evaluation counts as its first visit
+            if (c_slot[0] == 0 && n_step == 0) root_n = 1;  // the root's own evaluation counts as its first visit
             root_n += n_step;
             sims += n_step;
             n_rows = n_step = 0;
-            ctl[FWC_TOP] = top; ctl[FWC_TERM] += term_sims;
+            term_total += term_sims;
         }
-        if (e.c.profile) t_1 = bo_clock();
+    }
+    if (e.c.profile) t_1 = bo_clock();
+    if (on) {
         // ---- up to L descents; this lane's loads below see its stores above (one thread, program order) ----------------------
-        const int nmax = S - sims < L ? S - sims : L;
+        const int nmax = S - sims < LC ? S - sims : LC;
         bool busy = false;
         if (done || (root_link >= 0 && sims >= S)) {
             done = true;
         } else if (root_link < 0) {  // root not expanded yet: its evaluation is row 0 (no simulation attached)
-            ctl[FWC_F(L, FWR_SLOT, 0)] = 0; ctl[FWC_F(L, FWR_PLINK, 0)] = -1; ctl[FWC_F(L, FWR_SIM, 0)] = -1;
-            rs[0] = 0;
+            c_slot[0] = 0; c_plink[0] = -1; c_rsim[0] = -1;
             n_rows = 1;
         } else {
             busy = true;
@@ -863,23 +889,24 @@ BO_DEV void fw_select_lane_body(const Eng &e, const FastW &f, const float *value
                 best = -__builtin_inff(); bi = -1; bne = 0; bl = FW_UNVISITED;
                 fresh_run = false;
             }
-            // this pass's granules, all requested before the first is used (a granule beyond the run: the run's last one again)
+            // this pass's granules, all requested before the first is used (a record beyond the run: the run's last one again)
             WRec r[NREC];
             const WRec *R = A + (size_t)first * BO_FW_GR;
+            const int nrem = nrec - pass0;  // records of the run from this pass on
+            BO_UNROLL
+            for (int j = 0; j < NREC; j++) r[j] = fw_ld<NT>(R + pass0 + (j < nrem ? j : nrem - 1));
+            const int fa = fl0 - pass0, fb = fl1 - pass0, fc = fl2 - pass0;
+            const float best_in = best;
+            const int bi_in = bi, bne_in = bne, bl_in = bl;
+            bool rare = false;
             BO_UNROLL
             for (int j = 0; j < NREC; j++) {
-                const int i = pass0 + j;
-                r[j] = fw_ld<NT>(R + (i < nrec ? i : nrec - 1));
-            }
-            BO_UNROLL
-            for (int j = 0; j < NREC; j++) {
-                const int i = pass0 + j;
-                const bool ok = i < nrec && r[j].n >= 0;
-                const int cnt = (i == fl0 ? 1 : 0) + (i == fl1 ? 1 : 0) + (i == fl2 ? 1 : 0);
+                const bool ok = j < nrem && r[j].n >= 0;
+                const int cnt = (fa == j ? 1 : 0) + (fb == j ? 1 : 0) + (fc == j ? 1 : 0);
                 const int ne = r[j].n + cnt;
-                float rq, ru;
-                if (ne < BO_FW_RCP_TAB - 1) { const int t = ne < 0 ? 0 : ne; rq = s_rcp[t]; ru = s_rcp[t + 1]; }
-                else { rq = 1.0f / (float)ne; ru = 1.0f / (float)(1 + ne); }
+                const int t = ne < 0 ? 0 : ne > BO_FW_RCP_TAB - 2 ? BO_FW_RCP_TAB - 2 : ne;
+                const float rq = s_rcp[t], ru = s_rcp[t + 1];
+                rare = rare || (ok && ne > BO_FW_RCP_TAB - 2);
                 // q + u,  q = W_eff * rcp(n_eff),  u = (cpuct * P * sqrt(N)) * rcp(1 + n_eff),  rcp(k) = RN(1 / k)
                 const float we = r[j].w - (float)cnt;
                 const float t1 = cpuct * r[j].prior;
@@ -887,8 +914,26 @@ BO_DEV void fw_select_lane_body(const Eng &e, const FastW &f, const float *value
                 const float uu = t2 * ru;
                 const float qv = ne > 0 ? we * rq : 0.0f;
                 const float sc = qv + uu;
+                const bool better = ok && sc > best;  // first maximum in child order (NaN never wins)
                 kids += ok ? 1 : 0;
-                if (ok && sc > best) { best = sc; bi = i; bne = ne; bl = r[j].link; }  // first maximum in child order (NaN never wins)
+                best = better ? sc : best; bi = better ? pass0 + j : bi; bne = better ? ne : bne; bl = better ? r[j].link : bl;
+            }
+            if (rare) {  // a visit count beyond the reciprocal table: the pass again with exact operations
+                best = best_in; bi = bi_in; bne = bne_in; bl = bl_in;
+                for (int j = 0; j < NREC && j < nrem; j++) {
+                    const WRec rx = fw_ld<false>(R + pass0 + j);
+                    if (rx.n < 0) continue;
+                    const int cnt = (fa == j ? 1 : 0) + (fb == j ? 1 : 0) + (fc == j ? 1 : 0);
+                    const int ne = rx.n + cnt;
+                    const float rq = ne > 0 ? 1.0f / (float)ne : 0.0f, ru = 1.0f / (float)(1 + ne);
+                    const float we = rx.w - (float)cnt;
+                    const float t1 = cpuct * rx.prior;
+                    const float t2 = t1 * sq;
+                    const float uu = t2 * ru;
+                    const float qv = ne > 0 ? we * rq : 0.0f;
+                    const float sc = qv + uu;
+                    if (sc > best) { best = sc; bi = pass0 + j; bne = ne; bl = rx.link; }
+                }
             }
             pass0 += NREC;
             if (pass0 < nrec) continue;  // more of this run
@@ -917,7 +962,6 @@ BO_DEV void fw_select_lane_body(const Eng &e, const FastW &f, const float *value
             pass0 = 0; fresh_run = true;
             if (nl >= 0) { link = nl; pn = bne + 1; d++; continue; }  // one level down
             // ---- end of a descent ----------------------------------------------------------------------------------------
-            const int plen = d + 1;
             int q;
             if (nl == FW_MATE) q = FW_SIM_MATE;
             else if (nl == FW_DRAW) q = FW_SIM_DRAW;
@@ -925,17 +969,14 @@ BO_DEV void fw_select_lane_body(const Eng &e, const FastW &f, const float *value
                 q = -1;
                 BO_UNROLL
                 for (int k = LC - 1; k >= 0; k--)  // a leaf another descent of this step already selected shares that descent's row
-                    if (k < n_rows && rs[k] == leaf) q = k;
+                    if (k < n_rows && c_slot[k] == leaf) q = k;
                 if (q < 0) {  // becomes NN row n_rows
                     q = n_rows;
-                    BO_UNROLL
-                    for (int k = 0; k < LC; k++)
-                        if (k == q) rs[k] = leaf;
-                    ctl[FWC_F(L, FWR_SLOT, q)] = leaf; ctl[FWC_F(L, FWR_PLINK, q)] = old_link; ctl[FWC_F(L, FWR_SIM, q)] = s;
+                    fw_put(c_slot, q, leaf); fw_put(c_plink, q, old_link); fw_put(c_rsim, q, s);
                     n_rows++;
                 }
             }
-            ctl[FWC_F(L, FWS_ROW, s)] = q; ctl[FWC_F(L, FWS_PLEN, s)] = plen;
+            fw_put(c_srow, s, q); fw_put(c_splen, s, d + 1);
             n_step = s + 1;
             if (n_step < nmax) {  // the game's next descent starts at the root
                 link = root_link; pn = root_n + n_step + 1; d = 1;
@@ -946,10 +987,10 @@ BO_DEV void fw_select_lane_body(const Eng &e, const FastW &f, const float *value
             }
         }
         // ---- a step of known-terminal hits only needs no evaluation: account for it now (program order: the paths are this lane's own stores)
-        int pn_add = levels + n_step;  // a path holds the root and one node per level
+        const int pn_add = levels + n_step;  // a path holds the root and one node per level
         if (n_rows == 0 && n_step > 0) {
             for (int s = 0; s < n_step; s++) {
-                const int q = ctl[FWC_F(L, FWS_ROW, s)], plen = ctl[FWC_F(L, FWS_PLEN, s)];
+                const int q = fw_pick(c_srow, s), plen = fw_pick(c_splen, s);
                 const float v = q == FW_SIM_MATE ? 1.0f : 0.0f;
                 for (int k = 1; k < plen; k++) {
                     WRec *R = A + sp[(size_t)s * BO_FW_PATH_CAP + k];
@@ -957,17 +998,23 @@ BO_DEV void fw_select_lane_body(const Eng &e, const FastW &f, const float *value
                     fw_st_nw(R, y.n + 1, y.w + (((plen - 1 - k) & 1) ? -v : v));
                 }
             }
-            ctl[FWC_TERM] += n_step;
+            term_total += n_step;
             root_n += n_step; sims += n_step; n_step = 0;
             if (sims >= S) done = true;
         }
         A[0].n = root_n;
         e.sims_done[g] = sims; e.phase[g] = done ? PH_DONE : PH_RUN;
-        e.req_node[g] = n_rows > 0 ? rs[0] : -1;
-        ctl[FWC_NROWS] = n_rows; ctl[FWC_NSTEP] = n_step;
-        if (levels) { ctl[FWC_LEVELS] += levels; ctl[FWC_KIDS] += kids; ctl[FWC_GRAN] += grans; ctl[FWC_PNODES] += pn_add; }
+        e.req_node[g] = n_rows > 0 ? c_slot[0] : -1;
+        // the control block goes back (row_nlegal / row_term are the leaf kernel's to write)
+        fw_v4 h = c_head, st = c_stat, tt = c_t;
+        h[FWC_NROWS] = n_rows; h[FWC_NSTEP] = n_step; h[FWC_TOP] = top;
+        st[0] = c_stat[0] + levels; st[1] = c_stat[1] + kids; st[2] = c_stat[2] + grans; st[3] = c_stat[3] + (levels ? pn_add : 0);
+        tt[0] = term_total;
+        fw_st4(ctl + 0, h); fw_st4(ctl + 4, st); fw_st4(ctl + 8, tt);
+        fw_st4(ctl + FWC_F(LC, FWR_SLOT, 0), c_slot); fw_st4(ctl + FWC_F(LC, FWR_PLINK, 0), c_plink); fw_st4(ctl + FWC_F(LC, FWR_SIM, 0), c_rsim);
+        fw_st4(ctl + FWC_F(LC, FWS_ROW, 0), c_srow); fw_st4(ctl + FWC_F(LC, FWS_PLEN, 0), c_splen);
     }
-    if (e.c.profile && on) {  // per lane here: [0] backup, [2] descents, [4] passes of the level loop, [5] lanes
+    if (e.c.profile && on) {  // per lane here: [0] control block + backup, [2] descents, [4] passes of the level loop, [5] lanes
         unsigned long long *pp = e.prof + (size_t)g * BO_PROF_SLOTS;
         const unsigned long long t_2 = bo_clock();
         pp[0] += t_1 - t_0; pp[2] += t_2 - t_1; pp[4] += (unsigned long long)n_iter; pp[5] += 1ull;
