@@ -1,6 +1,6 @@
 #!/bin/bash
 # scripts/gpu_round.sh -- one gpurun call: GPU tests, then the bench lines; stops at the first step that timed out / was killed.
-# usage (on the GPU box): bash scripts/gpu_round.sh <tag> [steps...]   steps: see the case list below (tests bench bench200 steady cfg1 cfg4 g2048 fast* uci nccl1 dist2 trace pmctower ...)
+# usage (on the GPU box): bash scripts/gpu_round.sh <tag> [steps...]   steps: see the case list below (tests bench bench200 steady cfg1 cfg4 g2048 fast fast16k fastsweep pmcfast uci nccl1 dist2 trace pmctower ...)
 set -u
 tag=$1; shift
 out=gpurun_out
@@ -21,6 +21,8 @@ for step in "$@"; do
     testsall) run gpu_tests 1000 python -m pytest tests -m gpu -q ;;
     newtests) run gpu_newtests 900 python -m pytest tests/test_baseline_configs_gpu.py tests/test_dropin_gpu.py -m gpu -q -s ;;
     bench)   run bench_default 600 python bench.py ;;
+    driver)  run bench_driver_cmd 600 python bench.py --gpus 1 --steps 20 --warmup 5 ;;
+    smoke)   run smoke 600 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench3)  run bench_a 300 python bench.py --no-cpu-baseline --no-roofline ; run bench_b 300 python bench.py --no-cpu-baseline --no-roofline ; run bench_c 300 python bench.py --no-cpu-baseline --no-roofline ;;
     bench200) run bench_200a 300 python bench.py --steps 200 --no-cpu-baseline --no-roofline ;
               run bench_200b 300 python bench.py --steps 200 --no-cpu-baseline --no-roofline ;;
@@ -31,10 +33,11 @@ for step in "$@"; do
     cfg1)    run bench_cfg1 300 python bench.py --sims 400 --no-cpu-baseline --no-roofline ;;
     cfg4)    run bench_cfg4 400 python bench.py --games 512 --net 20x256 --net-dtype fp16 --no-cpu-baseline --no-roofline ;;
     g2048)   run bench_g2048 400 python bench.py --games 2048 --no-cpu-baseline --no-roofline ;;
-    fast)    run bench_fast 500 python bench.py --fast --leaves 16 --preroll 48 --steps 6 --warmup 1 --opening-steps 0 --no-cpu-baseline ;;
-    fast16)  run bench_fast_f16 500 python bench.py --fast --leaves 16 --net-dtype fp16 --preroll 48 --steps 6 --warmup 1 --opening-steps 0 --no-cpu-baseline --wide-trees 32768 ;;
-    fast4k)  run bench_fast_4096 700 python bench.py --fast --games 4096 --leaves 4 --net-dtype fp16 --preroll 24 --steps 3 --warmup 1 --opening-steps 0 --no-cpu-baseline --wide-trees 32768 ;;
-    fast32k) run bench_fast_32k 900 python bench.py --fast --games 32768 --leaves 1 --sims 64 --net 4x64 --net-dtype fp16 --preroll 6 --steps 2 --warmup 1 --opening-steps 0 --no-cpu-baseline --wide-trees 32768 ;;
+    fast)    run bench_fast 800 python bench.py --fast ;;
+    fast16k) run bench_fast_16k 600 python bench.py --fast --games 16384 ;;
+    fastprof) run bench_fast_prof 800 env BO_SELECT_PROFILE=1 python bench.py --fast --games 16384 ;;
+    fastsweep) run bench_fast_sweep 900 env BO_SELECT_PROFILE=1 python bench.py --fast --select-sweep ;;
+    fastsmall) run bench_fast_256x16 500 python bench.py --fast --games 256 --leaves 16 --sims 800 --preroll 48 --steps 6 --warmup 1 --opening-steps 0 --arena-granules-per-expansion 24 ;;
     fasttests) run gpu_fasttests 600 python -m pytest tests/test_engine_gpu.py -m gpu -q -k "fast_mode" ;;
     uci)     run uci_latency 300 python tests/uci_latency.py ;;
     nccl1)   run bench_nccl1 300 env RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 python bench.py --force-dist --exchange-every 4 --steps 60 --no-cpu-baseline --no-roofline ;;
@@ -43,8 +46,10 @@ for step in "$@"; do
               run stepprof_slow 400 python scripts/step_profile.py 640 100 300000 ;;
     trace)   mkdir -p $out/${tag}_trace; run trace 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace -- python bench.py --steps 200 --opening-steps 0 --no-cpu-baseline --no-roofline ;
              python scripts/kernel_percentiles.py $out/${tag}_trace > $out/${tag}_trace_percentiles.md 2>&1 ; rm -f $out/${tag}_trace/*/*_kernel_trace.csv.keep ; tail -n 40 $out/${tag}_trace_percentiles.md ;;
-    pmcfast) mkdir -p $out/${tag}_pmcfast; run pmcfast 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex "bo_k_fw" --output-format csv -d $out/${tag}_pmcfast -- python bench.py --fast --games 4096 --leaves 4 --net-dtype fp16 --preroll 4 --steps 1 --warmup 1 --opening-steps 0 --no-cpu-baseline --no-graph --wide-trees 32768 ;
-             python scripts/pmc_summary.py $out/${tag}_pmcfast > $out/${tag}_pmcfast.md 2>&1 ; cat $out/${tag}_pmcfast.md ;;
+    pmcfast) mkdir -p $out/${tag}_pmcfast; run pmcfast 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex "bo_k_fw_select" --output-format csv -d $out/${tag}_pmcfast -- python bench.py --fast --games 16384 --preroll 2 --steps 1 --warmup 0 --opening-steps 0 --no-cpu-baseline --no-graph --roofline-steps 32 ;
+             python scripts/pmc_summary.py $out/${tag}_pmcfast > $out/${tag}_pmcfast.md 2>&1 ; cat $out/${tag}_pmcfast.md ; rm -rf $out/${tag}_pmcfast ;;
+    pmcfastw) mkdir -p $out/${tag}_pmcfastw; run pmcfastw 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --kernel-include-regex "bo_k_fw_select" --output-format csv -d $out/${tag}_pmcfastw -- python bench.py --fast --games 16384 --preroll 2 --steps 1 --warmup 0 --opening-steps 0 --no-cpu-baseline --no-graph --roofline-steps 32 ;
+             python scripts/pmc_summary.py $out/${tag}_pmcfastw WRITE_SIZE > $out/${tag}_pmcfastw.md 2>&1 ; cat $out/${tag}_pmcfastw.md ; rm -rf $out/${tag}_pmcfastw ;;
     pmctower) for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
                  p=$(echo $pass | cut -d" " -f1); mkdir -p $out/${tag}_pmctower_$p;
                  run pmctower_$p 400 rocprofv3 --pmc $pass --kernel-trace --kernel-include-regex "bo_k_tower_wg|bo_k_heads" --output-format csv -d $out/${tag}_pmctower_$p -- python scripts/forward_profile.py tower_wg 256 ;
