@@ -61,7 +61,7 @@
 #define FW_DRAW (-3)
 #define FW_SIM_MATE (-2)      // sim_row codes of simulations that ended in a known terminal (no NN row)
 #define FW_SIM_DRAW (-3)
-enum { FW_SEL_NT = 1, FW_SEL_ROOT_IN_REGS = 2, FW_SEL_DENSE = 4, FW_SEL_LANE = 8 };  // FastW::sel_flags
+enum { FW_SEL_NT = 1, FW_SEL_ROOT_IN_REGS = 2, FW_SEL_DENSE = 4, FW_SEL_LANE = 8, FW_SEL_OCT = 16 };  // FastW::sel_flags
 
 struct alignas(16) WRec {
     int n;        // visits; -1 = padding of a run's last granule, never selected
@@ -260,29 +260,34 @@ BO_DEV int fw_ctz(unsigned long long m) { return __builtin_ctzll(m); }
 //      backup costs three dependent round trips for the whole wave, not one per simulation and game
 //   3. L descents per game over the read-only tree; rows / simulations are noted in the LDS copy of the control block
 //   4. the control blocks go back with one coalesced store per game
-template <int UT, int LCAP, bool NT, bool ROOTC>
+// W lanes per game (32: half a wave, two records per lane; 8: an eighth, RPL = 5 records per lane and 8 games per instruction),
+// UT games interleaved per group of W lanes
+template <int W, int RPL, int UT, int LCAP, bool NT, bool ROOTC>
 BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int kind) {
     typedef typename FwMask<LCAP>::T mask_t;
-    constexpr int CSL = FWC_HEAD + FWR_FIELDS * LCAP, NCR = (CSL + 31) / 32, NVR = (LCAP + 31) / 32;
+    constexpr int NGRP = 64 / W, NSL = NGRP * UT;  // groups of lanes per wave; games per wave
+    constexpr int CSL = FWC_HEAD + FWR_FIELDS * LCAP, NCR = (CSL + W - 1) / W, NVR = (LCAP + W - 1) / W;
+    static_assert(LCAP <= W * 2, "row list scan covers two words per lane");
     constexpr int BO_FW_BK_CH = UT >= 4 ? 2 : 4;  // simulations of a game whose backups are fetched together and chained in registers
-    BO_SHARED int s_ctl[2 * UT][NCR * 32];                         // the games' control blocks
-    BO_SHARED float s_val[2 * UT][NVR * 32];                       // values of the step's rows
+    BO_SHARED int s_ctl[NSL][NCR * W];                         // the games' control blocks
+    BO_SHARED float s_val[NSL][NVR * W];                       // values of the step's rows
     constexpr int NW = (LCAP + 3) / 4;
-    BO_SHARED unsigned s_idx[2 * UT][BO_FW_PATH_CAP][NW];         // child index chosen at depth d by descent s of the step: byte s of the depth's words
+    BO_SHARED unsigned s_idx[NSL][BO_FW_PATH_CAP][NW];         // child index chosen at depth d by descent s of the step: byte s of the depth's words
     BO_SHARED float s_rcp[BO_FW_RCP_TAB];                          // RN(1 / k)
-    BO_SHARED int s_path[2 * UT][BO_FW_PATH_CAP];                  // record ids of the descent in progress
-    const int lane = bo_lane(), half = lane >> 5, c = lane & 31, hb = half << 5;
+    BO_SHARED int s_path[NSL][BO_FW_PATH_CAP];                  // record ids of the descent in progress
+    const int lane = bo_lane(), half = lane / W, c = lane % W, hb = half * W;  // (`half`: this lane's group)
+    const unsigned long long gmask = W == 64 ? ~0ull : ((1ull << W) - 1ull);
     const int L = f.L, S = e.c.S, G = e.c.G;
     const float cpuct = e.c.cpuct;
     // the 2 * UT games of a workgroup are consecutive: their arenas are addressed as one uniform base + a 32-bit offset
-    const int g0 = bo_block() * 2 * UT;
+    const int g0 = bo_block() * NSL;
     WRec *const base = f.arena + fw_arena_off(f, g0, 0);
     unsigned aoff[UT];  // records from `base` to the game's live arena
     int sims[UT], n_rows[UT], n_step[UT], root_n[UT], root_link[UT];
     int link[UT], pn[UT], d[UT];
     mask_t M[UT];
     bool on[UT], busy[UT], done[UT];
-    WRec rr0[ROOTC ? UT : 1], rr1[ROOTC ? UT : 1];
+    WRec rr[ROOTC ? UT : 1][RPL];
 #define FW_G(u) (g0 + half * UT + (u))
 #define FW_A(u) (base + aoff[u])
 #define FW_SLOT(u) (half * UT + (u))
@@ -304,9 +309,9 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
             const int gg = in ? FW_G(u) : g0;
             const int *ctl = fw_ctl(f, gg);
             BO_UNROLL
-            for (int k = 0; k < NCR; k++) creg[u][k] = c + 32 * k < f.CS ? ctl[c + 32 * k] : 0;
+            for (int k = 0; k < NCR; k++) creg[u][k] = c + W * k < f.CS ? ctl[c + W * k] : 0;
             BO_UNROLL
-            for (int k = 0; k < NVR; k++) vreg[u][k] = (kind != POLICY_NONE && c + 32 * k < L) ? value[(size_t)gg * L + c + 32 * k] : 0.0f;
+            for (int k = 0; k < NVR; k++) vreg[u][k] = (kind != POLICY_NONE && c + W * k < L) ? value[(size_t)gg * L + c + W * k] : 0.0f;
             ph[u] = in ? e.phase[gg] : PH_IDLE;
             sims[u] = e.sims_done[gg];
             done[u] = e.root_term[gg] != 0;
@@ -314,9 +319,9 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
         BO_UNROLL
         for (int u = 0; u < UT; u++) {
             BO_UNROLL
-            for (int k = 0; k < NCR; k++) FW_C(u, c + 32 * k) = creg[u][k];
+            for (int k = 0; k < NCR; k++) FW_C(u, c + W * k) = creg[u][k];
             BO_UNROLL
-            for (int k = 0; k < NVR; k++) s_val[FW_SLOT(u)][c + 32 * k] = vreg[u][k];
+            for (int k = 0; k < NVR; k++) s_val[FW_SLOT(u)][c + W * k] = vreg[u][k];
         }
         bo_wave_sync();
         BO_UNROLL
@@ -366,7 +371,7 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
                         v = q == FW_SIM_MATE ? 1.0f : 0.0f;
                         term_sims[u] += ok ? 1 : 0;
                     }
-                    if (plen > 32) deep[u] = 1;
+                    if (plen > W) deep[u] = 1;
                     val[u][j] = c >= 1 && c < plen;  // the root (depth 0) only counts visits
                     sgn[u][j] = ((plen - 1 - c) & 1) ? -v : v;
                     rec[u][j] = val[u][j] ? sp[(size_t)s * BO_FW_PATH_CAP + c] : 0;
@@ -400,17 +405,18 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
         for (int u = 0; u < UT; u++) {
             root_n[u] = rootrec[u].n; root_link[u] = rootrec[u].link;
             if (!bk[u]) continue;
-            if (deep[u]) {  // path depths 32..63 (rare): one simulation at a time
+            if (deep[u]) {  // path depths W..63 (rare): one simulation at a time
                 const int *sp = f.sim_path + (size_t)FW_G(u) * L * BO_FW_PATH_CAP;
                 for (int s = 0; s < n_step[u]; s++) {
-                    const int q = FW_C(u, FWC_F(L, FWS_ROW, s)), plen = FW_C(u, FWC_F(L, FWS_PLEN, s)), k = c + 32;
-                    if (k >= plen) continue;
+                    const int q = FW_C(u, FWC_F(L, FWS_ROW, s)), plen = FW_C(u, FWC_F(L, FWS_PLEN, s));
                     float v;
                     if (q >= 0) { const int t = FW_C(u, FWC_F(L, FWR_TERM, q)); v = t > 0 ? (t == 1 ? 1.0f : 0.0f) : -s_val[FW_SLOT(u)][q]; }
                     else v = q == FW_SIM_MATE ? 1.0f : 0.0f;
-                    WRec *R = FW_A(u) + sp[(size_t)s * BO_FW_PATH_CAP + k];
-                    const fw_nw y = fw_ld_nw(R);
-                    fw_st_nw(R, y.n + 1, y.w + (((plen - 1 - k) & 1) ? -v : v));
+                    for (int k = c + W; k < plen; k += W) {
+                        WRec *R = FW_A(u) + sp[(size_t)s * BO_FW_PATH_CAP + k];
+                        const fw_nw y = fw_ld_nw(R);
+                        fw_st_nw(R, y.n + 1, y.w + (((plen - 1 - k) & 1) ? -v : v));
+                    }
                 }
             }
             int top = top0[u];
@@ -439,7 +445,7 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
     //   * branch-free: predicated arithmetic and clamped addresses (as divergent if-blocks a level compiled to ~850 issued
     //     instructions, two thirds of them exec-mask bookkeeping, and every conditional load was waited for inside its own block).
     enum { ST_LEVELS = 0, ST_GRAN, ST_KIDS, ST_WORDS };
-    BO_SHARED int s_st[2 * UT][ST_WORDS];
+    BO_SHARED int s_st[NSL][ST_WORDS];
 #define FW_ST(u, i) s_st[FW_SLOT(u)][(i)]
     int nmax[UT];  // descents this launch may make: min(L, S - sims)
     BO_UNROLL
@@ -465,14 +471,14 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
                 const int nrec = fw_ngran(root_link[u]) * BO_FW_GR;
                 const WRec *R = FW_A(u) + (size_t)fw_first(root_link[u]) * BO_FW_GR;
                 WRec pad; pad.n = -1; pad.w = 0.0f; pad.prior = 0.0f; pad.link = FW_UNVISITED;
-                rr0[u] = c < nrec ? fw_ld<false>(R + c) : pad;
-                rr1[u] = c + 32 < nrec ? fw_ld<false>(R + c + 32) : pad;
+                BO_UNROLL
+                for (int k = 0; k < RPL; k++) rr[u][k] = c + W * k < nrec ? fw_ld<false>(R + c + W * k) : pad;
                 if (c == 0) FW_ST(u, ST_GRAN) = fw_ngran(root_link[u]);
             }
         }
     }
     bo_wave_sync();
-    WRec r0[UT], r1[UT];
+    WRec r[UT][RPL];
     float sqt[UT];
     // request the run behind link[u] (unconditional loads from clamped addresses: a lane beyond the run re-reads its first record,
     // the same cache line; an idle game reads granule 0 of its arena, always there) and the square root of the visits
@@ -482,8 +488,8 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
         const int lk_ = (busy[u] && !cached_) ? link[u] : 0;                                                            \
         const int nrec_ = fw_ngran(lk_) * BO_FW_GR;                                                                     \
         const WRec *R_ = FW_A(u) + (size_t)fw_first(lk_) * BO_FW_GR;                                                    \
-        r0[u] = fw_ld<NT>(R_ + (c < nrec_ ? c : 0));                                                                    \
-        r1[u] = fw_ld<NT>(R_ + (c + 32 < nrec_ ? c + 32 : 0));                                                          \
+        BO_UNROLL                                                                                                       \
+        for (int k_ = 0; k_ < RPL; k_++) r[u][k_] = fw_ld<NT>(R_ + (c + W * k_ < nrec_ ? c + W * k_ : 0));              \
         sqt[u] = f.sqrt_tab[pn[u] < BO_FW_SQRT_TAB ? pn[u] : 0];                                                        \
     }
     bool any = false;
@@ -503,30 +509,40 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
             const int ngran = fw_ngran(lk), nrec = ngran * BO_FW_GR, first = fw_first(lk);
             const int dd = d[u] < BO_FW_PATH_CAP ? d[u] : BO_FW_PATH_CAP - 1;
             const bool atroot = d[u] == 1;
-            if (ROOTC && atroot) { r0[u] = rr0[u]; r1[u] = rr1[u]; }
+            if (ROOTC && atroot) {
+                BO_UNROLL
+                for (int k = 0; k < RPL; k++) r[u][k] = rr[u][k];
+            }
             // descents of this step in flight through this lane's candidates: those that share the whole path so far (mask M) and
             // chose this lane's child at this depth (one byte per descent and depth, LCAP bytes = NW words per depth)
             unsigned iw[NW];
             BO_UNROLL
             for (int w = 0; w < NW; w++) iw[w] = s_idx[slot][dd][w];
-            int cnt0 = 0, cnt1 = 0;
-            BO_UNROLL
-            for (int sp = 0; sp < LCAP - 1; sp++) {
-                const int b = (int)((iw[sp >> 2] >> (8 * (sp & 3))) & 255u), in = (int)((M[u] >> sp) & 1);
-                cnt0 += in & (b == c ? 1 : 0);
-                cnt1 += in & (b == c + 32 ? 1 : 0);
-            }
             // a candidate's PUCT score from its statistics with the descents in flight through it: q + u,
             //   q = W_eff * rcp(n_eff)   u = (cpuct * P * sqrt(N)) * rcp(1 + n_eff)     rcp(k) = RN(1 / k)
             // rcp and sqrt come from tables; counts beyond them (rare) take ONE wave-uniform side path with the exact operations
-            const bool ok0 = lv && c < nrec && r0[u].n >= 0, ok1 = lv && c + 32 < nrec && r1[u].n >= 0;
-            const int ne0 = r0[u].n + cnt0, ne1 = r1[u].n + cnt1;
-            const int t0 = ne0 < 0 ? 0 : ne0 > BO_FW_RCP_TAB - 2 ? BO_FW_RCP_TAB - 2 : ne0, t1 = ne1 < 0 ? 0 : ne1 > BO_FW_RCP_TAB - 2 ? BO_FW_RCP_TAB - 2 : ne1;
-            float sq = sqt[u], rq0 = s_rcp[t0], ru0 = s_rcp[t0 + 1], rq1 = s_rcp[t1], ru1 = s_rcp[t1 + 1];
-            if (bo_ballot(lv && (pn[u] >= BO_FW_SQRT_TAB || (ok0 && ne0 > BO_FW_RCP_TAB - 2) || (ok1 && ne1 > BO_FW_RCP_TAB - 2))) != 0) {
+            int cnt[RPL], ne[RPL];
+            bool ok[RPL];
+            float rq[RPL], ru[RPL];
+            bool beyond = lv && pn[u] >= BO_FW_SQRT_TAB;
+            BO_UNROLL
+            for (int k = 0; k < RPL; k++) {
+                cnt[k] = 0;
+                BO_UNROLL
+                for (int sp = 0; sp < LCAP - 1; sp++)
+                    cnt[k] += (int)((M[u] >> sp) & 1) & ((int)((iw[sp >> 2] >> (8 * (sp & 3))) & 255u) == c + W * k ? 1 : 0);
+                ok[k] = lv && c + W * k < nrec && r[u][k].n >= 0;
+                ne[k] = r[u][k].n + cnt[k];
+                const int t = ne[k] < 0 ? 0 : ne[k] > BO_FW_RCP_TAB - 2 ? BO_FW_RCP_TAB - 2 : ne[k];
+                rq[k] = s_rcp[t]; ru[k] = s_rcp[t + 1];
+                beyond = beyond || (ok[k] && ne[k] > BO_FW_RCP_TAB - 2);
+            }
+            float sq = sqt[u];
+            if (bo_ballot(beyond) != 0) {
                 if (pn[u] >= BO_FW_SQRT_TAB) sq = sqrtf((float)pn[u]);
-                if (ne0 > BO_FW_RCP_TAB - 2) { rq0 = 1.0f / (float)ne0; ru0 = 1.0f / (float)(1 + ne0); }
-                if (ne1 > BO_FW_RCP_TAB - 2) { rq1 = 1.0f / (float)ne1; ru1 = 1.0f / (float)(1 + ne1); }
+                BO_UNROLL
+                for (int k = 0; k < RPL; k++)
+                    if (ne[k] > BO_FW_RCP_TAB - 2) { rq[k] = 1.0f / (float)ne[k]; ru[k] = 1.0f / (float)(1 + ne[k]); }
             }
 #define BO_FW_SCORE(rec, cnt, ne, rq, ru, ok, sc)                                                               \
             float sc;                                                                                           \
@@ -539,19 +555,21 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
                 sc = qv + uu;                                                                                   \
                 sc = ((ok) && sc == sc) ? sc : -__builtin_inff();                                               \
             }
-            BO_FW_SCORE(r0[u], cnt0, ne0, rq0, ru0, ok0, sc0)
-            BO_FW_SCORE(r1[u], cnt1, ne1, rq1, ru1, ok1, sc1)
-            const bool second = sc1 > sc0;
-            float best = second ? sc1 : sc0;
-            int bi = second ? c + 32 : c, bne = second ? ne1 : ne0, bl = second ? r1[u].link : r0[u].link;
-            const uint64_t k0 = bo_ballot(ok0), k1 = bo_ballot(ok1);
-            const int nk = __builtin_popcount((unsigned)(k0 >> hb)) + __builtin_popcount((unsigned)(k1 >> hb));  // children scanned at this level
-            const bool wide = bo_ballot(lv && nrec > 64) != 0;  // a run of more than 64 records somewhere in the wave (rare: > 64 legal moves)
+            float best = -__builtin_inff();
+            int bi = c, bne = ne[0], bl = r[u][0].link, nk = 0;
+            BO_UNROLL
+            for (int k = 0; k < RPL; k++) {  // (a later record of the lane wins only with a strictly better score: first maximum in child order)
+                BO_FW_SCORE(r[u][k], cnt[k], ne[k], rq[k], ru[k], ok[k], sck)
+                const bool better = k == 0 || sck > best;
+                best = better ? sck : best; bi = better ? c + W * k : bi; bne = better ? ne[k] : bne; bl = better ? r[u][k].link : bl;
+                nk += __builtin_popcountll((bo_ballot(ok[k]) >> hb) & gmask);  // children scanned at this level
+            }
+            const bool wide = bo_ballot(lv && nrec > W * RPL) != 0;  // a run with more records than one pass takes, somewhere in the wave
             int extra = 0;
             if (wide) {
-                if (lv && nrec > 64) {
+                if (lv && nrec > W * RPL) {
                     const WRec *R = FW_A(u) + (size_t)first * BO_FW_GR;
-                    for (int i = 64 + c; i < nrec; i += 32) {
+                    for (int i = W * RPL + c; i < nrec; i += W) {
                         const WRec rx = fw_ld<false>(R + i);
                         int cntx = 0;
                         BO_UNROLL
@@ -573,26 +591,30 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
             { const float o = __builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, mx), 0)); mx = o > mx ? o : mx; }
             { const float o = __builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, mx), 1)); mx = o > mx ? o : mx; }
             { const float o = __builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, mx), 2)); mx = o > mx ? o : mx; }
-            { const float o = __builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, mx), 3)); mx = o > mx ? o : mx; }
-            { const float o = bo_shfl_xor_f(mx, 16); mx = o > mx ? o : mx; }
+            if (W >= 16) { const float o = __builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, mx), 3)); mx = o > mx ? o : mx; }
+            if (W >= 32) { const float o = bo_shfl_xor_f(mx, 16); mx = o > mx ? o : mx; }
             const bool top_ = lv && best == mx && mx > -__builtin_inff();
-            const unsigned b0 = (unsigned)(bo_ballot(top_ && bi < 32) >> hb), b1 = (unsigned)(bo_ballot(top_ && bi < 64) >> hb);
-            int win = b0 ? __builtin_ctz(b0) : b1 ? 32 + __builtin_ctz(b1) : -1;
-            if (wide) {  // (the maximum may sit beyond record 63)
-                for (int p = 2; p < 8; p++) {
-                    const unsigned bp = (unsigned)(bo_ballot(top_ && (bi >> 5) == p) >> hb);
-                    if (win < 0 && bp) win = 32 * p + __builtin_ctz(bp);
+            int win = -1;
+            BO_UNROLL
+            for (int p = RPL - 1; p >= 0; p--) {  // (lowest pass first, then lowest lane: the last assignment that holds is the lowest pass)
+                const unsigned long long bp = (bo_ballot(top_ && bi / W == p) >> hb) & gmask;
+                win = bp ? W * p + __builtin_ctzll(bp) : win;
+            }
+            if (wide) {  // (the maximum may sit beyond the records of one pass)
+                for (int p = RPL; p * W < 256; p++) {
+                    const unsigned long long bp = (bo_ballot(top_ && bi / W == p) >> hb) & gmask;
+                    if (win < 0 && bp) win = W * p + __builtin_ctzll(bp);
                 }
             }
             const bool nan_all = lv && win < 0;  // every score was NaN: take the first child (it exists: a run is never empty)
             if (bo_ballot(nan_all) != 0) {
                 if (nan_all) {
                     win = 0;
-                    if (c == 0) { bi = 0; bne = r0[u].n; bl = r0[u].link; bo_atomic_or(&e.status[FW_G(u)], ST_NAN_SCORE); }  // (no in-flight visits added: the search is broken anyway)
+                    if (c == 0) { bi = 0; bne = r[u][0].n; bl = r[u][0].link; bo_atomic_or(&e.status[FW_G(u)], ST_NAN_SCORE); }  // (no in-flight visits added: the search is broken anyway)
                 }
             }
             // the winner's statistics come from the lane that scored it (index win belongs to lane win & 31, whose own best it is)
-            const int src = hb + (win & 31);
+            const int src = hb + (win & (W - 1));
             const int w_ne = bo_shfl(bne, src);
             int w_l = bo_shfl(bl, src);
             // ---- what this game requests next, and the request itself --------------------------------------------------------
@@ -630,15 +652,15 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
                 const bool fresh = ended && w_l == FW_UNVISITED;
                 const int n_rows_l = FW_C(u, FWC_NROWS);
                 const uint64_t h0 = bo_ballot(fresh && c < n_rows_l && FW_C(u, FWC_F(L, FWR_SLOT, c < LCAP ? c : 0)) == leaf);
-                const uint64_t h1 = LCAP > 32 ? bo_ballot(fresh && c + 32 < n_rows_l && FW_C(u, FWC_F(L, FWR_SLOT, c + 32 < LCAP ? c + 32 : 0)) == leaf) : 0ull;
+                const uint64_t h1 = LCAP > W ? bo_ballot(fresh && c + W < n_rows_l && FW_C(u, FWC_F(L, FWR_SLOT, c + W < LCAP ? c + W : 0)) == leaf) : 0ull;
                 if (ended) {
-                    const unsigned m0 = (unsigned)(h0 >> hb), m1 = (unsigned)(h1 >> hb);
+                    const unsigned long long m0 = (h0 >> hb) & gmask, m1 = (h1 >> hb) & gmask;
                     const int plen = old_d + 1;
                     int q;
                     if (w_l == FW_MATE) q = FW_SIM_MATE;
                     else if (w_l == FW_DRAW) q = FW_SIM_DRAW;
-                    else if (m0) q = __builtin_ctz(m0);
-                    else if (m1) q = 32 + __builtin_ctz(m1);
+                    else if (m0) q = __builtin_ctzll(m0);
+                    else if (m1) q = W + __builtin_ctzll(m1);
                     else {  // becomes NN row n_rows
                         q = n_rows_l;
                         if (c == 0) {
@@ -648,8 +670,7 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
                     }
                     if (c == 0) { FW_C(u, FWC_F(L, FWS_ROW, s)) = q; FW_C(u, FWC_F(L, FWS_PLEN, s)) = plen; FW_C(u, FWC_NSTEP) = s + 1; }
                     int *path = f.sim_path + ((size_t)FW_G(u) * L + s) * BO_FW_PATH_CAP;
-                    if (c < plen) path[c] = s_path[slot][c];
-                    if (c + 32 < plen) path[c + 32] = s_path[slot][c + 32];
+                    for (int k = c; k < plen; k += W) path[k] = s_path[slot][k];
                 }
                 bo_wave_sync();  // (the row / simulation lists in LDS)
             }
@@ -673,7 +694,7 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
                 for (int s = 0; s < ns; s++) {  // (every simulation of the step hit a known terminal: exact values, no rows)
                     const int q = FW_C(u, FWC_F(L, FWS_ROW, s)), plen = FW_C(u, FWC_F(L, FWS_PLEN, s));
                     const float v = q == FW_SIM_MATE ? 1.0f : 0.0f;
-                    for (int k = c; k < plen; k += 32) {
+                    for (int k = c; k < plen; k += W) {
                         if (k == 0) continue;
                         WRec *R = FW_A(u) + sp[(size_t)s * BO_FW_PATH_CAP + k];
                         const fw_nw y = fw_ld_nw(R);
@@ -707,7 +728,7 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
         int *ctl = fw_ctl(f, FW_G(u));
         BO_UNROLL
         for (int k = 0; k < NCR; k++)
-            if (c + 32 * k < FWC_HEAD + FWR_FIELDS * L) ctl[c + 32 * k] = FW_C(u, c + 32 * k);
+            if (c + W * k < FWC_HEAD + FWR_FIELDS * L) ctl[c + W * k] = FW_C(u, c + W * k);
     }
     if (e.c.profile && lane == 0) {
         unsigned long long *pp = e.prof + (size_t)g0 * BO_PROF_SLOTS;
@@ -1037,7 +1058,7 @@ BO_FW_LANE_OCC BO_KERNEL void bo_k_fw_select_lane_nt(Eng e, FastW f, const float
 #endif
 #define BO_FW_SELECT_KERNEL(UT, LCAP, FL, OCC)                                                                         \
     OCC BO_KERNEL void bo_k_fw_select_u##UT##l##LCAP##_##FL(Eng e, FastW f, const float *value, int kind) {            \
-        fw_select_body<UT, LCAP, ((FL) & FW_SEL_NT) != 0, ((FL) & FW_SEL_ROOT_IN_REGS) != 0>(e, f, value, kind);        \
+        fw_select_body<32, 2, UT, LCAP, ((FL) & FW_SEL_NT) != 0, ((FL) & FW_SEL_ROOT_IN_REGS) != 0>(e, f, value, kind); \
     }
 #define BO_FW_SELECT_FLAGSETS(UT, LCAP, DENSE_W)                                                                       \
     BO_FW_SELECT_KERNEL(UT, LCAP, 0, ) BO_FW_SELECT_KERNEL(UT, LCAP, 1, ) BO_FW_SELECT_KERNEL(UT, LCAP, 2, ) BO_FW_SELECT_KERNEL(UT, LCAP, 3, ) \
@@ -1048,6 +1069,13 @@ BO_FW_SELECT_FLAGSETS(2, 4, 6)   // 80 registers: 6 waves per SIMD, 96 games per
 BO_FW_SELECT_KERNEL(4, 8, 0, ) BO_FW_SELECT_KERNEL(4, 8, 3, )
 BO_FW_SELECT_KERNEL(2, 16, 0, ) BO_FW_SELECT_KERNEL(2, 16, 3, )
 BO_FW_SELECT_KERNEL(1, 64, 0, ) BO_FW_SELECT_KERNEL(1, 64, 3, )
+// eight lanes per game: eight games per wave-instruction, five records per lane
+#define BO_FW_SELECT_OCT(LCAP, FL)                                                                                     \
+    BO_KERNEL void bo_k_fw_select_o8l##LCAP##_##FL(Eng e, FastW f, const float *value, int kind) {                      \
+        fw_select_body<8, 5, 1, LCAP, ((FL) & FW_SEL_NT) != 0, ((FL) & FW_SEL_ROOT_IN_REGS) != 0>(e, f, value, kind);   \
+    }
+BO_FW_SELECT_OCT(4, 0) BO_FW_SELECT_OCT(4, 1) BO_FW_SELECT_OCT(4, 2) BO_FW_SELECT_OCT(4, 3)
+BO_FW_SELECT_OCT(8, 0) BO_FW_SELECT_OCT(8, 2)
 
 // ---- leaf: materialise the position of row r, its legal moves, is_game_over(claim_draw=True), its planes ------------------
 BO_KERNEL void bo_k_fw_leaf(Eng e, FastW f, float *nn_in) {

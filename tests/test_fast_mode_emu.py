@@ -249,6 +249,11 @@ def check_multi(backend, L, sims, opts):
     (4, 60, dict(select_flags=8)),       # one lane per game
     (4, 80, dict(select_flags=9)),
     (4, 130, dict(select_flags=8)),
+    (4, 90, dict(select_flags=16)),      # eight lanes per game
+    (4, 90, dict(select_flags=18)),
+    (3, 60, dict(select_flags=17)),
+    (7, 84, dict(select_flags=16)),
+    (8, 96, dict(select_flags=18)),
     (4, 70, dict()),                      # the defaults
     (4, 60, dict(games_per_halfwave=4, select_flags=2)),
     (4, 60, dict(games_per_halfwave=4, select_flags=0)),
