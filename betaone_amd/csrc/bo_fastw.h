@@ -274,7 +274,6 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
     constexpr int NW = (LCAP + 3) / 4;
     BO_SHARED unsigned s_idx[NSL][BO_FW_PATH_CAP][NW];         // child index chosen at depth d by descent s of the step: byte s of the depth's words
     BO_SHARED float s_rcp[BO_FW_RCP_TAB];                          // RN(1 / k)
-    BO_SHARED int s_path[NSL][BO_FW_PATH_CAP];                  // record ids of the descent in progress
     const int lane = bo_lane(), half = lane / W, c = lane % W, hb = half * W;  // (`half`: this lane's group)
     const unsigned long long gmask = W == 64 ? ~0ull : ((1ull << W) - 1ull);
     const int L = f.L, S = e.c.S, G = e.c.G;
@@ -466,7 +465,7 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
         } else {
             busy[u] = true;
             link[u] = root_link[u]; pn[u] = root_n[u] + 1;
-            if (c == 0) s_path[FW_SLOT(u)][0] = 0;
+            if (c == 0) f.sim_path[(size_t)FW_G(u) * L * BO_FW_PATH_CAP] = 0;
             if (ROOTC) {
                 const int nrec = fw_ngran(root_link[u]) * BO_FW_GR;
                 const WRec *R = FW_A(u) + (size_t)fw_first(root_link[u]) * BO_FW_GR;
@@ -525,13 +524,26 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
             bool ok[RPL];
             float rq[RPL], ru[RPL];
             bool beyond = lv && pn[u] >= BO_FW_SQRT_TAB;
+            unsigned cpk = 0u;  // descents in flight through this lane's records: 4 bits per pass (an index b belongs to lane b % W, pass b / W)
+            BO_UNROLL
+            for (int sp = 0; sp < LCAP - 1; sp++) {
+                const unsigned bb = (iw[sp >> 2] >> (8 * (sp & 3))) & 255u;
+                const unsigned mine = (unsigned)((M[u] >> sp) & 1) & ((bb % W) == (unsigned)c ? 1u : 0u);
+                cpk += (bb / W < 8u ? mine : 0u) << (4 * (bb / W & 7u));
+            }
+            int nkl = 0;
             BO_UNROLL
             for (int k = 0; k < RPL; k++) {
-                cnt[k] = 0;
-                BO_UNROLL
-                for (int sp = 0; sp < LCAP - 1; sp++)
-                    cnt[k] += (int)((M[u] >> sp) & 1) & ((int)((iw[sp >> 2] >> (8 * (sp & 3))) & 255u) == c + W * k ? 1 : 0);
+                if (LCAP <= 16) {
+                    cnt[k] = k < 8 ? (int)((cpk >> (4 * k)) & 15u) : 0;
+                } else {  // (more than 15 descents can share a record: count them one by one)
+                    cnt[k] = 0;
+                    BO_UNROLL
+                    for (int sp = 0; sp < LCAP - 1; sp++)
+                        cnt[k] += (int)((M[u] >> sp) & 1) & ((int)((iw[sp >> 2] >> (8 * (sp & 3))) & 255u) == c + W * k ? 1 : 0);
+                }
                 ok[k] = lv && c + W * k < nrec && r[u][k].n >= 0;
+                nkl += ok[k] ? 1 : 0;
                 ne[k] = r[u][k].n + cnt[k];
                 const int t = ne[k] < 0 ? 0 : ne[k] > BO_FW_RCP_TAB - 2 ? BO_FW_RCP_TAB - 2 : ne[k];
                 rq[k] = s_rcp[t]; ru[k] = s_rcp[t + 1];
@@ -556,13 +568,12 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
                 sc = ((ok) && sc == sc) ? sc : -__builtin_inff();                                               \
             }
             float best = -__builtin_inff();
-            int bi = c, bne = ne[0], bl = r[u][0].link, nk = 0;
+            int bi = c, bne = ne[0], bl = r[u][0].link;
             BO_UNROLL
             for (int k = 0; k < RPL; k++) {  // (a later record of the lane wins only with a strictly better score: first maximum in child order)
                 BO_FW_SCORE(r[u][k], cnt[k], ne[k], rq[k], ru[k], ok[k], sck)
                 const bool better = k == 0 || sck > best;
                 best = better ? sck : best; bi = better ? c + W * k : bi; bne = better ? ne[k] : bne; bl = better ? r[u][k].link : bl;
-                nk += __builtin_popcountll((bo_ballot(ok[k]) >> hb) & gmask);  // children scanned at this level
             }
             const bool wide = bo_ballot(lv && nrec > W * RPL) != 0;  // a run with more records than one pass takes, somewhere in the wave
             int extra = 0;
@@ -588,24 +599,21 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
             // first maximum in child order within the half-wave: the maximum by four DPP row rounds and one cross-row exchange, then
             // the lowest child index among the lanes that hold it (a lane's index is lane + 32 * pass: lowest pass first, then lowest lane)
             float mx = best;
-            { const float o = __builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, mx), 0)); mx = o > mx ? o : mx; }
-            { const float o = __builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, mx), 1)); mx = o > mx ? o : mx; }
-            { const float o = __builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, mx), 2)); mx = o > mx ? o : mx; }
-            if (W >= 16) { const float o = __builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, mx), 3)); mx = o > mx ? o : mx; }
-            if (W >= 32) { const float o = bo_shfl_xor_f(mx, 16); mx = o > mx ? o : mx; }
-            const bool top_ = lv && best == mx && mx > -__builtin_inff();
-            int win = -1;
-            BO_UNROLL
-            for (int p = RPL - 1; p >= 0; p--) {  // (lowest pass first, then lowest lane: the last assignment that holds is the lowest pass)
-                const unsigned long long bp = (bo_ballot(top_ && bi / W == p) >> hb) & gmask;
-                win = bp ? W * p + __builtin_ctzll(bp) : win;
-            }
-            if (wide) {  // (the maximum may sit beyond the records of one pass)
-                for (int p = RPL; p * W < 256; p++) {
-                    const unsigned long long bp = (bo_ballot(top_ && bi / W == p) >> hb) & gmask;
-                    if (win < 0 && bp) win = W * p + __builtin_ctzll(bp);
-                }
-            }
+            int nk = nkl;  // children scanned at this level: the lanes' counts added up alongside
+#define BO_FW_RED(kind_)                                                                                                 \
+            { const float o = __builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, mx), kind_)); mx = o > mx ? o : mx; nk += BO_ROW_XCHG(nk, kind_); }
+            BO_FW_RED(0) BO_FW_RED(1) BO_FW_RED(2)
+            if (W >= 16) BO_FW_RED(3)
+            if (W >= 32) { const float o = bo_shfl_xor_f(mx, 16); mx = o > mx ? o : mx; nk += bo_shfl_xor(nk, 16); }
+#undef BO_FW_RED
+            // the lowest child index among the lanes that hold the maximum: a minimum over the group
+            int win = (lv && best == mx && mx > -__builtin_inff()) ? bi : 0x7fffffff;
+#define BO_FW_MIN(kind_) { const int o = BO_ROW_XCHG(win, kind_); win = o < win ? o : win; }
+            BO_FW_MIN(0) BO_FW_MIN(1) BO_FW_MIN(2)
+            if (W >= 16) BO_FW_MIN(3)
+            if (W >= 32) { const int o = bo_shfl_xor(win, 16); win = o < win ? o : win; }
+#undef BO_FW_MIN
+            if (win == 0x7fffffff) win = -1;
             const bool nan_all = lv && win < 0;  // every score was NaN: take the first child (it exists: a run is never empty)
             if (bo_ballot(nan_all) != 0) {
                 if (nan_all) {
@@ -638,7 +646,7 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
             const int leaf = first * BO_FW_GR + win;
             if (lv && c == 0) {
                 reinterpret_cast<unsigned char *>(&s_idx[slot][dd][0])[s] = (unsigned char)win;
-                s_path[slot][dd] = leaf;
+                f.sim_path[((size_t)FW_G(u) * L + s) * BO_FW_PATH_CAP + dd] = leaf;  // (the path, level by level: read back by the next launch's backup)
                 FW_ST(u, ST_LEVELS) += 1; FW_ST(u, ST_KIDS) += nk;
                 if (!(ROOTC && atroot)) FW_ST(u, ST_GRAN) += ngran;
             }
@@ -669,8 +677,7 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
                         }
                     }
                     if (c == 0) { FW_C(u, FWC_F(L, FWS_ROW, s)) = q; FW_C(u, FWC_F(L, FWS_PLEN, s)) = plen; FW_C(u, FWC_NSTEP) = s + 1; }
-                    int *path = f.sim_path + ((size_t)FW_G(u) * L + s) * BO_FW_PATH_CAP;
-                    for (int k = c; k < plen; k += W) path[k] = s_path[slot][k];
+                    if (more && c == 0) f.sim_path[((size_t)FW_G(u) * L + s + 1) * BO_FW_PATH_CAP] = 0;  // (the next descent's path starts at the root)
                 }
                 bo_wave_sync();  // (the row / simulation lists in LDS)
             }
