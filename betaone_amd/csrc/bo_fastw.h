@@ -302,11 +302,19 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
     {
         int creg[UT][NCR], ph[UT], top0[UT];
         float vreg[UT][NVR];
+        // (requested with the control blocks, before anyone knows whether they are needed: both arenas' root records and the first
+        //  BO_FW_BK_CH paths' record ids at this lane's depth -- the backup then starts one round trip earlier)
+        WRec root2[UT][2];
+        int pid[UT][BO_FW_BK_CH];
         BO_UNROLL
         for (int u = 0; u < UT; u++) {
             const bool in = FW_G(u) < G;
             const int gg = in ? FW_G(u) : g0;
             const int *ctl = fw_ctl(f, gg);
+            BO_UNROLL
+            for (int a = 0; a < 2; a++) root2[u][a] = fw_ld<false>(f.arena + fw_arena_off(f, gg, a));
+            BO_UNROLL
+            for (int j = 0; j < BO_FW_BK_CH; j++) pid[u][j] = f.sim_path[((size_t)gg * L + (j < L ? j : L - 1)) * BO_FW_PATH_CAP + c];
             BO_UNROLL
             for (int k = 0; k < NCR; k++) creg[u][k] = c + W * k < f.CS ? ctl[c + W * k] : 0;
             BO_UNROLL
@@ -339,8 +347,8 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
         int maxstep = 0;
         BO_UNROLL
         for (int u = 0; u < UT; u++) {
-            rootrec[u].n = 0; rootrec[u].w = 0.0f; rootrec[u].prior = 0.0f; rootrec[u].link = FW_UNVISITED;
-            if (on[u]) rootrec[u] = fw_ld<false>(FW_A(u));  // (n is not touched by the backup below: the root only counts visits)
+            rootrec[u] = FW_C(u, FWC_CUR) ? root2[u][1] : root2[u][0];  // (its n is not touched by the backup below: the root only counts visits)
+            if (!on[u]) { rootrec[u].n = 0; rootrec[u].link = FW_UNVISITED; }
             bk[u] = on[u] && n_rows[u] > 0;
             if (bk[u] && n_step[u] > maxstep) maxstep = n_step[u];
         }
@@ -373,7 +381,7 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
                     if (plen > W) deep[u] = 1;
                     val[u][j] = c >= 1 && c < plen;  // the root (depth 0) only counts visits
                     sgn[u][j] = ((plen - 1 - c) & 1) ? -v : v;
-                    rec[u][j] = val[u][j] ? sp[(size_t)s * BO_FW_PATH_CAP + c] : 0;
+                    rec[u][j] = val[u][j] ? (s0 == 0 ? pid[u][j] : sp[(size_t)s * BO_FW_PATH_CAP + c]) : 0;
                 }
             }
             BO_UNROLL
