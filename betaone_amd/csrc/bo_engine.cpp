@@ -252,8 +252,8 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
         FastW &f = e->f;
         const size_t L = (size_t)cfg->leaves_per_step;
         f.L = (int)L;
-        f.sel_ut = 2; f.sel_flags = FW_SEL_OCT | FW_SEL_ROOT_IN_REGS;  // measured fastest on an MI355X (profiles/r03_fast_select_variants.md):
-                                                                       // eight lanes per game, the root's run in registers (more than 8 leaves per step: half-wave forms)
+        f.sel_ut = 2; f.sel_flags = FW_SEL_OCT;  // measured fastest on an MI355X (profiles/r03_fast_select_variants.md): eight lanes per game
+                                                 // (more than 8 leaves per step: the half-wave forms)
         // Arena capacity per game, in granules of BO_FW_GR records.  A search creates at most S + L + 1 runs (one per expanded
         // node: header + 1..32 record granules, ~6 granules = 768 bytes at chess's ~35 legal moves) on top of the subtree kept
         // from the previous search: room for 24 granules (3 KB) per possible expansion of this and of the previous search.

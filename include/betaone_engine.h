@@ -212,7 +212,7 @@ int bo_debug_tree(bo_engine *e, int slot, bo_node *out, int32_t cap, int32_t *n_
 /* FAST mode (cfg.mode = 1; NOT the reference's semantics).  Every argument: -1 leaves the
  * setting as it is.  tree_reuse != 0 (default) keeps the played child's subtree as the next search's tree -- the reference
  * rebuilds the tree every move (mcts.py:176).  games_per_halfwave (2 or 4, default 2): games the select + backup kernel
- * interleaves per half-wavefront in the half-wave forms (leaves_per_step > 8 caps it at 2, > 16 at 1).  select_flags (default 18):
+ * interleaves per half-wavefront in the half-wave forms (leaves_per_step > 8 caps it at 2, > 16 at 1).  select_flags (default 16):
  * bit 0 non-temporal loads of the child runs, bit 1 the root's run stays in registers for all descents of a step, bit 2 the
  * half-wave kernel is built for one more wavefront per SIMD (register spills), bit 3 (leaves_per_step == 4 only) the
  * one-lane-per-game form, bit 4 (leaves_per_step <= 8) eight lanes per game = eight games per wave-instruction.
