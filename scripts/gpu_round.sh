@@ -47,9 +47,9 @@ for step in "$@"; do
     trace)   mkdir -p $out/${tag}_trace; run trace 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace -- python bench.py --steps 200 --opening-steps 0 --no-cpu-baseline --no-roofline ;
              python scripts/kernel_percentiles.py $out/${tag}_trace > $out/${tag}_trace_percentiles.md 2>&1 ; rm -f $out/${tag}_trace/*/*_kernel_trace.csv.keep ; tail -n 40 $out/${tag}_trace_percentiles.md ;;
     pmcfast) mkdir -p $out/${tag}_pmcfast; run pmcfast 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex "bo_k_fw_select" --output-format csv -d $out/${tag}_pmcfast -- python bench.py --fast --preroll 2 --steps 1 --warmup 0 --opening-steps 0 --no-cpu-baseline --no-graph --roofline-steps 32 ;
-             python scripts/pmc_summary.py $out/${tag}_pmcfast > $out/${tag}_pmcfast.md 2>&1 ; cat $out/${tag}_pmcfast.md ; rm -rf $out/${tag}_pmcfast ;;
+             python scripts/pmc_summary.py $out/${tag}_pmcfast FETCH_SIZE 32 > $out/${tag}_pmcfast.md 2>&1 ; cat $out/${tag}_pmcfast.md ; rm -rf $out/${tag}_pmcfast ;;
     pmcfastw) mkdir -p $out/${tag}_pmcfastw; run pmcfastw 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --kernel-include-regex "bo_k_fw_select" --output-format csv -d $out/${tag}_pmcfastw -- python bench.py --fast --preroll 2 --steps 1 --warmup 0 --opening-steps 0 --no-cpu-baseline --no-graph --roofline-steps 32 ;
-             python scripts/pmc_summary.py $out/${tag}_pmcfastw WRITE_SIZE > $out/${tag}_pmcfastw.md 2>&1 ; cat $out/${tag}_pmcfastw.md ; rm -rf $out/${tag}_pmcfastw ;;
+             python scripts/pmc_summary.py $out/${tag}_pmcfastw WRITE_SIZE 32 > $out/${tag}_pmcfastw.md 2>&1 ; cat $out/${tag}_pmcfastw.md ; rm -rf $out/${tag}_pmcfastw ;;
     pmctower) for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
                  p=$(echo $pass | cut -d" " -f1); mkdir -p $out/${tag}_pmctower_$p;
                  run pmctower_$p 400 rocprofv3 --pmc $pass --kernel-trace --kernel-include-regex "bo_k_tower_wg|bo_k_heads" --output-format csv -d $out/${tag}_pmctower_$p -- python scripts/forward_profile.py tower_wg 256 ;
