@@ -12,6 +12,7 @@
 #include "bo_tower.h"
 #include "bo_tower_wg.h"
 #include "bo_tower_h.h"
+#include "bo_tower_s.h"
 #include "bo_heads.h"
 #include "bo_rt.h"
 #include "bo_hostrng.h"
@@ -1220,29 +1221,31 @@ extern "C" int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layer
 #else
     static_assert(sizeof(bo_tower_layer_desc) == sizeof(bo_tower_layer), "descriptor layouts must agree");
     if (!layers || !weights || !params || !out || n_layers < 1 || n_layers > 4096) return fail(BO_E_ARG, "bad arguments");
-    if (algo == BO_TOWER_DIRECT_F16 ? (channels != 128 && channels != 256) : (channels != 64 && channels != 128))
-        return fail(BO_E_CONFIG, "bo_nn_tower: channels must be 64 or 128 (fp32: two padded images per board in LDS) or 128 / 256 (BO_TOWER_DIRECT_F16)");
+    const bool half_w = algo == BO_TOWER_DIRECT_F16 || algo == BO_TOWER_SPLIT_F16;  // fp16 weight fragments, 16-byte offsets
+    if (half_w ? (channels != 128 && channels != 256) : (channels != 64 && channels != 128))
+        return fail(BO_E_CONFIG, "bo_nn_tower: channels must be 64 or 128 (fp32: two padded images per board in LDS) or 128 / 256 (BO_TOWER_DIRECT_F16, BO_TOWER_SPLIT_F16)");
     if (n_weights % 4) return fail(BO_E_ARG, "n_weights must be a multiple of 4");
-    if (algo != BO_TOWER_DIRECT && algo != BO_TOWER_WINOGRAD && algo != BO_TOWER_DIRECT_F16) return fail(BO_E_ARG, "unknown algo");
+    if (algo != BO_TOWER_DIRECT && algo != BO_TOWER_WINOGRAD && !half_w) return fail(BO_E_ARG, "unknown algo");
     if (algo == BO_TOWER_DIRECT_F16 && !head) return fail(BO_E_ARG, "BO_TOWER_DIRECT_F16 needs the fused head (it has no tower output buffer)");
     const int C = channels;
+    const int split = algo == BO_TOWER_SPLIT_F16 ? 2 : 1;  // (hi, lo) fragment pairs; one more float (the inverse weight scale) behind every bias
     for (int l = 0; l < n_layers; l++) {  // every offset the kernel will form stays inside the two buffers
         const bo_tower_layer_desc &L = layers[l];
         // K steps per layer: direct = groups of 8 input channels, Winograd = groups of 4; the input conv is padded to 128
         const int cin = L.kind == 0 ? 128 : C;
         const int want_t4 = algo == BO_TOWER_DIRECT ? cin / 8 : algo == BO_TOWER_WINOGRAD ? cin / 4 : 9 * cin / 16;
         const int64_t w4 = algo == BO_TOWER_DIRECT ? (int64_t)9 * want_t4 * C * 2
-                           : algo == BO_TOWER_WINOGRAD ? (int64_t)want_t4 * (C / 16) * 4 * 64 : (int64_t)want_t4 * (C / 32) * 64;
+                           : algo == BO_TOWER_WINOGRAD ? (int64_t)want_t4 * (C / 16) * 4 * 64 : (int64_t)want_t4 * (C / 32) * 64 * split;
         if (L.kind < 0 || L.kind > 3 || (l == 0) != (L.kind == 0)) return fail(BO_E_ARG, "layer " + std::to_string(l) + ": bad kind");
         if (L.kind == 1 && (l + 1 >= n_layers || layers[l + 1].kind < 2)) return fail(BO_E_ARG, "a first conv must be followed by a second conv");
         if (L.kind >= 2 && layers[l - 1].kind != 1) return fail(BO_E_ARG, "a second conv must follow a first conv");
         if (L.t4 != want_t4) return fail(BO_E_ARG, "layer " + std::to_string(l) + ": t4 must be " + std::to_string(want_t4));
         if (L.w_off4 < 0 || ((int64_t)L.w_off4 + w4) * 4 > n_weights) return fail(BO_E_ARG, "weights offset out of range");
-        if (L.bias_off < 0 || (int64_t)L.bias_off + C > n_params) return fail(BO_E_ARG, "bias offset out of range");
+        if (L.bias_off < 0 || (int64_t)L.bias_off + C + (split - 1) > n_params) return fail(BO_E_ARG, "bias offset out of range");
         if (algo == BO_TOWER_WINOGRAD && (L.bias_off & 3)) return fail(BO_E_ARG, "BO_TOWER_WINOGRAD: bias_off must be a multiple of 4 floats");
         if (L.kind == 3) {
             if (L.hidden < 1 || L.hidden > 16) return fail(BO_E_CONFIG, "SE hidden width must be 1..16");
-            if (algo == BO_TOWER_DIRECT_F16 && L.hidden > C / 16) return fail(BO_E_CONFIG, "BO_TOWER_DIRECT_F16: SE hidden width must be <= channels/16");
+            if (half_w && L.hidden > C / 16) return fail(BO_E_CONFIG, "fp16-pipe towers: SE hidden width must be <= channels/16");
             if (L.se_w1_off < 0 || (int64_t)L.se_w1_off + (int64_t)L.hidden * C > n_params || L.se_w2_off < 0 ||
                 (int64_t)L.se_w2_off + (int64_t)L.hidden * C > n_params)
                 return fail(BO_E_ARG, "SE weight offset out of range");
@@ -1251,13 +1254,13 @@ extern "C" int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layer
     }
     if (layers[n_layers - 1].kind < 2) return fail(BO_E_ARG, "the tower must end with a second conv");
     if (head) {
-        if (algo == BO_TOWER_DIRECT) return fail(BO_E_CONFIG, "fused head convolutions need BO_TOWER_WINOGRAD or BO_TOWER_DIRECT_F16");
+        if (algo == BO_TOWER_DIRECT) return fail(BO_E_CONFIG, "fused head convolutions need BO_TOWER_WINOGRAD, BO_TOWER_DIRECT_F16 or BO_TOWER_SPLIT_F16");
         if (head->channels < 1 || head->channels > 256 || head->split < 0 || head->split > head->channels) return fail(BO_E_ARG, "bad head channels/split");
-        if (head->b_off < 0 || (int64_t)head->b_off + head->channels > n_params) return fail(BO_E_ARG, "head bias offset out of range");
+        if (head->b_off < 0 || (int64_t)head->b_off + head->channels + (split - 1) > n_params) return fail(BO_E_ARG, "head bias offset out of range");
         if (algo == BO_TOWER_WINOGRAD) {
             if (head->w_off < 0 || (head->w_off & 3) || (int64_t)head->w_off + (int64_t)((head->channels + 15) / 16) * 16 * C > n_params)
                 return fail(BO_E_ARG, "head weight offset out of range");
-        } else if (head->w_off < 0 || ((int64_t)head->w_off + (int64_t)((head->channels + 31) / 32) * (C / 16) * 64) * 4 > n_weights) {
+        } else if (head->w_off < 0 || ((int64_t)head->w_off + (int64_t)((head->channels + 31) / 32) * (C / 16) * 64 * split) * 4 > n_weights) {
             return fail(BO_E_ARG, "head weight offset out of range");
         }
     }
@@ -1310,6 +1313,16 @@ extern "C" int bo_nn_tower_forward(bo_tower *t, const float *x_dev, float *y_dev
         const bo_h8 *w8 = reinterpret_cast<const bo_h8 *>(t->wts);
         if (t->channels == 256) hipLaunchKernelGGL((bo_k_tower_h<256, 2>), dim3(g2), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, batch, hh);
         else hipLaunchKernelGGL((bo_k_tower_h<128, 1>), dim3(g2), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, batch, hh);
+        RT((int)hipGetLastError());
+        return BO_OK;
+    }
+    if (t->algo == BO_TOWER_SPLIT_F16) {  // float32 in and out, fp16 (hi, lo) pairs on the matrix pipe; one board per workgroup
+        bo_tower_head_s hs;
+        hs.channels = t->head_channels; hs.split = t->head_split; hs.w_off8 = t->head_w_off; hs.b_off = t->head_b_off;
+        hs.out_a = (float *)head_a_dev; hs.out_b = (float *)head_b_dev;
+        const bo_h8 *w8 = reinterpret_cast<const bo_h8 *>(t->wts);
+        if (t->channels == 256) hipLaunchKernelGGL((bo_k_tower_s<256, 2>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
+        else hipLaunchKernelGGL((bo_k_tower_s<128, 1>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
         RT((int)hipGetLastError());
         return BO_OK;
     }

@@ -6,8 +6,9 @@
 //   * fp16 MFMA is 16x the fp32 rate, so a 3x3 layer of one board costs 7.7 us of MFMA time while its 1.18 MB of
 //     weights need ~17 us to stream from L2 to a CU: a workgroup therefore keeps TWO boards (512 games per GPU =
 //     2 boards per CU) and every weight fragment feeds 4 MFMAs (2 boards x 2 position halves);
-//   * activations live in LDS channels-last, [board][padded 10x10 cell][C + 8] fp16 (528-byte cell pitch: the B
-//     operand of a lane, 8 consecutive channels of one cell = one ds_read_b128, is bank-conflict free).  ONE image
+//   * activations live in LDS channels-last, [board][padded 10x10 cell][C] fp16, the 16-byte chunks of a cell swizzled
+//     (bo_sw below: the B operand of a lane, 8 consecutive channels of one cell = one ds_read_b128, is then
+//     bank-conflict free for every tap; the padded pitch of C + 8 used before was 3-way conflicted).  ONE image
 //     per board: each wave holds its 32 output channels x all 128 positions in 64 accumulator registers, so after a
 //     barrier the layer's output overwrites its input in place; the skip connection stays in registers (packed fp16);
 //   * direct (not Winograd) convolution: M = 32 output channels per wave (8 waves), N = 128 positions, K = 9 taps x C
@@ -20,6 +21,19 @@
 
 typedef _Float16 bo_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 bo_h4 __attribute__((ext_vector_type(4)));
+
+// LDS images [padded 10x10 cell][C fp16 channels]: a lane's B operand is one 16-byte chunk (8 channels) of a cell, and a
+// ds_read_b128 is served in four groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31} of each wave half,
+// MI355X_MICROARCH.md section LDS) whose 16 cells must sit on 16 different bank quads.  With a linear cell pitch two cells
+// 16 apart (rows r and r+2 of a 10-wide image overlap that way) always collide: the pitch of C + 8 halves used before cost
+// three LDS cycles per group instead of one, and the four waves' reads then took as long as the MFMAs they feed.  So chunk
+// j of a cell is stored at chunk position j ^ bo_sw(cell) (low four bits): for every tap and both lane groups the 16 cells
+// of a group get 16 different positions (checked exhaustively, tests/test_abi.py).
+__device__ __host__ inline int bo_sw(int cell) { return ((cell % 10) + 8 * (cell / 10)) & 15; }
+template <int PH>
+__device__ inline int bo_sw_addr(int cell, int chunk, int sw) { return cell * PH + ((chunk & ~15) << 3) + (((chunk ^ sw) & 15) << 3); }
+template <int PH>
+__device__ inline int bo_sw_addr(int cell, int chunk) { return bo_sw_addr<PH>(cell, chunk, bo_sw(cell)); }
 
 struct bo_tower_head_h {
     int channels = 0, split = 0, w_off8 = 0, b_off = 0;  // head weights: [mt 2][step C/16][lane][8 fp16] at bo_h8 offset w_off8 in wts
@@ -34,7 +48,7 @@ template <int C, int MT, int LAB = 0>
 __global__ void __launch_bounds__(C * 2 / MT)
 bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const float *__restrict__ params,
              const bo_tower_layer *__restrict__ layers, int n_layers, int B, bo_tower_head_h head) {
-    constexpr int NW = C / (32 * MT), NT = NW * 64, PH = C + 8, CELLS = 100, IMGH = CELLS * PH, CIN0 = 120, HPW = (16 + NW - 1) / NW;
+    constexpr int NW = C / (32 * MT), NT = NW * 64, PH = C, CELLS = 100, IMGH = CELLS * PH, CIN0 = 120, HPW = (16 + NW - 1) / NW;
     __shared__ __attribute__((aligned(16))) _Float16 X[2 * IMGH];
     __shared__ __attribute__((aligned(16))) float pooled[2][C];
     __shared__ float hid[2][16];
@@ -48,7 +62,9 @@ bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
     bo_h8 a[8][MT];            // A fragments of 8 consecutive K-steps
     bo_h8 bq[2][4];            // B operands of two consecutive K-steps
     bo_h4 skip[MT][4][4];      // block input at this lane's (positions, channels), packed like the LDS writes
-    const _Float16 *xl = X + (size_t)cell0 * PH + 8 * kg;  // + board*IMGH + half*40*PH + tap/channel offset
+    const int sw0 = bo_sw(cell0);  // (position n + 32 sits 4 rows further down: the same swizzle)
+    // B operand address (in halves) of K-step j of a group of 8: tap cell offset `tc`, first channel group cg0 (a multiple of 8)
+    auto b_base = [&](int tc, int cg0) { return (cell0 + tc) * PH + 16 * cg0 + (((kg ^ bo_sw(cell0 + tc)) & 15) << 3); };
     // weight fragments through a buffer descriptor: per-thread offset in one VGPR, layer / K-step offset in scalar registers,
     // no vector address arithmetic per load (see bo_tower_wg.h)
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bo_h8 *>(wts), 0, 0x7fffffff, 0x00020000);
@@ -63,12 +79,13 @@ bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
             a[j][mt] = __builtin_bit_cast(bo_h8, v);
         }
     };
-    auto read_b = [&](bo_h8(&b)[4], int off) {  // off: (tap offset in cells) * PH + 16 * channel group
+    auto read_b = [&](bo_h8(&b)[4], int base, int j) {  // K-step j of the group whose b_base() is `base`
         if (LAB == 2 || LAB >= 5) return;
-        b[0] = *reinterpret_cast<const bo_h8 *>(xl + off);
-        b[1] = *reinterpret_cast<const bo_h8 *>(xl + off + 40 * PH);
-        b[2] = *reinterpret_cast<const bo_h8 *>(xl + off + IMGH);
-        b[3] = *reinterpret_cast<const bo_h8 *>(xl + off + IMGH + 40 * PH);
+        const _Float16 *p = X + (base ^ (j << 4));
+        b[0] = *reinterpret_cast<const bo_h8 *>(p);
+        b[1] = *reinterpret_cast<const bo_h8 *>(p + 40 * PH);
+        b[2] = *reinterpret_cast<const bo_h8 *>(p + IMGH);
+        b[3] = *reinterpret_cast<const bo_h8 *>(p + IMGH + 40 * PH);
     };
 #define BO_H_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 
@@ -83,8 +100,9 @@ bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
             const int bb = i >> 11, rem = i & 2047, ic = rem >> 4, q = rem & 15;
             bo_f32x4 t = {0, 0, 0, 0};
             if (ic < CIN0 && b0 + bb < B) t = reinterpret_cast<const bo_f32x4 *>(x + (size_t)(b0 + bb) * CIN0 * 64)[rem];
-            _Float16 *dst = X + (size_t)bb * IMGH + (size_t)(((q >> 1) + 1) * 10 + (q & 1) * 4 + 1) * PH + ic;
-            dst[0] = (_Float16)t[0]; dst[PH] = (_Float16)t[1]; dst[2 * PH] = (_Float16)t[2]; dst[3 * PH] = (_Float16)t[3];
+            const int cell = ((q >> 1) + 1) * 10 + (q & 1) * 4 + 1;
+#pragma unroll
+            for (int e = 0; e < 4; e++) X[bb * IMGH + bo_sw_addr<PH>(cell + e, ic >> 3) + (ic & 7)] = (_Float16)t[e];
         }
         __syncthreads();
         for (int l = 0; l < n_layers; l++) {
@@ -102,17 +120,18 @@ bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
                 for (int t = 0; t < 4; t++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) acc[mt][t][r] = 0.0f;
-            read_b(bq[0], (-11) * PH);  // step 0: tap 0 = (-1, -1), channel group 0
+            int basen = b_base(-11, 0);  // step 0: tap 0 = (-1, -1), channel group 0
+            read_b(bq[0], basen, 0);
             for (int s0 = 0; s0 < L.t4; s0 += 8) {
                 const int tap = s0 / ncg, cg0 = s0 - tap * ncg;
-                const int off0 = ((tap / 3 - 1) * 10 + (tap % 3 - 1)) * PH + 16 * cg0;
-                // offset of the step after this group (first step of the next tap, or a harmless re-read at the layer's end)
+                const int base0 = basen;
+                // the group after this one (the next 8 channel groups or the next tap; a harmless re-read at the layer's end)
                 const int s8 = s0 + 8, tapn = s8 < L.t4 ? s8 / ncg : tap, cgn = s8 < L.t4 ? s8 - tapn * ncg : cg0;
-                const int offn = ((tapn / 3 - 1) * 10 + (tapn % 3 - 1)) * PH + 16 * cgn;
+                basen = b_base((tapn / 3 - 1) * 10 + (tapn % 3 - 1), cgn);
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const bo_h8(&bc)[4] = bq[j & 1];
-                    read_b(bq[(j + 1) & 1], j < 7 ? off0 + 16 * (j + 1) : offn);
+                    read_b(bq[(j + 1) & 1], j < 7 ? base0 : basen, j < 7 ? j + 1 : 0);
 #pragma unroll
                     for (int t = 0; t < 4; t++)
 #pragma unroll
@@ -185,9 +204,9 @@ bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
-                    _Float16 *cellp = X + (size_t)(t >> 1) * IMGH + (size_t)(cell0 + 40 * (t & 1)) * PH + (wave * MT + mt) * 32 + 4 * kg;
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
+                        _Float16 *cellp = X + (t >> 1) * IMGH + 40 * (t & 1) * PH + bo_sw_addr<PH>(cell0, (wave * MT + mt) * 4 + q, sw0) + 4 * kg;
                         bo_h4 o;
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
@@ -198,7 +217,7 @@ bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
                             o[e] = (_Float16)fmaxf(v, 0.0f);
                         }
                         if (L.kind != 1) skip[mt][t][q] = o;
-                        *reinterpret_cast<bo_h4 *>(cellp + 8 * q) = o;
+                        *reinterpret_cast<bo_h4 *>(cellp) = o;
                     }
                 }
             if (LAB != 6) __syncthreads();
@@ -211,11 +230,11 @@ bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
                 bo_f32x16 hacc;
 #pragma unroll
                 for (int r = 0; r < 16; r++) hacc[r] = 0.0f;
-                const _Float16 *xb = xl + (size_t)bb * IMGH + (t & 1) * 40 * PH;
 #pragma unroll 4
                 for (int st = 0; st < C / 16; st++) {
                     const bo_h8 aw = wts[(size_t)head.w_off8 + ((size_t)mt * (C / 16) + st) * 64 + lane];
-                    hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, *reinterpret_cast<const bo_h8 *>(xb + 16 * st), hacc, 0, 0, 0);
+                    const _Float16 *xb = X + bb * IMGH + (t & 1) * 40 * PH + bo_sw_addr<PH>(cell0, 2 * st + kg, sw0);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw, *reinterpret_cast<const bo_h8 *>(xb), hacc, 0, 0, 0);
                 }
                 if (b0 + bb < B) {
                     const int sq = 32 * (t & 1) + n;

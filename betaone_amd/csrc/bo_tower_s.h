@@ -1,0 +1,268 @@
+// betaone_amd/csrc/bo_tower_s.h -- the residual tower in float32 on the fp16 matrix pipe: every float32 operand is carried as a
+// PAIR of fp16 values (hi = RN16(v), lo = RN16(v - hi): 22 significant bits) and every product as three
+// v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi, fp32 accumulation; the dropped lo*lo term is 2^-22 of the product).
+// Same contract as bo_tower.h (one workgroup keeps one board in LDS for the whole tower of
+// /root/reference/network.py:48-118,167-195, BatchNorm folded; float32 planes in, float32 head planes / tower output out).
+//
+// Why: the fp32 matrix pipe is 1/16 of the fp16 one (157 vs ~2500 TFLOP/s dense).  bo_tower_wg.h sits at 0.80 of the fp32
+// peak with Winograd; three fp16 MFMAs per product in the DIRECT form cost 3 x 2.25 / 16 = 0.42 of the Winograd form's
+// matrix time, and the direct form streams 9/16 of the Winograd form's weight bytes (the stream from L2, ~56 B/clk/CU, is
+// what bounds a split-precision Winograd layer).
+//   * activations in LDS channels-last as two fp16 images (hi, lo) of [padded 10x10 cell][C]: the B operand of a lane
+//     (8 consecutive channels of one cell) is one ds_read_b128 per image, conflict-free through the chunk swizzle of
+//     bo_tower_h.h (bo_sw); ONE image pair per board, the layer's output overwrites its input after a barrier; the skip
+//     connection stays in registers as float32;
+//   * weights pre-split on the host, scaled per layer by a power of two so that the largest |w| sits just below 2^15 (a lo
+//     half is then a normal fp16 number for every weight above 2^-18 of the largest); the epilogue multiplies the
+//     accumulator by the inverse (exact) in the fma that adds the bias;
+//   * M = 32*MT output channels per wave (4 waves, one per SIMD), N = 64 positions (two 32-wide tiles), K = 9 taps x C in
+//     steps of 16 channels; A fragments [step][oc/32][hi|lo][lane][8 fp16] = one buffer_load_dwordx4 each, reloaded 8 steps
+//     ahead into the register set its own MFMAs just released.
+// Numerics (tests/test_fused_net_gpu.py): within 1e-5 of the float32 layer-by-layer net; G1 fixtures within 1e-4.
+#pragma once
+#if !defined(BO_WAVE_EMU)
+#include <hip/hip_runtime.h>
+#include "bo_tower.h"
+#include "bo_tower_h.h"
+
+struct bo_tower_head_s {
+    int channels = 0, split = 0, w_off8 = 0, b_off = 0;  // head weights: [mt][step C/16][hi|lo][lane][8 fp16] at bo_h8 offset w_off8 in wts;
+    float *out_a = nullptr, *out_b = nullptr;            // params[b_off + channels] = their inverse scale
+};
+
+// hi / lo halves of 4 float32 values (saturating: |v| beyond the fp16 range would turn into inf - inf)
+__device__ inline void bo_split4(const float (&v)[4], bo_h4 &hi, bo_h4 &lo) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const float c = fminf(fmaxf(v[e], -65504.0f), 65504.0f);
+        hi[e] = (_Float16)c;
+        lo[e] = (_Float16)(c - (float)hi[e]);
+    }
+}
+
+// LAB (scripts/conv_lab.hip only): 0 = the kernel; 1 = no weight loads; 2 = no B operand reads; 4 = no epilogue; 5 = 1 + 2 + 4
+template <int C, int MT, int LAB = 0>
+__global__ void __launch_bounds__(256)
+bo_k_tower_s(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const float *__restrict__ params,
+             const bo_tower_layer *__restrict__ layers, int n_layers, float *__restrict__ y, int B, bo_tower_head_s head) {
+    constexpr int NW = 4, NT = 256, PH = C, CELLS = 100, IMGH = CELLS * PH, CIN0 = 120, HPW = 16 / NW;
+    static_assert(C == 32 * MT * NW, "four waves of MT 32-channel tiles");
+    __shared__ __attribute__((aligned(16))) _Float16 X[2 * IMGH];  // [hi | lo][cell][PH]
+    __shared__ __attribute__((aligned(16))) float pooled[C];
+    __shared__ float hid[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kg = lane >> 5, n = lane & 31;
+    const int cell0 = ((n >> 3) + 1) * 10 + (n & 7) + 1;  // padded cell of position n; position n + 32 is cell0 + 40
+
+    for (int i = tid; i < 2 * IMGH / 8; i += NT) reinterpret_cast<bo_h8 *>(X)[i] = bo_h8{0, 0, 0, 0, 0, 0, 0, 0};
+
+    bo_f32x16 acc[MT][2];      // [tile][position half]: rows = channels 32*(MT*wave + tile) + (r&3) + 8*(r>>2) + 4*kg, col = position n + 32*half
+    bo_h8 a[8][MT][2];         // A fragments (hi, lo) of 8 consecutive K-steps
+    bo_h8 bq[2][2][2];         // B operands of two consecutive K-steps: [set][position half][hi | lo]
+    float skip[MT][2][16];     // block input at this lane's (channels, positions), float32
+    const int sw0 = bo_sw(cell0);  // (position n + 32 sits 4 rows further down: the same swizzle)
+    // B operand address (in halves) of K-step j of a group of 8: tap cell offset `tc`, first channel group cg0 (a multiple of 8)
+    auto b_base = [&](int tc, int cg0) { return (cell0 + tc) * PH + 16 * cg0 + (((kg ^ bo_sw(cell0 + tc)) & 15) << 3); };
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bo_h8 *>(wts), 0, 0x7fffffff, 0x00020000);
+    const int wvoff = ((wave * MT * 2) * 64 + lane) * 16;
+    auto load_a = [&](int j, int w_off8, int step) {
+        if (LAB == 1 || LAB >= 5) return;
+        typedef int bo_i32x4_t __attribute__((ext_vector_type(4)));
+        const int soff = __builtin_amdgcn_readfirstlane((w_off8 + step * (C / 32) * 2 * 64) * 16);
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int hl = 0; hl < 2; hl++) {
+                const bo_i32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff + (mt * 2 + hl) * 64 * 16, soff, 0);
+                a[j][mt][hl] = __builtin_bit_cast(bo_h8, v);
+            }
+    };
+    auto read_b = [&](bo_h8(&b)[2][2], int base, int j) {  // K-step j of the group whose b_base() is `base`
+        if (LAB == 2 || LAB >= 5) return;
+        const _Float16 *p = X + (base ^ (j << 4));
+        b[0][0] = *reinterpret_cast<const bo_h8 *>(p);
+        b[0][1] = *reinterpret_cast<const bo_h8 *>(p + IMGH);
+        b[1][0] = *reinterpret_cast<const bo_h8 *>(p + 40 * PH);
+        b[1][1] = *reinterpret_cast<const bo_h8 *>(p + IMGH + 40 * PH);
+    };
+#define BO_S_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+
+#pragma unroll
+    for (int j = 0; j < 8; j++) load_a(j, layers[0].w_off4, j);
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        // ---- stage the 120 input planes (float32 NCHW) as fp16 pairs, channels-last; channels >= 120 stay zero ----
+        __syncthreads();
+        for (int i = tid; i < 128 * 16; i += NT) {
+            const int ic = i >> 4, q = i & 15;
+            bo_f32x4 t = {0, 0, 0, 0};
+            if (ic < CIN0) t = reinterpret_cast<const bo_f32x4 *>(x + (size_t)b * CIN0 * 64)[i];
+            const float tv[4] = {t[0], t[1], t[2], t[3]};
+            bo_h4 hi, lo;
+            bo_split4(tv, hi, lo);
+            const int cell = ((q >> 1) + 1) * 10 + (q & 1) * 4 + 1;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                _Float16 *dst = X + bo_sw_addr<PH>(cell + e, ic >> 3) + (ic & 7);
+                dst[0] = hi[e]; dst[IMGH] = lo[e];
+            }
+        }
+        __syncthreads();
+        for (int l = 0; l < n_layers; l++) {
+            const bo_tower_layer L = layers[l];
+            const bo_tower_layer Ln = layers[l + 1 < n_layers ? l + 1 : 0];
+            const int ncg = L.t4 / 9;  // channel groups of 16 per tap (L.t4 = K-steps of the layer, a multiple of 8)
+            const float wscale = params[L.bias_off + C];  // 2^-T: the layer's weights were stored multiplied by 2^T
+            float bv[MT][16];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) bv[mt][r] = params[L.bias_off + (wave * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[mt][t][r] = 0.0f;
+            int basen = b_base(-11, 0);  // step 0: tap 0 = (-1, -1), channel group 0
+            read_b(bq[0], basen, 0);
+            for (int s0 = 0; s0 < L.t4; s0 += 8) {
+                const int tap = s0 / ncg, cg0 = s0 - tap * ncg;
+                const int base0 = basen;
+                // the group after this one (the next 8 channel groups or the next tap; a harmless re-read at the layer's end)
+                const int s8 = s0 + 8, tapn = s8 < L.t4 ? s8 / ncg : tap, cgn = s8 < L.t4 ? s8 - tapn * ncg : cg0;
+                basen = b_base((tapn / 3 - 1) * 10 + (tapn % 3 - 1), cgn);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const bo_h8(&bc)[2][2] = bq[j & 1];
+                    read_b(bq[(j + 1) & 1], j < 7 ? base0 : basen, j < 7 ? j + 1 : 0);
+#pragma unroll
+                    for (int t = 0; t < 2; t++)
+#pragma unroll
+                        for (int mt = 0; mt < MT; mt++) {  // the small terms first
+                            acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j][mt][1], bc[t][0], acc[mt][t], 0, 0, 0);
+                            acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j][mt][0], bc[t][1], acc[mt][t], 0, 0, 0);
+                            acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j][mt][0], bc[t][0], acc[mt][t], 0, 0, 0);
+                        }
+                    const int sn = s0 + j + 8;  // this set's next owner: 8 steps ahead, maybe in the next layer
+                    load_a(j, sn < L.t4 ? L.w_off4 : Ln.w_off4, sn < L.t4 ? sn : sn - L.t4);
+                    // every LDS read and weight load in the shadow of a different MFMA
+#pragma unroll
+                    for (int t = 0; t < 4; t++) { BO_S_SGB(0x008, 1); BO_S_SGB(0x100, 1); }
+                    if (MT > 1) BO_S_SGB(0x008, 4 * MT - 4);
+#pragma unroll
+                    for (int i = 0; i < 2 * MT; i++) { BO_S_SGB(0x008, 1); BO_S_SGB(0x020, 1); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();  // every wave has read the layer input: the output may overwrite it
+
+            // ---- epilogue: rows (r&3) + 8*(r>>2) + 4*kg of a tile are 4 consecutive channels per r>>2 ----
+            float gate[MT][16];
+            if (L.kind == 3) {
+                // SE gate (network.py:33-45).  Wave w owns hidden units w, w + 4, ...; lane n owns the gate of channel 32*(MT*wave + tile) + n.
+                // Weights are requested first, reductions run on the VALU (DPP).
+                const float *w1 = params + L.se_w1_off, *w2 = params + L.se_w2_off;
+                const bool have4 = lane < C / 4;  // a W1 row is C/4 float4: one per lane (C = 256) or per lane of the first half (128)
+                float w2r[MT][16];
+                bo_f32x4 w1r[HPW];
+#pragma unroll
+                for (int u = 0; u < HPW; u++)
+                    w1r[u] = (have4 && wave + u * NW < L.hidden) ? reinterpret_cast<const bo_f32x4 *>(w1 + (size_t)(wave + u * NW) * C)[lane] : bo_f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int h = 0; h < 16; h++) w2r[mt][h] = h < L.hidden ? w2[((wave * MT + mt) * 32 + n) * L.hidden + h] : 0.0f;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const float s = bo_half_sum(acc[mt][0][r] + acc[mt][1][r]);
+                        if (n == 16) pooled[(wave * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg] = s * (wscale * (1.0f / 64.0f)) + bv[mt][r];
+                    }
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < HPW; u++) {
+                    const bo_f32x4 m = have4 ? reinterpret_cast<const bo_f32x4 *>(pooled)[lane] : bo_f32x4{0, 0, 0, 0};
+                    float p = (w1r[u][0] * m[0] + w1r[u][1] * m[1]) + (w1r[u][2] * m[2] + w1r[u][3] * m[3]);
+                    p = bo_wave_sum63(p);
+                    if (lane == 63 && wave + u * NW < L.hidden) hid[wave + u * NW] = fmaxf(p, 0.0f);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    float g = 0.0f;
+#pragma unroll
+                    for (int h = 0; h < 16; h++)
+                        if (h < L.hidden) g += w2r[mt][h] * hid[h];
+                    g = 1.0f / (1.0f + expf(-g));
+#pragma unroll
+                    for (int r = 0; r < 16; r++) gate[mt][r] = __shfl(g, (r & 3) + 8 * (r >> 2) + 4 * kg);
+                }
+            }
+            if (LAB >= 4) {
+                if (acc[0][0][0] == 123.456f) X[tid] = (_Float16)(acc[0][1][1] + acc[MT - 1][0][2] + acc[MT - 1][1][3]);
+            } else
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const int ch0 = (wave * MT + mt) * 32 + 4 * kg;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        _Float16 *cellp = X + 40 * t * PH + bo_sw_addr<PH>(cell0, (wave * MT + mt) * 4 + q, sw0) + 4 * kg;
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int r = 4 * q + e;
+                            float v = acc[mt][t][r] * wscale + bv[mt][r];
+                            if (L.kind == 3) v = v * gate[mt][r];
+                            if (L.kind >= 2) v += skip[mt][t][r];
+                            o[e] = fmaxf(v, 0.0f);
+                            if (L.kind != 1) skip[mt][t][r] = o[e];
+                        }
+                        bo_h4 hi, lo;
+                        bo_split4(o, hi, lo);
+                        *reinterpret_cast<bo_h4 *>(cellp) = hi;
+                        *reinterpret_cast<bo_h4 *>(cellp + IMGH) = lo;
+                        if (L.last && y) {
+                            float *g2 = y + ((size_t)b * C + ch0 + 8 * q) * 64 + n + 32 * t;
+#pragma unroll
+                            for (int e = 0; e < 4; e++) g2[e * 64] = o[e];
+                        }
+                    }
+                }
+            __syncthreads();
+        }
+        // ---- the two 1x1 head convolutions + ReLU on the tower output in X: one 32x32 job per (32 head channels, position half) ----
+        if (head.channels > 0) {
+            const int mts = (head.channels + 31) >> 5;
+            const float hscale = params[head.b_off + head.channels];
+            for (int job = wave; job < mts * 2; job += NW) {
+                const int mt = job >> 1, t = job & 1;
+                bo_f32x16 hacc;
+#pragma unroll
+                for (int r = 0; r < 16; r++) hacc[r] = 0.0f;
+#pragma unroll 4
+                for (int st = 0; st < C / 16; st++) {
+                    const bo_h8 *wp = wts + (size_t)head.w_off8 + (((size_t)mt * (C / 16) + st) * 2) * 64 + lane;
+                    const bo_h8 ah = wp[0], al = wp[64];
+                    const _Float16 *xb = X + t * 40 * PH + bo_sw_addr<PH>(cell0, 2 * st + kg, sw0);
+                    const bo_h8 bh = *reinterpret_cast<const bo_h8 *>(xb), bl = *reinterpret_cast<const bo_h8 *>(xb + IMGH);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, hacc, 0, 0, 0);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, hacc, 0, 0, 0);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, hacc, 0, 0, 0);
+                }
+                const int sq = 32 * t + n;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int oc = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    if (oc < head.channels) {
+                        const float v = fmaxf(hacc[r] * hscale + params[head.b_off + oc], 0.0f);
+                        if (oc < head.split) head.out_a[((size_t)b * head.split + oc) * 64 + sq] = v;
+                        else head.out_b[((size_t)b * (head.channels - head.split) + (oc - head.split)) * 64 + sq] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+#endif

@@ -15,6 +15,8 @@ elementwise launches PyTorch issues (bias, ReLU, residual add, SE pooling / FCs 
   conv="tower":  input conv + all residual blocks are ONE persistent kernel that keeps each board's activations in
                  LDS (csrc/bo_tower.h); 64 or 128 filters.
   conv="tower_wg": the same with Winograd F(2x2,3x3) convolutions (csrc/bo_tower_wg.h), 2.25x fewer MFMA cycles.
+  conv="tower_split": float32 in and out on the fp16 matrix pipe (csrc/bo_tower_s.h): weights and activations as (hi, lo)
+                 fp16 pairs, three MFMAs per product, float32 accumulation; 128 or 256 filters, one board per workgroup.
   conv="tower_f16": fp16 weights/activations, fp32 accumulation (csrc/bo_tower_h.h), 128 or 256 filters, two boards
                  per workgroup; the evaluate stage of BASELINE.json configs[4].  Takes the engine's float32 planes.
 
@@ -74,6 +76,31 @@ def pack_conv_weight_f16(w: torch.Tensor) -> torch.Tensor:
     return u.permute(5, 2, 0, 3, 1, 4).contiguous().half()  # [tap][cg][mt][kg][o][i]
 
 
+def split_scale(w: torch.Tensor) -> float:
+    """The power of two s that puts the largest |s*w| in [2^14, 2^15) (BO_TOWER_SPLIT_F16: fp16 pairs of s*w)."""
+    m = float(w.abs().max())
+    if m == 0.0 or not np.isfinite(m):
+        return 1.0
+    return float(2.0 ** (14 - int(np.floor(np.log2(m)))))
+
+
+def split_f16(w: torch.Tensor):
+    """(hi, lo) fp16 with hi = RN16(w), lo = RN16(w - hi), computed in float64."""
+    w = w.double()
+    hi = w.half()
+    lo = (w - hi.double()).half()
+    return hi, lo
+
+
+def pack_conv_weight_split(w: torch.Tensor, scale: float) -> torch.Tensor:
+    """[c_out, c_in, 3, 3] float32 -> fp16 [9*c_in/16][c_out/32][2 = hi, lo][64][8] of scale*w (include/betaone_engine.h,
+    BO_TOWER_SPLIT_F16; the element order of pack_conv_weight_f16 with every fragment doubled)."""
+    co, ci = w.shape[0], w.shape[1]
+    hi, lo = split_f16(w.double() * scale)
+    u = torch.stack([hi, lo], 0).reshape(2, co // 32, 32, ci // 16, 2, 8, 9)  # [hl][mt][o][cg][kg][i][tap]
+    return u.permute(6, 3, 1, 0, 4, 2, 5).contiguous()  # [tap][cg][mt][hl][kg][o][i]
+
+
 def pack_conv_weight_small(w: torch.Tensor) -> torch.Tensor:
     """[c_out, c_in, 3, 3] -> [c_out/16][tap 9][c_in/16][64][4] (bo_nn_conv3x3_small): element (ot, tap, g, lane, e) =
     W[16*ot + (lane & 15)][16*g + 4*e + (lane >> 4)][tap]."""
@@ -115,7 +142,7 @@ class FusedPolicyValueNet(nn.Module):
         self.conv = conv
         # policy FC + softmax + value head as one kernel behind the Winograd tower (needs contiguous float32 Linear weights of the
         # reference's head shapes: 2 policy planes, 32 value planes, 256 hidden units)
-        self.fused_heads = conv in ("tower_wg", "tower", "mfma", "mfma_small", "tower_f16")
+        self.fused_heads = conv in ("tower_wg", "tower", "mfma", "mfma_small", "tower_f16", "tower_split")
         f = net.for_inference(dtype=torch.float32, channels_last=False)
         dev = next(f.parameters()).device
         if dev.type != "cuda":
@@ -184,8 +211,77 @@ class FusedPolicyValueNet(nn.Module):
         elif conv == "tower_f16":
             self._build_tower_f16(dev)
             self.layout = "nchw+tower_f16"
+        elif conv == "tower_split":
+            self._build_tower_split(dev)
+            self.layout = "nchw+tower_split"
         elif conv != "miopen":
-            raise ValueError("conv must be 'miopen', 'mfma', 'mfma_small', 'tower', 'tower_wg' or 'tower_f16'")
+            raise ValueError("conv must be 'miopen', 'mfma', 'mfma_small', 'tower', 'tower_wg', 'tower_split' or 'tower_f16'")
+
+    def _build_tower_split(self, dev):
+        """float32 tower on the fp16 matrix pipe (bo_nn_tower_create, BO_TOWER_SPLIT_F16): (hi, lo) fp16 pairs of the scaled weights,
+        the inverse scale behind every bias."""
+        c = self.w_in.shape[0]
+        if c not in (128, 256) or self.w_in.shape[1] != 120:
+            raise E.EngineError("conv='tower_split' supports 120 input planes and 128 or 256 filters")
+        wts, params, layers = [], [], []
+        n_h = n_p = 0  # halves in wts, floats in params
+
+        def add_w(t16):
+            nonlocal n_h
+            off = n_h // 8
+            flat = t16.reshape(-1).numpy()
+            wts.append(flat)
+            n_h += flat.size
+            return off
+
+        def add_p(t):
+            nonlocal n_p
+            off = n_p
+            flat = t.detach().float().cpu().contiguous().reshape(-1).numpy()
+            params.append(flat)
+            n_p += flat.size
+            return off
+
+        def add_conv(w, bias):  # -> (weights offset, bias offset); params: bias [c], 1 / scale
+            w = w.detach().float().cpu()
+            s = split_scale(w)
+            return add_w(pack_conv_weight_split(w, s)), add_p(torch.cat([bias.detach().float().cpu().reshape(-1), torch.tensor([1.0 / s])]))
+
+        w0 = torch.zeros((c, 128, 3, 3))
+        w0[:, :120] = self.w_in.detach().float().cpu()
+        wo, bo = add_conv(w0, self.b_in)
+        layers.append([wo, 9 * 128 // 16, bo, 0, 0, 0, 0, 0])
+        for w1, b1, w2, b2, se in self.blocks:
+            wo, bo = add_conv(w1, b1)
+            layers.append([wo, 9 * c // 16, bo, 1, 0, 0, 0, 0])
+            wo, bo = add_conv(w2, b2)
+            if se is not None:
+                if se[0].shape[0] > 16 or se[0].shape[0] > c // 16:
+                    raise E.EngineError("conv='tower_split' supports SE hidden widths up to min(16, filters/16)")
+                layers.append([wo, 9 * c // 16, bo, 3, add_p(se[0]), add_p(se[1]), se[0].shape[0], 0])
+            else:
+                layers.append([wo, 9 * c // 16, bo, 2, 0, 0, 0, 0])
+        layers[-1][7] = 1
+        self._head_ch, self._head_split = self.w_head.shape[0], self.n_policy_ch
+        mt = (self._head_ch + 31) // 32
+        wh = torch.zeros((mt * 32, c))
+        wh[:self._head_ch] = self.w_head.detach().float().cpu().reshape(self._head_ch, c)
+        hs = split_scale(wh)
+        hi, lo = split_f16(wh.double() * hs)
+        whp = torch.stack([hi, lo], 0).reshape(2, mt, 32, c // 16, 2, 8).permute(1, 3, 0, 4, 2, 5).contiguous()  # [mt][st][hl][kg][o][i]
+        head = np.array([self._head_ch, self._head_split, add_w(whp),
+                         add_p(torch.cat([self.b_head.detach().float().cpu().reshape(-1), torch.tensor([1.0 / hs])]))], dtype=np.int32)
+        wts = np.ascontiguousarray(np.concatenate(wts), dtype=np.float16)
+        if wts.size % 8:
+            wts = np.concatenate([wts, np.zeros(8 - wts.size % 8, np.float16)])
+        params = np.ascontiguousarray(np.concatenate(params), dtype=np.float32)
+        table = np.ascontiguousarray(np.array(layers, dtype=np.int32))
+        handle = C.c_void_p()
+        rc = self.lib.bo_nn_tower_create(table.ctypes.data, len(layers), wts.ctypes.data, wts.size // 2, params.ctypes.data, params.size, c,
+                                         3, head.ctypes.data, dev.index if dev.index is not None else torch.cuda.current_device(), C.byref(handle))
+        if rc:
+            raise E.EngineError(self.lib.bo_last_error().decode())
+        self.c, self._tower, self._tower_dev = c, handle, dev
 
     def _build_tower_f16(self, dev):
         """fp16 tower (bo_nn_tower_create, BO_TOWER_DIRECT_F16) + half copies of the three head Linear layers."""
@@ -349,7 +445,7 @@ class FusedPolicyValueNet(nn.Module):
             out = (pa, pb)
         else:
             y = torch.empty((B, self.c, 8, 8), dtype=torch.float32, device=x.device)
-            wg = self.conv == "tower_wg"
+            wg = self.conv in ("tower_wg", "tower_split")
             dummy = torch.empty((2, B, self._head_ch * 64), dtype=torch.float32, device=x.device) if wg else None
             rc = self.lib.bo_nn_tower_forward(self._tower, x.data_ptr(), y.data_ptr(), dummy[0].data_ptr() if wg else None,
                                               dummy[1].data_ptr() if wg else None, B, stream)
@@ -445,7 +541,7 @@ class FusedPolicyValueNet(nn.Module):
                 return self._heads(p, v, probs)
             logits = self.policy_fc_h(p)
             return (torch.softmax(logits.float(), dim=1) if probs else logits), torch.tanh(self.value_fc2_h(F.relu(self.value_fc1_h(v))))
-        if self.conv == "tower_wg":  # tower + head convolutions in one kernel, then the heads
+        if self.conv in ("tower_wg", "tower_split"):  # tower + head convolutions in one kernel, then the heads
             p, v = self._tower_forward(x, heads=True)
             if self.fused_heads and p.shape[1] == 128 and v.shape[1] == 2048:
                 return self._heads(p, v, probs)  # policy FC + softmax + value head: one launch (csrc/bo_heads.h)

@@ -322,6 +322,13 @@ int bo_nn_conv3x3_small(const float *x_dev, const float *wpacked_dev, const floa
  *   [16*(step % (c_in/16)) + 8*(lane >> 5) + i][tap = step / (c_in/16)] at 16-byte offset w_off4.  Needs `head`: its
  *   weights [ceil(channels/32)][C/16][64][8] fp16 with element (mt, st, lane, i) = Wh[32*mt + (lane & 31)][16*st +
  *   8*(lane >> 5) + i] at 16-byte offset w_off in `weights`; head outputs are fp16; y_dev is unused.
+ * algo BO_TOWER_SPLIT_F16 (csrc/bo_tower_s.h): float32 in and out, computed on the fp16 matrix pipe -- every float32 weight
+ *   and activation is a (hi, lo) pair of fp16 values (hi = RN16(v), lo = RN16(v - hi)), every product three fp16 MFMAs with
+ *   float32 accumulation (relative product error 2^-22); one board per workgroup; channels in {128, 256}; layout as
+ *   BO_TOWER_DIRECT_F16 with every fragment doubled: per layer [t4][C/32][2 = hi, lo][64][8] fp16 of s*W, s a power of two
+ *   chosen by the caller (largest |s*W| below 2^15), and 1/s as ONE MORE float behind the layer's bias (params[bias_off + C]).
+ *   `head` is optional: weights [ceil(channels/32)][C/16][2][64][8] at 16-byte offset w_off in `weights`, bias [channels]
+ *   followed by the inverse scale in params; head outputs are float32.  y_dev (optional) receives the tower output.
  * weights: float32 at float4 offset w_off4; params: float32 biases and SE matrices at float offsets.
  * head (optional, BO_TOWER_WINOGRAD only): the policy and value 1x1 convolutions + ReLU (network.py:101-113,191-195)
  *   fused behind the tower: bias [channels] and weights in params, the weights packed [ceil(channels/16)][C/16][64][4]
@@ -331,7 +338,7 @@ int bo_nn_conv3x3_small(const float *x_dev, const float *wpacked_dev, const floa
  * bo_nn_tower_create validates every offset and copies the three HOST arrays to `device`;
  * bo_nn_tower_forward(x_dev [batch,120,8,8] -> y_dev [batch,C,8,8], NCHW float32) is asynchronous on `stream`.
  * bo_nn_value_tail: out[b] = tanh(w . h[b] + bias[0]) (value_fc2 + tanh, network.py:116-118,197). */
-enum { BO_TOWER_DIRECT = 0, BO_TOWER_WINOGRAD = 1, BO_TOWER_DIRECT_F16 = 2 };
+enum { BO_TOWER_DIRECT = 0, BO_TOWER_WINOGRAD = 1, BO_TOWER_DIRECT_F16 = 2, BO_TOWER_SPLIT_F16 = 3 };
 typedef struct bo_tower_layer_desc {
     int32_t w_off4, t4, bias_off, kind, se_w1_off, se_w2_off, hidden, last;
 } bo_tower_layer_desc;

@@ -89,3 +89,30 @@ def test_evaluate_stage_route_is_a_shape_rule():
     assert R(256, 17, torch.float32) == "mfma"
     assert R(128, 4096, torch.float16) == R(256, 512, torch.float16) == R(256, 1, torch.float16) == "tower_f16"
     assert R(64, 4096, torch.float16) is None and R(96, 32, torch.float32) is None and R(128, 256, torch.bfloat16) is None
+
+
+def test_lds_chunk_swizzle_of_the_fp16_pipe_towers_is_conflict_free():
+    """csrc/bo_tower_h.h bo_sw (restated here): chunk j of a cell of the channels-last LDS image is stored at position
+    j ^ ((cell % 10 + 8 * (cell // 10)) & 15).  A ds_read_b128 is served per group of 16 lanes
+    ({0-3,12-15,20-27}, {4-11,16-19,28-31} of each wave half); for every tap, both position halves, both channel counts and
+    every chunk the 16 cells of a group must fall on 16 different bank quads -- and the linear pitch of C + 8 halves the
+    kernels used before put three cells of a group on one quad."""
+    import re
+    src = open(os.path.join(ROOT, "betaone_amd", "csrc", "bo_tower_h.h")).read()
+    assert re.search(r"bo_sw\(int cell\) \{ return \(\(cell % 10\) \+ 8 \* \(cell / 10\)\) & 15; \}", src), "restatement out of date"
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15] + list(range(20, 28)), list(range(4, 12)) + [16, 17, 18, 19, 28, 29, 30, 31]]
+    sw = lambda cell: ((cell % 10) + 8 * (cell // 10)) & 15
+    cell0 = lambda n: ((n >> 3) + 1) * 10 + (n & 7) + 1
+    for C in (128, 256):
+        for t in (0, 1):
+            for tap in range(9):
+                off = (tap // 3 - 1) * 10 + (tap % 3 - 1)
+                for g in groups:
+                    for j in range(C // 8):
+                        quads = set()
+                        for n in g:
+                            cell = cell0(n) + 40 * t + off
+                            quads.add((cell * (C // 8) + ((j & ~15) | ((j ^ sw(cell)) & 15))) % 16)
+                        assert len(quads) == 16, (C, t, tap, j)
+        old = [(cell0(n) * ((C + 8) // 8)) % 16 for n in groups[0]]
+        assert max(old.count(q) for q in old) == 3

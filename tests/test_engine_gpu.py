@@ -191,14 +191,16 @@ def test_mfma_conv3x3_matches_float64_convolution(backend, shape):
         conv3x3_mfma(lib, torch.zeros((1, 24, 8, 8)).cuda(), wp, bias, co)
 
 
-@pytest.mark.parametrize("conv", ["miopen", "mfma", "mfma_small", "tower", "tower_wg"])
+@pytest.mark.parametrize("conv", ["miopen", "mfma", "mfma_small", "tower", "tower_wg", "tower_split"])
 @pytest.mark.parametrize("size", [(3, 1, 64), (8, 2, 128), (2, 2, 256), (0, 3, 128), (4, 0, 64)])
 def test_fused_epilogue_net_matches_plain_net(backend, size, conv):
-    """csrc/bo_nn_fused.h, csrc/bo_conv.h, csrc/bo_tower.h: conv (MIOpen, the fp32-MFMA direct kernel, or the whole
-    tower as one persistent kernel) with fused epilogues == PolicyValueNet.forward, within 1e-5.  33 and 300 boards:
-    fewer and more boards than CUs (the tower kernel loops)."""
-    if conv.startswith("tower") and size[2] == 256:
+    """csrc/bo_nn_fused.h, csrc/bo_conv.h, csrc/bo_tower.h, csrc/bo_tower_s.h: conv (MIOpen, the fp32-MFMA direct kernel, the
+    whole tower as one persistent kernel on the fp32 matrix pipe, or on the fp16 pipe with (hi, lo) operand pairs) with fused
+    epilogues == PolicyValueNet.forward, within 1e-5.  33 and 300 boards: fewer and more boards than CUs (the tower kernel loops)."""
+    if conv in ("tower", "tower_wg") and size[2] == 256:
         pytest.skip("two padded 256-channel boards do not fit in LDS; the tower kernel is for 64/128 filters")
+    if conv == "tower_split" and size[2] == 64:
+        pytest.skip("the split-precision tower is built for 128 and 256 filters")
     import torch
     from betaone_amd import dropin
     dropin.install()
