@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=96)
     ap.add_argument("--net", default=None, choices=list(NETS), help="default 10x128")
     ap.add_argument("--net-dtype", default=None, choices=["fp32", "fp16", "bf16"], help="default fp32; --fast: fp16")
+    ap.add_argument("--f32-tower", default=None, choices=["split", "fp32"],
+                    help="float32 nets: 'split' (default, or BETAONE_F32_TOWER) = the tower on the fp16 matrix pipe with (hi, lo) operand pairs "
+                         "(csrc/bo_tower_s.h); 'fp32' = the fp32-MFMA Winograd tower of rounds 1-2 (csrc/bo_tower_wg.h)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -96,7 +99,7 @@ def parse():
     return args
 
 
-def make_net(name, device, dtype, batch=256):
+def make_net(name, device, dtype, batch=256, f32_pipe=None):
     from betaone_amd import dropin
 
     dropin.install()
@@ -111,7 +114,7 @@ def make_net(name, device, dtype, batch=256):
         return net, net.for_inference(dtype=td, channels_last=False)
     from betaone_amd.nn_tune import best_inference_copy
 
-    return net, best_inference_copy(net, batch, device, td)
+    return net, best_inference_copy(net, batch, device, td, f32_pipe=f32_pipe)
 
 
 class CastIn(torch.nn.Module):
@@ -202,8 +205,9 @@ def nn_roofline(net, batch, device, ro=None, drv=None, plies=3):
     (profiles/r02_bench_kernel_stats.md).  `back_to_back_us` is the same kernel replayed as 20 consecutive graph nodes:
     nothing but fp32 MFMA work for 30 ms, ~4 % slower per launch."""
     conv = getattr(net, "conv", None)
-    if conv not in ("tower", "tower_wg"):
+    if conv not in ("tower", "tower_wg", "tower_split"):
         return None
+    heads = conv in ("tower_wg", "tower_split")
     C, n_conv = net.c, 1 + 2 * len(net.blocks)
     x = torch.rand((batch, 120, 8, 8), device=device)
     with torch.no_grad():
@@ -211,13 +215,13 @@ def nn_roofline(net, batch, device, ro=None, drv=None, plies=3):
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
             for _ in range(3):
-                net._tower_forward(x, heads=conv == "tower_wg")
+                net._tower_forward(x, heads=heads)
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         per_graph, replays = 20, 4
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            keep = [net._tower_forward(x, heads=conv == "tower_wg") for _ in range(per_graph)]
+            keep = [net._tower_forward(x, heads=heads) for _ in range(per_graph)]
         g.replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -228,7 +232,7 @@ def nn_roofline(net, batch, device, ro=None, drv=None, plies=3):
         del keep
     b2b = e0.elapsed_time(e1) * 1e3 / (per_graph * replays)
     us, n_timed, how = b2b, per_graph * replays, "20 consecutive graph nodes x 4 replays"
-    if ro is not None and drv is not None and conv == "tower_wg":
+    if ro is not None and drv is not None and heads:
         graph = ro.use_graph
         ro.use_graph = False
         net.tower_events = []
@@ -240,9 +244,21 @@ def nn_roofline(net, batch, device, ro=None, drv=None, plies=3):
         if ev:
             us = sum(a.elapsed_time(b) for a, b in ev) * 1e3 / len(ev)
             n_timed, how = len(ev), f"event pair around every launch of {plies} more plies of this workload (eager launches)"
-    per_mac = 16 * 16 if conv == "tower_wg" else 9 * 64       # multiplies per (c_in, c_out) pair and board
+    per_mac = 16 * 16 if conv == "tower_wg" else 3 * 9 * 64 if conv == "tower_split" else 9 * 64  # multiplies per (c_in, c_out) pair and board
     executed = 2.0 * per_mac * C * (128 + (n_conv - 1) * C) * batch
     algorithmic = 2.0 * 9 * 64 * C * (120 + (n_conv - 1) * C) * batch
+    if conv == "tower_split":
+        # the pipe actually used: fp16 MFMA, ~2.5 PFLOP/s dense (MI355X_MICROARCH.md); three fp16 MFMAs per float32 product are all counted
+        # as executed flops.  (A bare chain of this instruction on all 1024 SIMDs sustains 1.74 PFLOP/s on this part: the matrix pipe
+        # under load clocks below the 2.4 GHz the peak is quoted at -- scripts/split_lab.hip, profiles/r03_split_tower.md.)
+        return {"bound": "mfma", "kernel": "bo_k_tower_s", "achieved": round(executed / us / 1e6, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                "frac": round(executed / us / 1e6 / 2500.0, 4), "traffic": None, "avg_launch_us": round(us, 1), "launches_timed": n_timed, "timing": how,
+                "back_to_back_us": round(b2b, 1), "boards_per_launch": batch, "conv_layers": n_conv,
+                "algorithmic_direct_conv_tflops": round(algorithmic / us / 1e6, 1),
+                "float32_equivalent_tflops": round(executed / 3.0 / us / 1e6, 1),
+                "note": "float32 planes in and out; every float32 operand a (hi, lo) fp16 pair, every product three v_mfma_f32_32x32x16_f16 with "
+                        "float32 accumulation (direct 3x3 form); one workgroup per board, activations LDS-resident for the whole tower; "
+                        "the fp32-pipe Winograd tower of rounds 1-2 (BETAONE_F32_TOWER=fp32 / --f32-tower fp32) ran 0.80 of the 157 TFLOP/s fp32 peak"}
     peak = 157.3  # TFLOP/s dense fp32 MFMA: 256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz (MI355X_MICROARCH.md)
     return {"bound": "mfma", "kernel": "bo_k_tower_wg" if conv == "tower_wg" else "bo_k_tower", "achieved": round(executed / us / 1e6, 1), "peak": peak,
             "unit": "TFLOP/s", "frac": round(executed / us / 1e6 / peak, 4), "traffic": TOWER_WG_PMC_BYTES if conv == "tower_wg" and batch == 256 and C == 128 else None,
@@ -495,7 +511,8 @@ def main():
     from betaone_amd.rollout import Rollout
 
     E.load_hip_library()
-    _, net = make_net(args.net, device, args.net_dtype, args.games * (args.leaves if args.fast else 1))
+    _, net = make_net(args.net, device, args.net_dtype, args.games * (args.leaves if args.fast else 1),
+                      f32_pipe=None if args.f32_tower is None else args.f32_tower == "fp32")
     net_layout = getattr(net, "layout", "nchw")
     if args.net_dtype != "fp32":
         net = CastIn(net, {"fp16": torch.float16, "bf16": torch.bfloat16}[args.net_dtype])
@@ -601,7 +618,7 @@ def main():
         out = {
             "metric": "mcts_nodes_per_sec", "value": round(sims / dt, 1), "unit": "nodes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "fp16": "f16", "bf16": "bf16"}[args.net_dtype], "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("f32 (3 x f16 split, f32 accumulate)" if getattr(getattr(net, "net", net), "conv", None) == "tower_split" else {"fp32": "f32", "fp16": "f16", "bf16": "bf16"}[args.net_dtype]), "data": "synthetic",
             "config": {"workload": f"{G} concurrent self-play games per GPU x {args.sims} sims/move, MCTS_BATCH_SIZE {args.batch}, "
                                    f"net {args.net} ({'+'.join(map(str, NETS[args.net][:2]))} blocks x {NETS[args.net][2]} filters, "
                                    f"random init, {args.net_dtype}, BN folded), games from the start position, per-game seeds = game id, "

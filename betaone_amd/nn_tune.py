@@ -43,24 +43,42 @@ def _time_forward(net, x, reps: int = 8) -> float:
     return best
 
 
-def kernel_route(filters: int, batch: int, dtype: torch.dtype):
+def f32_pipe_default() -> bool:
+    """BETAONE_F32_TOWER=fp32 keeps float32 nets on the fp32 matrix pipe (csrc/bo_tower_wg.h / bo_conv.h); the default 'split' runs
+    them on the fp16 pipe with (hi, lo) operand pairs (csrc/bo_tower_s.h: same 1e-5 agreement with the float32 net, 16x the rate)."""
+    import os
+    v = os.environ.get("BETAONE_F32_TOWER", "split").lower()
+    if v not in ("split", "fp32"):
+        raise ValueError("BETAONE_F32_TOWER must be 'split' or 'fp32'")
+    return v == "fp32"
+
+
+def kernel_route(filters: int, batch: int, dtype: torch.dtype, f32_pipe: bool = None):
     """Which hand-written evaluate stage (betaone_amd/fused_net.py `conv=`) a net of this shape runs on -- decided by shape, not by a
     timing race -- or None where none exists (the net then stays under PyTorch-ROCm's library kernels, and says so):
-      float32, 64 / 128 filters: batch <= 16 -> 'mfma_small' (a board's layer cut into c_out/16 x 4 workgroups), else 'tower_wg'
-                                 (the LDS-resident Winograd tower, one board per workgroup);
-      float32, 256 filters:      batch <= 16 -> 'mfma_small', else 'mfma' (per-layer implicit GEMM, csrc/bo_conv.h);
+      float32, 128 / 256 filters: batch <= 16 -> 'mfma_small' (a board's layer cut into c_out/16 x 4 workgroups), else 'tower_split'
+                                 (the LDS-resident tower on the fp16 matrix pipe, float32 operands as (hi, lo) fp16 pairs);
+                                 with f32_pipe (or BETAONE_F32_TOWER=fp32): 'tower_wg' (fp32-MFMA Winograd tower, 128 filters) /
+                                 'mfma' (per-layer implicit GEMM on the fp32 pipe, 256 filters);
+      float32, 64 filters:       batch <= 16 -> 'mfma_small', else 'tower_wg';
       float16, 128 / 256 filters: 'tower_f16' (csrc/bo_tower_h.h, two boards per workgroup)."""
+    if f32_pipe is None:
+        f32_pipe = f32_pipe_default()
     if dtype == torch.float32:
+        if filters in (64, 128, 256) and batch <= 16:
+            return "mfma_small"
+        if filters in (128, 256) and not f32_pipe:
+            return "tower_split"
         if filters in (64, 128):
-            return "mfma_small" if batch <= 16 else "tower_wg"
+            return "tower_wg"
         if filters == 256:
-            return "mfma_small" if batch <= 16 else "mfma"
+            return "mfma"
     if dtype == torch.float16 and filters in (128, 256):
         return "tower_f16"
     return None
 
 
-def best_inference_copy(model, batch: int, device, dtype: torch.dtype = torch.float32, verbose: bool = False, tune=None):
+def best_inference_copy(model, batch: int, device, dtype: torch.dtype = torch.float32, verbose: bool = False, tune=None, f32_pipe=None):
     """BN-folded inference copy of a PolicyValueNet for `batch` rows: the hand-written kernels chosen by kernel_route(); where
     there are none (other filter counts, bfloat16) the PyTorch-ROCm copy in NCHW up to 512 rows and channels-last beyond, with
     a warning naming the library path.  tune=True (or BETAONE_NN_TUNE=1) runs the start-up timing race of rounds 1-2 instead
@@ -81,7 +99,7 @@ def best_inference_copy(model, batch: int, device, dtype: torch.dtype = torch.fl
     from .fused_net import FusedPolicyValueNet
 
     filters = model.conv_input.out_channels
-    route = kernel_route(filters, batch, dtype)
+    route = kernel_route(filters, batch, dtype, f32_pipe)
     if route is not None:
         try:
             net = FusedPolicyValueNet(model.to(device), conv=route).to(device)

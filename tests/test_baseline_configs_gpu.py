@@ -163,7 +163,7 @@ def test_bench_steady_state_path_with_refills_and_late_game_positions_matches_or
     config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 8, 2, 128
     G, SIMS, LIMIT, PREROLL, STEPS, WATCH = 256, 800, 28, 40, 36, (0, 5, 13, 101, 255)
     torch.manual_seed(0)
-    net = FusedPolicyValueNet(network.PolicyValueNet().to("cuda:0").eval(), conv="tower_wg").to("cuda:0")
+    net = FusedPolicyValueNet(network.PolicyValueNet().to("cuda:0").eval(), conv="tower_split").to("cuda:0")  # (the route of nn_tune.kernel_route for this shape)
     prod, fens_p, _, slot_p, n_graphs = _bench_like_run(net, G, SIMS, LIMIT, PREROLL, STEPS, WATCH, record=False)
     assert n_graphs > 0  # the product run did replay n-iteration graphs
     recd, fens_r, rec, slot_r, _ = _bench_like_run(net, G, SIMS, LIMIT, PREROLL, STEPS, WATCH, record=True)
@@ -244,7 +244,7 @@ def test_config2_shard_256_games_800_sims_10x128_graph_and_winograd_tower(env):
     config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 8, 2, 128
     G, SIMS, PLIES, WATCH = 256, 800, 4, (0, 101, 255)
     torch.manual_seed(0)
-    net = FusedPolicyValueNet(network.PolicyValueNet().to("cuda:0").eval(), conv="tower_wg").to("cuda:0")
+    net = FusedPolicyValueNet(network.PolicyValueNet().to("cuda:0").eval(), conv="tower_split").to("cuda:0")  # (the route of nn_tune.kernel_route for this shape)
     ro = Rollout(net, G, num_simulations=SIMS, mcts_batch_size=96, device="cuda:0", use_graph=True, rng_mode="native",
                  policy_kind="probs")
     rec = SeamRecorder(ro, WATCH)

@@ -460,10 +460,11 @@ def test_evaluate_stage_is_routed_by_shape_to_the_hand_written_kernels(backend):
             config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 8, 2, 128
             torch.manual_seed(0)
             net = network.PolicyValueNet().to("cuda:0").eval()
-            assert best_inference_copy(net, 256, "cuda:0").layout == "nchw+tower_wg"
+            assert best_inference_copy(net, 256, "cuda:0").layout == "nchw+tower_split"
+            assert best_inference_copy(net, 256, "cuda:0", f32_pipe=True).layout == "nchw+tower_wg"  # (the fp32 matrix pipe stays selectable)
             for batch in (24, 100, 1000):  # not a BASELINE shape
                 routed = best_inference_copy(net, batch, "cuda:0")
-                assert routed.layout == "nchw+tower_wg", batch
+                assert routed.layout == "nchw+tower_split", batch
                 x = torch.rand((batch, 120, 8, 8), device="cuda:0")
                 with torch.no_grad():
                     (l0, v0), (l1, v1) = net(x), routed(x)
@@ -473,7 +474,8 @@ def test_evaluate_stage_is_routed_by_shape_to_the_hand_written_kernels(backend):
             config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 3, 1, 256
             big = network.PolicyValueNet().to("cuda:0").eval()
             assert best_inference_copy(big, 1, "cuda:0").layout == "nchw+mfma_small"
-            assert best_inference_copy(big, 64, "cuda:0").layout == "nchw+mfma"
+            assert best_inference_copy(big, 64, "cuda:0").layout == "nchw+tower_split"
+            assert best_inference_copy(big, 64, "cuda:0", f32_pipe=True).layout == "nchw+mfma"
             assert best_inference_copy(big, 512, "cuda:0", torch.float16).layout == "nchw+tower_f16"
         config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 2, 1, 96  # no hand-written kernels for 96 filters
         odd = network.PolicyValueNet().to("cuda:0").eval()
