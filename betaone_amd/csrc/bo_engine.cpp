@@ -1242,7 +1242,7 @@ extern "C" int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layer
         if (L.t4 != want_t4) return fail(BO_E_ARG, "layer " + std::to_string(l) + ": t4 must be " + std::to_string(want_t4));
         if (L.w_off4 < 0 || ((int64_t)L.w_off4 + w4) * 4 > n_weights) return fail(BO_E_ARG, "weights offset out of range");
         if (L.bias_off < 0 || (int64_t)L.bias_off + C + (split - 1) > n_params) return fail(BO_E_ARG, "bias offset out of range");
-        if (algo == BO_TOWER_WINOGRAD && (L.bias_off & 3)) return fail(BO_E_ARG, "BO_TOWER_WINOGRAD: bias_off must be a multiple of 4 floats");
+        if ((algo == BO_TOWER_WINOGRAD || algo == BO_TOWER_SPLIT_F16) && (L.bias_off & 3)) return fail(BO_E_ARG, "BO_TOWER_WINOGRAD / BO_TOWER_SPLIT_F16: bias_off must be a multiple of 4 floats");
         if (L.kind == 3) {
             if (L.hidden < 1 || L.hidden > 16) return fail(BO_E_CONFIG, "SE hidden width must be 1..16");
             if (half_w && L.hidden > C / 16) return fail(BO_E_CONFIG, "fp16-pipe towers: SE hidden width must be <= channels/16");

@@ -242,10 +242,10 @@ class FusedPolicyValueNet(nn.Module):
             n_p += flat.size
             return off
 
-        def add_conv(w, bias):  # -> (weights offset, bias offset); params: bias [c], 1 / scale
+        def add_conv(w, bias):  # -> (weights offset, bias offset); params: bias [c], 1 / scale, padding to a multiple of 4 floats
             w = w.detach().float().cpu()
             s = split_scale(w)
-            return add_w(pack_conv_weight_split(w, s)), add_p(torch.cat([bias.detach().float().cpu().reshape(-1), torch.tensor([1.0 / s])]))
+            return add_w(pack_conv_weight_split(w, s)), add_p(torch.cat([bias.detach().float().cpu().reshape(-1), torch.tensor([1.0 / s, 0.0, 0.0, 0.0])]))
 
         w0 = torch.zeros((c, 128, 3, 3))
         w0[:, :120] = self.w_in.detach().float().cpu()
@@ -259,6 +259,8 @@ class FusedPolicyValueNet(nn.Module):
                 if se[0].shape[0] > 16 or se[0].shape[0] > c // 16:
                     raise E.EngineError("conv='tower_split' supports SE hidden widths up to min(16, filters/16)")
                 layers.append([wo, 9 * c // 16, bo, 3, add_p(se[0]), add_p(se[1]), se[0].shape[0], 0])
+                if n_p % 4:
+                    add_p(torch.zeros(4 - n_p % 4))
             else:
                 layers.append([wo, 9 * c // 16, bo, 2, 0, 0, 0, 0])
         layers[-1][7] = 1

@@ -326,7 +326,8 @@ int bo_nn_conv3x3_small(const float *x_dev, const float *wpacked_dev, const floa
  *   and activation is a (hi, lo) pair of fp16 values (hi = RN16(v), lo = RN16(v - hi)), every product three fp16 MFMAs with
  *   float32 accumulation (relative product error 2^-22); one board per workgroup; channels in {128, 256}; layout as
  *   BO_TOWER_DIRECT_F16 with every fragment doubled: per layer [t4][C/32][2 = hi, lo][64][8] fp16 of s*W, s a power of two
- *   chosen by the caller (largest |s*W| below 2^15), and 1/s as ONE MORE float behind the layer's bias (params[bias_off + C]).
+ *   chosen by the caller (largest |s*W| below 2^15), and 1/s as ONE MORE float behind the layer's bias (params[bias_off + C];
+ *   bias_off a multiple of 4).
  *   `head` is optional: weights [ceil(channels/32)][C/16][2][64][8] at 16-byte offset w_off in `weights`, bias [channels]
  *   followed by the inverse scale in params; head outputs are float32.  y_dev (optional) receives the tower output.
  * weights: float32 at float4 offset w_off4; params: float32 biases and SE matrices at float offsets.

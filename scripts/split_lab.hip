@@ -29,6 +29,26 @@ __global__ void __launch_bounds__(256) k_mfma_peak_h(float *out, int iters) {
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+__global__ void __launch_bounds__(256) k_mfma_peak_h16(float *out, int iters) {
+    bo_f32x4 acc[8];
+    for (int i = 0; i < 8; i++) acc[i] = bo_f32x4{0, 0, 0, 0};
+    bo_h8 a, b;
+    for (int i = 0; i < 8; i++) { a[i] = (_Float16)(threadIdx.x * 0.001f + i); b[i] = (_Float16)(i * 0.5f); }
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, a, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, a, acc[i], 0, 0, 0);
+            }
+    }
+    float s = 0;
+    for (int i = 0; i < 8; i++) for (int r = 0; r < 4; r++) s += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 template <int C, int MT>
 static int lab(int blocks, int B) {
     const int NL = 2 * blocks + 1;
@@ -41,6 +61,7 @@ static int lab(int blocks, int B) {
     CK(hipMalloc(&oa, (size_t)B * 128 * 4)); CK(hipMalloc(&ob, (size_t)B * 2048 * 4));
     std::vector<bo_tower_layer> L(NL);
     for (int l = 0; l < NL; l++) L[l] = {(int)(l * per), l == 0 ? 72 : 9 * C / 16, l * (C + 4), l == 0 ? 0 : (l % 2 ? 1 : 2), 0, 0, 0, l == NL - 1};
+
     CK(hipMemcpy(tl, L.data(), NL * sizeof(bo_tower_layer), hipMemcpyHostToDevice));
     bo_tower_head_s hh; hh.channels = 34; hh.split = 2; hh.w_off8 = (int)(NL * per); hh.b_off = 60000; hh.out_a = oa; hh.out_b = ob;
     const char *names[6] = {"full", "no weight loads", "no B reads", "no epilogue", "MFMA loop only", "full, every layer the same weights"};
@@ -82,6 +103,19 @@ int main() {
         const double n = (double)iters * 48;  // MFMAs per wave
         printf("bare v_mfma_f32_32x32x16_f16 chains, one wave per SIMD on 256 CUs: %.1f ns per MFMA = %.1f TFLOP/s\n", ms * 1e6 / n,
                n * 32768.0 * 1024 / (ms * 1e-3) / 1e12);
+    }
+    {
+        float *out; CK(hipMalloc(&out, 256 * 256 * 4));
+        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        const int iters = 2000;
+        hipLaunchKernelGGL(k_mfma_peak_h16, dim3(256), dim3(256), 0, 0, out, iters);
+        (void)hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k_mfma_peak_h16, dim3(256), dim3(256), 0, 0, out, iters);
+        (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+        const double n = (double)iters * 96;  // MFMAs per wave
+        printf("bare v_mfma_f32_16x16x32_f16 chains (8 accumulators, 3 dependent MFMAs each), one wave per SIMD on 256 CUs: %.1f ns per MFMA = %.1f TFLOP/s\n",
+               ms * 1e6 / n, n * 16384.0 * 1024 / (ms * 1e-3) / 1e12);
     }
     if (lab<128, 1>(10, 256)) return 1;
     if (lab<256, 2>(20, 256)) return 1;
