@@ -1322,7 +1322,8 @@ extern "C" int bo_nn_tower_forward(bo_tower *t, const float *x_dev, float *y_dev
         hs.out_a = (float *)head_a_dev; hs.out_b = (float *)head_b_dev;
         const bo_h8 *w8 = reinterpret_cast<const bo_h8 *>(t->wts);
         if (t->channels == 256) hipLaunchKernelGGL((bo_k_tower_s<256, 2>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
-        else hipLaunchKernelGGL((bo_k_tower_s<128, 1>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
+        else  // (B operands read two K-steps ahead, weight fragments requested twelve ahead: profiles/r03_split_tower.md)
+            hipLaunchKernelGGL((bo_k_tower_s<128, 1, 0, 2, 12>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
         RT((int)hipGetLastError());
         return BO_OK;
     }

@@ -22,6 +22,7 @@
 #pragma once
 #if !defined(BO_WAVE_EMU)
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "bo_tower.h"
 #include "bo_tower_h.h"
 
@@ -40,8 +41,21 @@ __device__ inline void bo_split4(const float (&v)[4], bo_h4 &hi, bo_h4 &lo) {
     }
 }
 
-// LAB (scripts/conv_lab.hip only): 0 = the kernel; 1 = no weight loads; 2 = no B operand reads; 4 = no epilogue; 5 = 1 + 2 + 4
-template <int C, int MT, int LAB = 0>
+// the same for values that are >= 0 already (behind a ReLU)
+__device__ inline void bo_split4_pos(const float (&v)[4], bo_h4 &hi, bo_h4 &lo) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const float c = fminf(v[e], 65504.0f);
+        hi[e] = (_Float16)c;
+        lo[e] = (_Float16)__builtin_fmaf((float)hi[e], -1.0f, c);  // = c - hi, one rounding (v_fma_mix: the fp16 operand is widened on read)
+    }
+}
+
+// LAB (scripts/split_lab.hip only): 0 = the kernel; 1 = no weight loads; 2 = no B operand reads; 3 = B operand reads into a dead
+// register set (issued, never waited for by an MFMA); 4 = no epilogue; 5 = 1 + 2 + 4
+// BD = how many K-steps ahead of its MFMAs a B operand is read from LDS (1: two register sets; 2, 3: four);
+// AR = weight-fragment sets = how many K-steps ahead a weight fragment is requested (8, or 12 with the loop unrolled 24-fold)
+template <int C, int MT, int LAB = 0, int BD = 1, int AR = 8>
 __global__ void __launch_bounds__(256)
 bo_k_tower_s(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const float *__restrict__ params,
              const bo_tower_layer *__restrict__ layers, int n_layers, float *__restrict__ y, int B, bo_tower_head_s head) {
@@ -56,8 +70,12 @@ bo_k_tower_s(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
     for (int i = tid; i < 2 * IMGH / 8; i += NT) reinterpret_cast<bo_h8 *>(X)[i] = bo_h8{0, 0, 0, 0, 0, 0, 0, 0};
 
     bo_f32x16 acc[MT][2];      // [tile][position half]: rows = channels 32*(MT*wave + tile) + (r&3) + 8*(r>>2) + 4*kg, col = position n + 32*half
-    bo_h8 a[8][MT][2];         // A fragments (hi, lo) of 8 consecutive K-steps
-    bo_h8 bq[2][2][2];         // B operands of two consecutive K-steps: [set][position half][hi | lo]
+    constexpr int UNR = AR == 8 ? 8 : 24;
+    static_assert((AR == 8 || AR == 12) && BD >= 1 && BD <= 3, "ring sizes the unrolled loop can index statically");
+    bo_h8 a[AR][MT][2];        // A fragments (hi, lo) of AR consecutive K-steps
+    constexpr int BM = BD == 1 ? 1 : 3;
+    bo_h8 bq[BM + 1][2][2];    // B operands of consecutive K-steps: [set][position half][hi | lo]
+    bo_h8 bdead[2][2];         // (LAB 3)
     float skip[MT][2][16];     // block input at this lane's (channels, positions), float32
     const int sw0 = bo_sw(cell0);  // (position n + 32 sits 4 rows further down: the same swizzle)
     // B operand address (in halves) of K-step j of a group of 8: tap cell offset `tc`, first channel group cg0 (a multiple of 8)
@@ -76,8 +94,9 @@ bo_k_tower_s(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
                 a[j][mt][hl] = __builtin_bit_cast(bo_h8, v);
             }
     };
-    auto read_b = [&](bo_h8(&b)[2][2], int base, int j) {  // K-step j of the group whose b_base() is `base`
+    auto read_b = [&](bo_h8(&b0)[2][2], int base, int j) {  // K-step j of the group whose b_base() is `base`
         if (LAB == 2 || LAB >= 5) return;
+        bo_h8(&b)[2][2] = LAB == 3 ? bdead : b0;
         const _Float16 *p = X + (base ^ (j << 4));
         b[0][0] = *reinterpret_cast<const bo_h8 *>(p);
         b[0][1] = *reinterpret_cast<const bo_h8 *>(p + IMGH);
@@ -87,7 +106,7 @@ bo_k_tower_s(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
 #define BO_S_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 
 #pragma unroll
-    for (int j = 0; j < 8; j++) load_a(j, layers[0].w_off4, j);
+    for (int j = 0; j < AR; j++) load_a(j, layers[0].w_off4, j);
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         // ---- stage the 120 input planes (float32 NCHW) as fp16 pairs, channels-last; channels >= 120 stay zero ----
         __syncthreads();
@@ -122,28 +141,30 @@ bo_k_tower_s(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
                 for (int t = 0; t < 2; t++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) acc[mt][t][r] = 0.0f;
-            int basen = b_base(-11, 0);  // step 0: tap 0 = (-1, -1), channel group 0
-            read_b(bq[0], basen, 0);
-            for (int s0 = 0; s0 < L.t4; s0 += 8) {
-                const int tap = s0 / ncg, cg0 = s0 - tap * ncg;
-                const int base0 = basen;
-                // the group after this one (the next 8 channel groups or the next tap; a harmless re-read at the layer's end)
-                const int s8 = s0 + 8, tapn = s8 < L.t4 ? s8 / ncg : tap, cgn = s8 < L.t4 ? s8 - tapn * ncg : cg0;
-                basen = b_base((tapn / 3 - 1) * 10 + (tapn % 3 - 1), cgn);
+            int basec = 0, basen = b_base(-11, 0);  // step 0: tap 0 = (-1, -1), channel group 0
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const bo_h8(&bc)[2][2] = bq[j & 1];
-                    read_b(bq[(j + 1) & 1], j < 7 ? base0 : basen, j < 7 ? j + 1 : 0);
+            for (int j = 0; j < BD; j++) read_b(bq[j], basen, j);
+            for (int s0 = 0; s0 < L.t4; s0 += UNR) {
+#pragma unroll
+                for (int j = 0; j < UNR; j++) {
+                    if ((j & 7) == 0) {  // a group of 8 steps = 8 channel groups of one tap
+                        basec = basen;
+                        // the group after this one (the next 8 channel groups or the next tap; a harmless re-read at the layer's end)
+                        const int s8 = s0 + j + 8, sc = s8 < L.t4 ? s8 : s0 + j, tapn = sc / ncg;
+                        basen = b_base((tapn / 3 - 1) * 10 + (tapn % 3 - 1), sc - tapn * ncg);
+                    }
+                    const bo_h8(&bc)[2][2] = bq[j & BM];
+                    read_b(bq[(j + BD) & BM], (j & 7) + BD < 8 ? basec : basen, (j + BD) & 7);
 #pragma unroll
                     for (int t = 0; t < 2; t++)
 #pragma unroll
                         for (int mt = 0; mt < MT; mt++) {  // the small terms first
-                            acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j][mt][1], bc[t][0], acc[mt][t], 0, 0, 0);
-                            acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j][mt][0], bc[t][1], acc[mt][t], 0, 0, 0);
-                            acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j][mt][0], bc[t][0], acc[mt][t], 0, 0, 0);
+                            acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j % AR][mt][1], bc[t][0], acc[mt][t], 0, 0, 0);
+                            acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j % AR][mt][0], bc[t][1], acc[mt][t], 0, 0, 0);
+                            acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j % AR][mt][0], bc[t][0], acc[mt][t], 0, 0, 0);
                         }
-                    const int sn = s0 + j + 8;  // this set's next owner: 8 steps ahead, maybe in the next layer
-                    load_a(j, sn < L.t4 ? L.w_off4 : Ln.w_off4, sn < L.t4 ? sn : sn - L.t4);
+                    const int sn = s0 + j + AR;  // this set's next owner: AR steps ahead, maybe in the next layer
+                    load_a(j % AR, sn < L.t4 ? L.w_off4 : Ln.w_off4, sn < L.t4 ? sn : sn - L.t4);
                     // every LDS read and weight load in the shadow of a different MFMA
 #pragma unroll
                     for (int t = 0; t < 4; t++) { BO_S_SGB(0x008, 1); BO_S_SGB(0x100, 1); }
@@ -198,38 +219,50 @@ bo_k_tower_s(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
                     for (int r = 0; r < 16; r++) gate[mt][r] = __shfl(g, (r & 3) + 8 * (r >> 2) + 4 * kg);
                 }
             }
-            if (LAB >= 4) {
-                if (acc[0][0][0] == 123.456f) X[tid] = (_Float16)(acc[0][1][1] + acc[MT - 1][0][2] + acc[MT - 1][1][3]);
-            } else
+            // (one straight-line copy per layer kind: with the kind tested per element the compiler emitted ~160 selects per layer)
+            auto write_back = [&](auto kind_c, auto y_c) {
+                constexpr int KIND = decltype(kind_c)::value;
+                constexpr bool TO_Y = decltype(y_c)::value;
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++)
+                for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    const int ch0 = (wave * MT + mt) * 32 + 4 * kg;
+                    for (int t = 0; t < 2; t++) {
+                        const int ch0 = (wave * MT + mt) * 32 + 4 * kg;
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        _Float16 *cellp = X + 40 * t * PH + bo_sw_addr<PH>(cell0, (wave * MT + mt) * 4 + q, sw0) + 4 * kg;
-                        float o[4];
+                        for (int q = 0; q < 4; q++) {
+                            _Float16 *cellp = X + 40 * t * PH + bo_sw_addr<PH>(cell0, (wave * MT + mt) * 4 + q, sw0) + 4 * kg;
+                            float o[4];
 #pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const int r = 4 * q + e;
-                            float v = acc[mt][t][r] * wscale + bv[mt][r];
-                            if (L.kind == 3) v = v * gate[mt][r];
-                            if (L.kind >= 2) v += skip[mt][t][r];
-                            o[e] = fmaxf(v, 0.0f);
-                            if (L.kind != 1) skip[mt][t][r] = o[e];
-                        }
-                        bo_h4 hi, lo;
-                        bo_split4(o, hi, lo);
-                        *reinterpret_cast<bo_h4 *>(cellp) = hi;
-                        *reinterpret_cast<bo_h4 *>(cellp + IMGH) = lo;
-                        if (L.last && y) {
-                            float *g2 = y + ((size_t)b * C + ch0 + 8 * q) * 64 + n + 32 * t;
+                            for (int e = 0; e < 4; e++) {
+                                const int r = 4 * q + e;
+                                float v = __builtin_fmaf(acc[mt][t][r], wscale, bv[mt][r]);  // (wscale is a power of two: the product is exact either way)
+                                if (KIND == 3) v = v * gate[mt][r];
+                                if (KIND >= 2) v += skip[mt][t][r];
+                                o[e] = fmaxf(v, 0.0f);
+                                if (KIND != 1) skip[mt][t][r] = o[e];
+                            }
+                            bo_h4 hi, lo;
+                            bo_split4_pos(o, hi, lo);
+                            *reinterpret_cast<bo_h4 *>(cellp) = hi;
+                            *reinterpret_cast<bo_h4 *>(cellp + IMGH) = lo;
+                            if (TO_Y) {
+                                float *g2 = y + ((size_t)b * C + ch0 + 8 * q) * 64 + n + 32 * t;
 #pragma unroll
-                            for (int e = 0; e < 4; e++) g2[e * 64] = o[e];
+                                for (int e = 0; e < 4; e++) g2[e * 64] = o[e];
+                            }
                         }
                     }
-                }
+            };
+            using std::integral_constant;
+            if (LAB >= 4) {
+                if (acc[0][0][0] == 123.456f) X[tid] = (_Float16)(acc[0][1][1] + acc[MT - 1][0][2] + acc[MT - 1][1][3] + (LAB == 3 ? (float)bdead[0][0][0] + (float)bdead[1][1][7] : 0.0f));
+            } else if (L.last && y) {
+                if (L.kind == 3) write_back(integral_constant<int, 3>{}, std::true_type{});
+                else write_back(integral_constant<int, 2>{}, std::true_type{});
+            } else if (L.kind == 0) write_back(integral_constant<int, 0>{}, std::false_type{});
+            else if (L.kind == 1) write_back(integral_constant<int, 1>{}, std::false_type{});
+            else if (L.kind == 2) write_back(integral_constant<int, 2>{}, std::false_type{});
+            else write_back(integral_constant<int, 3>{}, std::false_type{});
             __syncthreads();
         }
         // ---- the two 1x1 head convolutions + ReLU on the tower output in X: one 32x32 job per (32 head channels, position half) ----

@@ -64,8 +64,10 @@ static int lab(int blocks, int B) {
 
     CK(hipMemcpy(tl, L.data(), NL * sizeof(bo_tower_layer), hipMemcpyHostToDevice));
     bo_tower_head_s hh; hh.channels = 34; hh.split = 2; hh.w_off8 = (int)(NL * per); hh.b_off = 60000; hh.out_a = oa; hh.out_b = ob;
-    const char *names[6] = {"full", "no weight loads", "no B reads", "no epilogue", "MFMA loop only", "full, every layer the same weights"};
-    for (int variant = 0; variant < 6; variant++) {
+    const char *names[11] = {"full", "no weight loads", "no B reads", "no epilogue", "MFMA loop only", "full, every layer the same weights",
+                             "B reads into a dead register set", "B operands read two K-steps ahead", "B three K-steps ahead",
+                             "B three ahead, weights 12 ahead", "B two ahead, weights 12 ahead"};
+    for (int variant = 0; variant < 11; variant++) {
         if (variant == 5) {
             for (int l = 1; l < NL; l++) L[l].w_off4 = (int)(1 * per);
             CK(hipMemcpy(tl, L.data(), NL * sizeof(bo_tower_layer), hipMemcpyHostToDevice));
@@ -77,6 +79,11 @@ static int lab(int blocks, int B) {
             else if (variant == 2) hipLaunchKernelGGL((bo_k_tower_s<C, MT, 2>), g, t, 0, 0, x, tw, tp, tl, NL, nullptr, B, hh);
             else if (variant == 3) hipLaunchKernelGGL((bo_k_tower_s<C, MT, 4>), g, t, 0, 0, x, tw, tp, tl, NL, nullptr, B, hh);
             else if (variant == 4) hipLaunchKernelGGL((bo_k_tower_s<C, MT, 5>), g, t, 0, 0, x, tw, tp, tl, NL, nullptr, B, hh);
+            else if (variant == 6) hipLaunchKernelGGL((bo_k_tower_s<C, MT, 3>), g, t, 0, 0, x, tw, tp, tl, NL, nullptr, B, hh);
+            else if (variant == 7) hipLaunchKernelGGL((bo_k_tower_s<C, MT, 0, 2>), g, t, 0, 0, x, tw, tp, tl, NL, nullptr, B, hh);
+            else if (variant == 8) hipLaunchKernelGGL((bo_k_tower_s<C, MT, 0, 3>), g, t, 0, 0, x, tw, tp, tl, NL, nullptr, B, hh);
+            else if (variant == 9) hipLaunchKernelGGL((bo_k_tower_s<C, MT, 0, 3, 12>), g, t, 0, 0, x, tw, tp, tl, NL, nullptr, B, hh);
+            else if (variant == 10) hipLaunchKernelGGL((bo_k_tower_s<C, MT, 0, 2, 12>), g, t, 0, 0, x, tw, tp, tl, NL, nullptr, B, hh);
             else hipLaunchKernelGGL((bo_k_tower_s<C, MT, 0>), g, t, 0, 0, x, tw, tp, tl, NL, nullptr, B, hh);
         };
         for (int i = 0; i < 3; i++) go();
