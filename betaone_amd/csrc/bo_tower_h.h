@@ -44,7 +44,9 @@ struct bo_tower_head_h {
 // 5 = 1 + 2 + 4; 6 = 5 without barriers
 // MT = 32-channel output tiles per wave: C/(32*MT) waves per workgroup.  MT = 2 (256 filters: 4 waves, one per SIMD, 64
 // channels x 128 positions = 128 accumulator registers) reads every B operand for two MFMAs and halves the LDS traffic.
-template <int C, int MT, int LAB = 0>
+// BD = how many K-steps ahead of its MFMAs a B operand is read from LDS (1: two register sets; 2, 3: four); AR = weight-fragment
+// sets = how many K-steps ahead a fragment is requested (8, or 12 with the loop unrolled 24-fold) -- see bo_tower_s.h
+template <int C, int MT, int LAB = 0, int BD = 1, int AR = 8>
 __global__ void __launch_bounds__(C * 2 / MT)
 bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const float *__restrict__ params,
              const bo_tower_layer *__restrict__ layers, int n_layers, int B, bo_tower_head_h head) {
@@ -59,8 +61,10 @@ bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
     for (int i = tid; i < 2 * IMGH / 8; i += NT) reinterpret_cast<bo_h8 *>(X)[i] = bo_h8{0, 0, 0, 0, 0, 0, 0, 0};
 
     bo_f32x16 acc[MT][4];      // [tile][board*2 + half]: rows = channels 32*(MT*wave + tile) + (r&3) + 8*(r>>2) + 4*kg, col = position n
-    bo_h8 a[8][MT];            // A fragments of 8 consecutive K-steps
-    bo_h8 bq[2][4];            // B operands of two consecutive K-steps
+    constexpr int UNR = AR == 8 ? 8 : 24, BM = BD == 1 ? 1 : 3;
+    static_assert((AR == 8 || AR == 12) && BD >= 1 && BD <= 3, "ring sizes the unrolled loop can index statically");
+    bo_h8 a[AR][MT];           // A fragments of AR consecutive K-steps
+    bo_h8 bq[BM + 1][4];       // B operands of consecutive K-steps
     bo_h4 skip[MT][4][4];      // block input at this lane's (positions, channels), packed like the LDS writes
     const int sw0 = bo_sw(cell0);  // (position n + 32 sits 4 rows further down: the same swizzle)
     // B operand address (in halves) of K-step j of a group of 8: tap cell offset `tc`, first channel group cg0 (a multiple of 8)
@@ -90,7 +94,7 @@ bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
 #define BO_H_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 
 #pragma unroll
-    for (int j = 0; j < 8; j++) load_a(j, layers[0].w_off4, j);
+    for (int j = 0; j < AR; j++) load_a(j, layers[0].w_off4, j);
     const int npairs = (B + 1) >> 1;
     for (int pb = blockIdx.x; pb < npairs; pb += gridDim.x) {
         const int b0 = 2 * pb;
@@ -120,24 +124,26 @@ bo_k_tower_h(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
                 for (int t = 0; t < 4; t++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) acc[mt][t][r] = 0.0f;
-            int basen = b_base(-11, 0);  // step 0: tap 0 = (-1, -1), channel group 0
-            read_b(bq[0], basen, 0);
-            for (int s0 = 0; s0 < L.t4; s0 += 8) {
-                const int tap = s0 / ncg, cg0 = s0 - tap * ncg;
-                const int base0 = basen;
-                // the group after this one (the next 8 channel groups or the next tap; a harmless re-read at the layer's end)
-                const int s8 = s0 + 8, tapn = s8 < L.t4 ? s8 / ncg : tap, cgn = s8 < L.t4 ? s8 - tapn * ncg : cg0;
-                basen = b_base((tapn / 3 - 1) * 10 + (tapn % 3 - 1), cgn);
+            int basec = 0, basen = b_base(-11, 0);  // step 0: tap 0 = (-1, -1), channel group 0
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const bo_h8(&bc)[4] = bq[j & 1];
-                    read_b(bq[(j + 1) & 1], j < 7 ? base0 : basen, j < 7 ? j + 1 : 0);
+            for (int j = 0; j < BD; j++) read_b(bq[j], basen, j);
+            for (int s0 = 0; s0 < L.t4; s0 += UNR) {
+#pragma unroll
+                for (int j = 0; j < UNR; j++) {
+                    if ((j & 7) == 0) {  // a group of 8 steps = 8 channel groups of one tap
+                        basec = basen;
+                        // the group after this one (the next 8 channel groups or the next tap; a harmless re-read at the layer's end)
+                        const int s8 = s0 + j + 8, sc = s8 < L.t4 ? s8 : s0 + j, tapn = sc / ncg;
+                        basen = b_base((tapn / 3 - 1) * 10 + (tapn % 3 - 1), sc - tapn * ncg);
+                    }
+                    const bo_h8(&bc)[4] = bq[j & BM];
+                    read_b(bq[(j + BD) & BM], (j & 7) + BD < 8 ? basec : basen, (j + BD) & 7);
 #pragma unroll
                     for (int t = 0; t < 4; t++)
 #pragma unroll
-                        for (int mt = 0; mt < MT; mt++) acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j][mt], bc[t], acc[mt][t], 0, 0, 0);
-                    const int sn = s0 + j + 8;  // this set's next owner: 8 steps ahead, maybe in the next layer
-                    load_a(j, sn < L.t4 ? L.w_off4 : Ln.w_off4, sn < L.t4 ? sn : sn - L.t4);
+                        for (int mt = 0; mt < MT; mt++) acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[j % AR][mt], bc[t], acc[mt][t], 0, 0, 0);
+                    const int sn = s0 + j + AR;  // this set's next owner: AR steps ahead, maybe in the next layer
+                    load_a(j % AR, sn < L.t4 ? L.w_off4 : Ln.w_off4, sn < L.t4 ? sn : sn - L.t4);
                     // every LDS read and weight load in the shadow of a different MFMA
 #pragma unroll
                     for (int t = 0; t < 4; t++) { BO_H_SGB(0x008, MT); BO_H_SGB(0x100, 1); }

@@ -116,7 +116,41 @@ static int lab(int blocks, int B, bool random_data = false) {
     return 0;
 }
 
-int main() {
+// fp16 tower, 128 filters, two boards per workgroup: prefetch depths (BD, AR) at a fast-mode batch
+template <int BD, int AR>
+static int lab_h(int blocks, int B) {
+    constexpr int C = 128;
+    const int NL = 2 * blocks + 1;
+    const size_t per = (size_t)(9 * C / 16) * (C / 32) * 64;  // bo_h8 per layer
+    bo_h8 *tw; float *tp, *x; bo_tower_layer *tl; _Float16 *oa, *ob;
+    CK(hipMalloc(&tw, per * NL * 16 + (1 << 20))); CK(hipMemset(tw, 0, per * NL * 16 + (1 << 20)));
+    CK(hipMalloc(&tp, 64 * 1024 * 4)); CK(hipMemset(tp, 0, 64 * 1024 * 4));
+    CK(hipMalloc(&x, (size_t)B * 120 * 64 * 4)); CK(hipMemset(x, 0, (size_t)B * 120 * 64 * 4));
+    CK(hipMalloc(&tl, NL * sizeof(bo_tower_layer)));
+    CK(hipMalloc(&oa, (size_t)B * 128 * 2)); CK(hipMalloc(&ob, (size_t)B * 2048 * 2));
+    std::vector<bo_tower_layer> L(NL);
+    for (int l = 0; l < NL; l++) L[l] = {(int)(l * per), 72, l * (C + 4), l == 0 ? 0 : (l % 2 ? 1 : 2), 0, 0, 0, l == NL - 1};
+    CK(hipMemcpy(tl, L.data(), NL * sizeof(bo_tower_layer), hipMemcpyHostToDevice));
+    bo_tower_head_h hh; hh.channels = 34; hh.split = 2; hh.w_off8 = (int)(NL * per); hh.b_off = 60000; hh.out_a = oa; hh.out_b = ob;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    auto go = [&]() { hipLaunchKernelGGL((bo_k_tower_h<C, 1, 0, BD, AR>), dim3(256), dim3(256), 0, 0, x, tw, tp, tl, NL, B, hh); };
+    for (int i = 0; i < 2; i++) go();
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < 5; i++) go();
+    (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("fp16 tower %d+0x128, B=%d, B operands %d steps ahead, weights %d ahead: %.1f us = %.2f us/layer/512 boards\n", blocks, B, BD, AR,
+           ms * 1000 / 5, ms * 1000 / 5 / NL / (B / 512));
+    (void)hipFree(tw); (void)hipFree(tp); (void)hipFree(x); (void)hipFree(tl); (void)hipFree(oa); (void)hipFree(ob);
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1) {  // fp16 tower only
+        if (lab_h<1, 8>(10, 4096) || lab_h<2, 8>(10, 4096) || lab_h<3, 8>(10, 4096) || lab_h<2, 12>(10, 4096) || lab_h<1, 12>(10, 4096)) return 1;
+        if (lab_h<1, 8>(10, 512) || lab_h<2, 8>(10, 512) || lab_h<2, 12>(10, 512)) return 1;
+        return 0;
+    }
     {
         float *out; CK(hipMalloc(&out, 256 * 256 * 4));
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
