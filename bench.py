@@ -191,6 +191,7 @@ def select_roofline(args, device):
             "levels_per_launch": levels, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(t * 1e3, 4)}
 
 
+TOWER_S_PMC_BYTES = 110_849_000   # rocprofv3 --pmc FETCH_SIZE (x 2) + WRITE_SIZE of bo_k_tower_s<128>, 256 boards (profiles/r03_tower_split_pmc.md)
 TOWER_WG_PMC_BYTES = 187_641_000  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of bo_k_tower_wg<128>, 256 boards (profiles/r02_tower_wg_pmc.md)
 
 
@@ -252,7 +253,10 @@ def nn_roofline(net, batch, device, ro=None, drv=None, plies=3):
         # as executed flops.  (A bare chain of this instruction on all 1024 SIMDs sustains 1.74 PFLOP/s on this part: the matrix pipe
         # under load clocks below the 2.4 GHz the peak is quoted at -- scripts/split_lab.hip, profiles/r03_split_tower.md.)
         return {"bound": "mfma", "kernel": "bo_k_tower_s", "achieved": round(executed / us / 1e6, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                "frac": round(executed / us / 1e6 / 2500.0, 4), "traffic": None, "avg_launch_us": round(us, 1), "launches_timed": n_timed, "timing": how,
+                "frac": round(executed / us / 1e6 / 2500.0, 4), "traffic": TOWER_S_PMC_BYTES if batch == 256 and C == 128 and n_conv == 21 else None,
+                "traffic_source": "constant from the committed PMC pass profiles/r03_tower_split_pmc.md (2 x FETCH_SIZE + WRITE_SIZE per launch: every XCD's L2 "
+                                  "streams the 12 MB of split weights once); valid for 256 boards of the 10x128 net only, null otherwise",
+                "avg_launch_us": round(us, 1), "launches_timed": n_timed, "timing": how,
                 "back_to_back_us": round(b2b, 1), "boards_per_launch": batch, "conv_layers": n_conv,
                 "algorithmic_direct_conv_tflops": round(algorithmic / us / 1e6, 1),
                 "float32_equivalent_tflops": round(executed / 3.0 / us / 1e6, 1),
