@@ -342,7 +342,7 @@ def fast_select_sweep(ro, drv, steps=12):
     """Every variant of the select + backup kernel over `steps` more launches each on this run's trees (they keep growing meanwhile;
     when the searches run out of simulations a ply is played in between)."""
     out = []
-    for ut, fl in ((2, 48), (2, 16), (2, 48), (2, 18), (2, 0), (4, 8)):  # (flags 16..19: eight lanes per game, 48: + root levels in one pass; 0..7: half a wave per game; 8 / 9: one lane per game)
+    for ut, fl in ((2, 18), (2, 16), (2, 19), (2, 0), (4, 8)):  # (flags 16..19: eight lanes per game; 0..7: half a wave per game; 8 / 9: one lane per game)
         if True:
             ro.eng.fast_options(games_per_halfwave=ut, select_flags=fl)
             r = fast_select_roofline(ro, drv, steps, f" u{ut} flags{fl}")

@@ -476,7 +476,6 @@ static int launch_fw_select(bo_engine *e, const float *value_dev, int kind, void
         const int blocks = (G + 7) / 8;
         const int fl = f.sel_flags & 3;
 #define SELO(K) return RT_LAUNCH(K, blocks, stream, e->d, e->f, value_dev, kind)
-        if (f.sel_flags & FW_SEL_ROOTB) { if (L > 4) SELO(bo_k_fw_select_r8l8); SELO(bo_k_fw_select_r8l4); }
         if (L > 4) { if (fl & 2) SELO(bo_k_fw_select_o8l8_2); SELO(bo_k_fw_select_o8l8_0); }
         if (fl == 3) SELO(bo_k_fw_select_o8l4_3);
         if (fl == 2) SELO(bo_k_fw_select_o8l4_2);
@@ -1000,7 +999,7 @@ extern "C" int bo_fast_options(bo_engine *e, int32_t tree_reuse, int32_t games_p
         return fail(BO_E_ARG, "bo_fast_options: games_per_halfwave must be 1, 2 or 4");
     if (tree_reuse >= 0) e->fast_reuse = tree_reuse ? 1 : 0;
     if (games_per_halfwave >= 0) e->f.sel_ut = games_per_halfwave == 1 ? 2 : games_per_halfwave;  // (one game per half-wave is the form for more than 16 leaves per step)
-    if (select_flags >= 0) e->f.sel_flags = select_flags & (FW_SEL_NT | FW_SEL_ROOT_IN_REGS | FW_SEL_DENSE | FW_SEL_LANE | FW_SEL_OCT | FW_SEL_ROOTB);
+    if (select_flags >= 0) e->f.sel_flags = select_flags & (FW_SEL_NT | FW_SEL_ROOT_IN_REGS | FW_SEL_DENSE | FW_SEL_LANE | FW_SEL_OCT);
     return BO_OK;
 }
 

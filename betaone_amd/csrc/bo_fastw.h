@@ -61,7 +61,7 @@
 #define FW_DRAW (-3)
 #define FW_SIM_MATE (-2)      // sim_row codes of simulations that ended in a known terminal (no NN row)
 #define FW_SIM_DRAW (-3)
-enum { FW_SEL_NT = 1, FW_SEL_ROOT_IN_REGS = 2, FW_SEL_DENSE = 4, FW_SEL_LANE = 8, FW_SEL_OCT = 16, FW_SEL_ROOTB = 32 };  // FastW::sel_flags
+enum { FW_SEL_NT = 1, FW_SEL_ROOT_IN_REGS = 2, FW_SEL_DENSE = 4, FW_SEL_LANE = 8, FW_SEL_OCT = 16 };  // FastW::sel_flags
 
 struct alignas(16) WRec {
     int n;        // visits; -1 = padding of a run's last granule, never selected
@@ -262,14 +262,8 @@ BO_DEV int fw_ctz(unsigned long long m) { return __builtin_ctzll(m); }
 //   4. the control blocks go back with one coalesced store per game
 // W lanes per game (32: half a wave, two records per lane; 8: an eighth, RPL = 5 records per lane and 8 games per instruction),
 // UT games interleaved per group of W lanes
-// ROOTB (eight lanes per game, L <= 8): the step's descents share the root's run, so ALL of their root levels are scored in one
-// pass over registers -- descent s + 1 differs from descent s only in the visit count under the square root and in one more
-// in-flight visit on the child descent s chose -- and only the levels below the root go through the level loop; what a finished
-// descent means for the row / simulation lists (known terminal, a leaf another descent already asked for, a new row) is worked
-// out once per launch behind the loop instead of behind every level.  Same decisions in the same order as the plain form.
-template <int W, int RPL, int UT, int LCAP, bool NT, bool ROOTC, bool ROOTB = false>
+template <int W, int RPL, int UT, int LCAP, bool NT, bool ROOTC>
 BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int kind) {
-    static_assert(!ROOTB || (W == 8 && UT == 1 && LCAP <= 8 && !ROOTC), "root batching: the eight-lanes-per-game form");
     typedef typename FwMask<LCAP>::T mask_t;
     constexpr int NGRP = 64 / W, NSL = NGRP * UT;  // groups of lanes per wave; games per wave
     constexpr int CSL = FWC_HEAD + FWR_FIELDS * LCAP, NCR = (CSL + W - 1) / W, NVR = (LCAP + W - 1) / W;
@@ -491,311 +485,6 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
         }
     }
     bo_wave_sync();
-    if (ROOTB) {
-        BO_SHARED int s_end[NSL][LCAP][4];  // how descent s ended: leaf record, link of the run it lives in, its state code, path length
-        const int slot = FW_SLOT(0);
-        const bool bz = busy[0];
-        const int nst = bz ? nmax[0] : 0;  // descents this launch makes for the game
-        const int lk0 = bz ? root_link[0] : 0;
-        const int ngran0 = fw_ngran(lk0), nrec0 = ngran0 * BO_FW_GR, first0 = fw_first(lk0);
-        const WRec *R0 = FW_A(0) + (size_t)first0 * BO_FW_GR;
-        const float ninf = -__builtin_inff();
-        // ---- 3a. the root level of every descent of the step: one request, LCAP scorings in registers ---------------------
-        WRec r0[RPL];
-        BO_UNROLL
-        for (int k = 0; k < RPL; k++) r0[k] = fw_ld<NT>(R0 + (c + W * k < nrec0 ? c + W * k : 0));
-        float sq0[LCAP];
-        BO_UNROLL
-        for (int s = 0; s < LCAP; s++) { const int pn_ = root_n[0] + 1 + s; sq0[s] = f.sqrt_tab[pn_ < BO_FW_SQRT_TAB ? pn_ : 0]; }
-        int cnt[RPL], ne[RPL];
-        bool ok[RPL];
-        float rq[RPL], ru[RPL], t1[RPL], we[RPL];
-        int nk0 = 0;
-        BO_UNROLL
-        for (int k = 0; k < RPL; k++) {
-            ok[k] = bz && c + W * k < nrec0 && r0[k].n >= 0;
-            nk0 += ok[k] ? 1 : 0;
-            cnt[k] = 0; ne[k] = r0[k].n;
-            t1[k] = cpuct * r0[k].prior;
-            we[k] = r0[k].w - (float)cnt[k];
-            const int t = ne[k] < 0 ? 0 : ne[k] > BO_FW_RCP_TAB - 2 ? BO_FW_RCP_TAB - 2 : ne[k];
-            rq[k] = s_rcp[t]; ru[k] = s_rcp[t + 1];
-        }
-        const bool wide0 = bo_ballot(bz && nrec0 > W * RPL) != 0;  // a root with more children than one pass takes, somewhere in the wave
-        int win1[LCAP], wne1[LCAP], wl1[LCAP];
-        int kids_l = 0, levels_l = 0, gran_l = 0;  // this lane's share of the game's counters (lane 0 of the game: levels, granules)
-        BO_UNROLL
-        for (int s = 0; s < LCAP; s++) {
-            const bool lv = bz && s < nst;
-            const int pn_ = root_n[0] + 1 + s;
-            float sq = sq0[s];
-            bool beyond = lv && pn_ >= BO_FW_SQRT_TAB;
-            BO_UNROLL
-            for (int k = 0; k < RPL; k++) beyond = beyond || (lv && ok[k] && ne[k] > BO_FW_RCP_TAB - 2);
-            if (bo_ballot(beyond) != 0) {  // counts beyond the tables (rare): the exact operations
-                if (pn_ >= BO_FW_SQRT_TAB) sq = sqrtf((float)pn_);
-                BO_UNROLL
-                for (int k = 0; k < RPL; k++)
-                    if (ne[k] > BO_FW_RCP_TAB - 2) { rq[k] = 1.0f / (float)ne[k]; ru[k] = 1.0f / (float)(1 + ne[k]); }
-            }
-            float best = ninf;
-            int bi = c, bne = ne[0], bl = r0[0].link;
-            BO_UNROLL
-            for (int k = 0; k < RPL; k++) {
-                const float t2_ = t1[k] * sq;
-                const float uu = t2_ * ru[k];
-                const float qv = ne[k] > 0 ? we[k] * rq[k] : 0.0f;
-                float sck = qv + uu;
-                sck = (lv && ok[k] && sck == sck) ? sck : ninf;
-                const bool better = k == 0 || sck > best;
-                best = better ? sck : best; bi = better ? c + W * k : bi; bne = better ? ne[k] : bne; bl = better ? r0[k].link : bl;
-            }
-            int extra = 0;
-            if (wide0) {
-                if (lv && nrec0 > W * RPL) {
-                    for (int i = W * RPL + c; i < nrec0; i += W) {
-                        const WRec rx = fw_ld<false>(R0 + i);
-                        int cntx = 0;
-                        BO_UNROLL
-                        for (int sp = 0; sp < LCAP; sp++) cntx += (sp < s && win1[sp < s ? sp : 0] == i) ? 1 : 0;
-                        const bool okx = rx.n >= 0;
-                        const int nex = rx.n + cntx;
-                        const float rqx = nex > 0 ? 1.0f / (float)nex : 0.0f, rux = 1.0f / (float)(1 + nex);
-                        extra += okx ? 1 : 0;
-                        const float wex = rx.w - (float)cntx;
-                        const float t1x = cpuct * rx.prior;
-                        const float t2x = t1x * sq;
-                        const float uux = t2x * rux;
-                        const float qvx = nex > 0 ? wex * rqx : 0.0f;
-                        float scx = qvx + uux;
-                        scx = (okx && scx == scx) ? scx : ninf;
-                        if (scx > best) { best = scx; bi = i; bne = nex; bl = rx.link; }
-                    }
-                }
-            }
-            float mx = best;
-#define BO_FW_RED8(kind_) { const float o = __builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, mx), kind_)); mx = o > mx ? o : mx; }
-            BO_FW_RED8(0) BO_FW_RED8(1) BO_FW_RED8(2)
-            int win = (lv && best == mx && mx > ninf) ? bi : 0x7fffffff;
-#define BO_FW_MIN8(kind_) { const int o = BO_ROW_XCHG(win, kind_); win = o < win ? o : win; }
-            BO_FW_MIN8(0) BO_FW_MIN8(1) BO_FW_MIN8(2)
-            if (win == 0x7fffffff) win = -1;
-            const bool nan_all = lv && win < 0;  // every score was NaN: take the first child (it exists: a run is never empty)
-            if (bo_ballot(nan_all) != 0) {
-                if (nan_all) {
-                    win = 0;
-                    if (c == 0) { bi = 0; bne = r0[0].n; bl = r0[0].link; bo_atomic_or(&e.status[FW_G(0)], ST_NAN_SCORE); }
-                }
-            }
-            const int src = hb + (win & (W - 1));
-            const int w_ne = bo_shfl(bne, src);
-            const int w_l = bo_shfl(bl, src);
-            win1[s] = win; wne1[s] = w_ne; wl1[s] = w_l;
-            BO_UNROLL
-            for (int k = 0; k < RPL; k++) {  // the chosen child carries one more descent in flight
-                const int add = (lv && win == c + W * k) ? 1 : 0;
-                cnt[k] += add; ne[k] += add;
-                we[k] = r0[k].w - (float)cnt[k];
-                const int t = ne[k] < 0 ? 0 : ne[k] > BO_FW_RCP_TAB - 2 ? BO_FW_RCP_TAB - 2 : ne[k];
-                rq[k] = s_rcp[t]; ru[k] = s_rcp[t + 1];
-            }
-            kids_l += lv ? nk0 + extra : 0;
-            if (lv && c == 0) {
-                int *sp = f.sim_path + ((size_t)FW_G(0) * L + s) * BO_FW_PATH_CAP;
-                sp[0] = 0; sp[1] = first0 * BO_FW_GR + win;
-                levels_l += 1;
-                if (w_l < 0) { s_end[slot][s][0] = first0 * BO_FW_GR + win; s_end[slot][s][1] = lk0; s_end[slot][s][2] = w_l; s_end[slot][s][3] = 2; }
-            }
-        }
-        if (bz && c == 0) gran_l += ngran0;
-        // ---- 3b. the levels below the root, one descent after the other (pipelined as in the plain form) ------------------
-        // descent s starts at depth 2 in the run behind its root child; the descents before it that chose the same root child share its path so far
-        auto first_deep = [&](int from) {  // the first descent >= from that goes below the root, or LCAP
-            int nx = LCAP;
-            BO_UNROLL
-            for (int sp = LCAP - 1; sp >= 0; sp--) nx = (sp >= from && sp < nst && wl1[sp] >= 0) ? sp : nx;
-            return nx;
-        };
-        auto pick = [&](const int (&a)[LCAP], int i) { int v = a[0]; BO_UNROLL for (int sp = 1; sp < LCAP; sp++) v = sp == i ? a[sp] : v; return v; };
-        auto mask1 = [&](int sd) {  // earlier descents through the same root child
-            const int ws = pick(win1, sd);
-            mask_t m = 0;
-            BO_UNROLL
-            for (int sp = 0; sp < LCAP - 1; sp++) m |= (mask_t)((sp < sd && win1[sp] == ws) ? 1 : 0) << sp;
-            return m;
-        };
-        int sd = first_deep(0);
-        bool bd = bz && sd < LCAP;
-        int lnk = bd ? pick(wl1, sd) : 0, pnd = bd ? pick(wne1, sd) + 1 : 1, dd2 = 2;
-        mask_t Md = bd ? mask1(sd) : (mask_t)0;
-        WRec rd[RPL];
-        float sqd;
-#define BO_FW_ISSUE_D                                                                                                   \
-        {                                                                                                               \
-            const int lk_ = bd ? lnk : 0;                                                                               \
-            const int nrec_ = fw_ngran(lk_) * BO_FW_GR;                                                                 \
-            const WRec *R_ = FW_A(0) + (size_t)fw_first(lk_) * BO_FW_GR;                                                \
-            BO_UNROLL                                                                                                   \
-            for (int k_ = 0; k_ < RPL; k_++) rd[k_] = fw_ld<NT>(R_ + (c + W * k_ < nrec_ ? c + W * k_ : 0));            \
-            sqd = f.sqrt_tab[pnd < BO_FW_SQRT_TAB ? pnd : 0];                                                           \
-        }
-        BO_FW_ISSUE_D
-        while (bo_ballot(bd) != 0) {
-            n_iter++;
-            const bool lv = bd;
-            const int lk = lv ? lnk : 0;
-            const int ngran = fw_ngran(lk), nrec = ngran * BO_FW_GR, first = fw_first(lk);
-            const int dd = dd2 < BO_FW_PATH_CAP ? dd2 : BO_FW_PATH_CAP - 1;
-            unsigned iw[NW];
-            BO_UNROLL
-            for (int w = 0; w < NW; w++) iw[w] = s_idx[slot][dd][w];
-            int cntd[RPL], ned[RPL];
-            bool okd[RPL];
-            float rqd[RPL], rud[RPL];
-            bool beyond = lv && pnd >= BO_FW_SQRT_TAB;
-            unsigned cpk = 0u;  // descents in flight through this lane's records: 4 bits per pass
-            BO_UNROLL
-            for (int sp = 0; sp < LCAP - 1; sp++) {
-                const unsigned bb = (iw[sp >> 2] >> (8 * (sp & 3))) & 255u;
-                const unsigned mine = (unsigned)((Md >> sp) & 1) & ((bb % W) == (unsigned)c ? 1u : 0u);
-                cpk += (bb / W < 8u ? mine : 0u) << (4 * (bb / W & 7u));
-            }
-            int nkl = 0;
-            BO_UNROLL
-            for (int k = 0; k < RPL; k++) {
-                cntd[k] = (int)((cpk >> (4 * k)) & 15u);
-                okd[k] = lv && c + W * k < nrec && rd[k].n >= 0;
-                nkl += okd[k] ? 1 : 0;
-                ned[k] = rd[k].n + cntd[k];
-                const int t = ned[k] < 0 ? 0 : ned[k] > BO_FW_RCP_TAB - 2 ? BO_FW_RCP_TAB - 2 : ned[k];
-                rqd[k] = s_rcp[t]; rud[k] = s_rcp[t + 1];
-                beyond = beyond || (okd[k] && ned[k] > BO_FW_RCP_TAB - 2);
-            }
-            float sq = sqd;
-            if (bo_ballot(beyond) != 0) {
-                if (pnd >= BO_FW_SQRT_TAB) sq = sqrtf((float)pnd);
-                BO_UNROLL
-                for (int k = 0; k < RPL; k++)
-                    if (ned[k] > BO_FW_RCP_TAB - 2) { rqd[k] = 1.0f / (float)ned[k]; rud[k] = 1.0f / (float)(1 + ned[k]); }
-            }
-            float best = ninf;
-            int bi = c, bne = ned[0], bl = rd[0].link;
-            BO_UNROLL
-            for (int k = 0; k < RPL; k++) {
-                const float wek = rd[k].w - (float)cntd[k];
-                const float t1k = cpuct * rd[k].prior;
-                const float t2k = t1k * sq;
-                const float uu = t2k * rud[k];
-                const float qv = ned[k] > 0 ? wek * rqd[k] : 0.0f;
-                float sck = qv + uu;
-                sck = (okd[k] && sck == sck) ? sck : ninf;
-                const bool better = k == 0 || sck > best;
-                best = better ? sck : best; bi = better ? c + W * k : bi; bne = better ? ned[k] : bne; bl = better ? rd[k].link : bl;
-            }
-            const bool wide = bo_ballot(lv && nrec > W * RPL) != 0;
-            if (wide) {
-                if (lv && nrec > W * RPL) {
-                    const WRec *R = FW_A(0) + (size_t)first * BO_FW_GR;
-                    for (int i = W * RPL + c; i < nrec; i += W) {
-                        const WRec rx = fw_ld<false>(R + i);
-                        int cntx = 0;
-                        BO_UNROLL
-                        for (int sp = 0; sp < LCAP - 1; sp++)
-                            cntx += (int)((Md >> sp) & 1) & ((int)((iw[sp >> 2] >> (8 * (sp & 3))) & 255u) == i ? 1 : 0);
-                        const bool okx = rx.n >= 0;
-                        const int nex = rx.n + cntx;
-                        const float rqx = nex > 0 ? 1.0f / (float)nex : 0.0f, rux = 1.0f / (float)(1 + nex);
-                        nkl += okx ? 1 : 0;
-                        const float wex = rx.w - (float)cntx;
-                        const float t1x = cpuct * rx.prior;
-                        const float t2x = t1x * sq;
-                        const float uux = t2x * rux;
-                        const float qvx = nex > 0 ? wex * rqx : 0.0f;
-                        float scx = qvx + uux;
-                        scx = (okx && scx == scx) ? scx : ninf;
-                        if (scx > best) { best = scx; bi = i; bne = nex; bl = rx.link; }
-                    }
-                }
-            }
-            kids_l += nkl;  // (per lane: added up over the game's lanes once, behind the loop)
-            float mx = best;
-            BO_FW_RED8(0) BO_FW_RED8(1) BO_FW_RED8(2)
-            int win = (lv && best == mx && mx > ninf) ? bi : 0x7fffffff;
-            BO_FW_MIN8(0) BO_FW_MIN8(1) BO_FW_MIN8(2)
-            if (win == 0x7fffffff) win = -1;
-            const bool nan_all = lv && win < 0;
-            if (bo_ballot(nan_all) != 0) {
-                if (nan_all) {
-                    win = 0;
-                    if (c == 0) { bi = 0; bne = rd[0].n; bl = rd[0].link; bo_atomic_or(&e.status[FW_G(0)], ST_NAN_SCORE); }
-                }
-            }
-            const int src = hb + (win & (W - 1));
-            const int w_ne = bo_shfl(bne, src);
-            int w_l = bo_shfl(bl, src);
-            const int old_link = lnk, old_d = dd2, s = sd;
-            const bool over = lv && w_l >= 0 && old_d + 1 >= BO_FW_PATH_CAP;  // path buffer full: the visit counts as a draw
-            if (over) w_l = FW_DRAW;
-            const bool cont = lv && w_l >= 0, ended = lv && !cont;
-            mask_t Mn = Md;
-            BO_UNROLL
-            for (int sp = 0; sp < LCAP - 1; sp++)  // earlier descents that went elsewhere no longer share the path
-                Mn &= ~((mask_t)((int)((iw[sp >> 2] >> (8 * (sp & 3))) & 255u) != win ? 1 : 0) << sp);
-            const int snx = ended ? first_deep(s + 1) : s;
-            const bool more = ended && snx < LCAP;
-            sd = snx;
-            lnk = cont ? w_l : more ? pick(wl1, snx) : lnk;
-            pnd = cont ? w_ne + 1 : more ? pick(wne1, snx) + 1 : pnd;
-            dd2 = cont ? old_d + 1 : 2;
-            Md = cont ? Mn : more ? mask1(snx) : Md;
-            bd = cont || more;
-            BO_FW_ISSUE_D
-            // ---- the level's bookkeeping, under the latency of the request above ---------------------------------------
-            const int leaf = first * BO_FW_GR + win;
-            if (lv && c == 0) {
-                reinterpret_cast<unsigned char *>(&s_idx[slot][dd][0])[s] = (unsigned char)win;
-                f.sim_path[((size_t)FW_G(0) * L + s) * BO_FW_PATH_CAP + dd] = leaf;
-                levels_l += 1; gran_l += ngran;
-                if (ended) { s_end[slot][s][0] = leaf; s_end[slot][s][1] = old_link; s_end[slot][s][2] = w_l; s_end[slot][s][3] = old_d + 1; }
-            }
-            if (bo_ballot(over) != 0) { if (over && c == 0) bo_atomic_or(&e.status[FW_G(0)], ST_DEPTH_OVERFLOW); }
-            bo_wave_sync();  // lane 0's in-flight byte is read by the game's other lanes in later iterations
-        }
-#undef BO_FW_ISSUE_D
-#undef BO_FW_RED8
-#undef BO_FW_MIN8
-        // ---- 3c. what the finished descents mean for the row / simulation lists: once per launch, lane 0 of the game -----
-        {   // children scanned: the lanes' counts added up
-            int kk = kids_l;
-            kk += BO_ROW_XCHG(kk, 0); kk += BO_ROW_XCHG(kk, 1); kk += BO_ROW_XCHG(kk, 2);
-            kids_l = kk;
-        }
-        bo_wave_sync();
-        if (bz && c == 0) {
-            int nr = FW_C(0, FWC_NROWS);
-            for (int s = 0; s < nst; s++) {
-                const int leaf = s_end[slot][s][0], plink = s_end[slot][s][1], wl = s_end[slot][s][2], plen = s_end[slot][s][3];
-                int q;
-                if (wl == FW_MATE) q = FW_SIM_MATE;
-                else if (wl == FW_DRAW) q = FW_SIM_DRAW;
-                else {
-                    q = -1;
-                    for (int rr2 = nr - 1; rr2 >= 0; rr2--)
-                        if (FW_C(0, FWC_F(L, FWR_SLOT, rr2)) == leaf) q = rr2;  // a leaf another descent of this step already selected shares its row
-                    if (q < 0) {
-                        q = nr;
-                        FW_C(0, FWC_F(L, FWR_SLOT, q)) = leaf; FW_C(0, FWC_F(L, FWR_PLINK, q)) = plink; FW_C(0, FWC_F(L, FWR_SIM, q)) = s;
-                        nr = q + 1;
-                    }
-                }
-                FW_C(0, FWC_F(L, FWS_ROW, s)) = q; FW_C(0, FWC_F(L, FWS_PLEN, s)) = plen;
-            }
-            FW_C(0, FWC_NROWS) = nr; FW_C(0, FWC_NSTEP) = nst;
-            FW_ST(0, ST_LEVELS) = levels_l; FW_ST(0, ST_KIDS) = kids_l; FW_ST(0, ST_GRAN) = gran_l;
-        }
-        n_step[0] = nst;
-        bo_wave_sync();
-    } else {
     WRec r[UT][RPL];
     float sqt[UT];
     // request the run behind link[u] (unconditional loads from clamped addresses: a lane beyond the run re-reads its first record,
@@ -1003,7 +692,6 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
         }
     }
 #undef BO_FW_ISSUE
-    }
     if (e.c.profile) t_3 = bo_clock();
 
     // ---- a step of known-terminal hits only needs no evaluation: account for it now ---------------------------------------
@@ -1402,9 +1090,6 @@ BO_FW_SELECT_KERNEL(1, 64, 0, ) BO_FW_SELECT_KERNEL(1, 64, 3, )
         fw_select_body<8, 5, 1, LCAP, ((FL) & FW_SEL_NT) != 0, ((FL) & FW_SEL_ROOT_IN_REGS) != 0>(e, f, value, kind);   \
     }
 BO_FW_SELECT_OCT(4, 0) BO_FW_SELECT_OCT(4, 1) BO_FW_SELECT_OCT(4, 2) BO_FW_SELECT_OCT(4, 3)
-// eight lanes per game with the root levels of a step's descents scored in one pass (FW_SEL_OCT | FW_SEL_ROOTB)
-BO_KERNEL void bo_k_fw_select_r8l4(Eng e, FastW f, const float *value, int kind) { fw_select_body<8, 5, 1, 4, false, false, true>(e, f, value, kind); }
-BO_KERNEL void bo_k_fw_select_r8l8(Eng e, FastW f, const float *value, int kind) { fw_select_body<8, 5, 1, 8, false, false, true>(e, f, value, kind); }
 BO_FW_SELECT_OCT(8, 0) BO_FW_SELECT_OCT(8, 2)
 
 // ---- leaf: materialise the position of row r, its legal moves, is_game_over(claim_draw=True), its planes ------------------

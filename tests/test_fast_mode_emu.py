@@ -249,12 +249,6 @@ def check_multi(backend, L, sims, opts):
     (4, 60, dict(select_flags=8)),       # one lane per game
     (4, 80, dict(select_flags=9)),
     (4, 130, dict(select_flags=8)),
-    (4, 90, dict(select_flags=48)),      # eight lanes per game, the descents' root levels scored in one pass
-    (4, 130, dict(select_flags=48)),
-    (3, 60, dict(select_flags=48)),
-    (1, 30, dict(select_flags=48)),
-    (7, 84, dict(select_flags=48)),
-    (8, 96, dict(select_flags=48)),
     (4, 90, dict(select_flags=16)),      # eight lanes per game
     (4, 90, dict(select_flags=18)),
     (3, 60, dict(select_flags=17)),
