@@ -117,3 +117,35 @@ def test_lds_chunk_swizzle_of_the_fp16_pipe_towers_is_conflict_free():
                         assert len(quads) == 16, (C, t, tap, j)
         old = [(cell0(n) * ((C + 8) // 8)) % 16 for n in groups[0]]
         assert max(old.count(q) for q in old) == 3
+
+
+def test_split_precision_weight_packing_reconstructs_float32_and_follows_the_documented_layout():
+    """fused_net.pack_conv_weight_split (BO_TOWER_SPLIT_F16, include/betaone_engine.h): element (step, mt, hl, lane, i) of a layer is the
+    hi / lo fp16 half of s * W[32*mt + (lane & 31)][16*(step % (c_in/16)) + 8*(lane >> 5) + i][tap = step / (c_in/16)]; hi + lo gives
+    s * W back to 2^-22 relative (the lo half of any weight above 2^-18 of the largest is a normal fp16 number), s is a power of two
+    that puts the largest |s * W| in [2^14, 2^15)."""
+    import numpy as np
+    import torch
+    from betaone_amd.fused_net import pack_conv_weight_split, split_scale, split_f16
+
+    torch.manual_seed(3)
+    co, ci = 64, 32
+    w = torch.randn(co, ci, 3, 3) * 0.05
+    w[5, 7, 1, 2] = 0.0
+    s = split_scale(w)
+    assert s == 2.0 ** round(np.log2(s)) and 2.0 ** 14 <= float(w.abs().max()) * s < 2.0 ** 15
+    p = pack_conv_weight_split(w, s)
+    assert p.dtype == torch.float16 and tuple(p.shape) == (9, ci // 16, co // 32, 2, 2, 32, 8)
+    flat = p.reshape(9 * (ci // 16), co // 32, 2, 64, 8).double()  # [step][mt][hl][lane][i]
+    rs = np.random.RandomState(0)
+    for _ in range(200):
+        step, mt, lane, i = rs.randint(9 * (ci // 16)), rs.randint(co // 32), rs.randint(64), rs.randint(8)
+        oc, ic, tap = 32 * mt + (lane & 31), 16 * (step % (ci // 16)) + 8 * (lane >> 5) + i, step // (ci // 16)
+        want = float(w[oc, ic, tap // 3, tap % 3]) * s
+        got = float(flat[step, mt, 0, lane, i] + flat[step, mt, 1, lane, i])
+        assert abs(got - want) <= abs(want) * 2.0 ** -21 + 2.0 ** -24, (step, mt, lane, i)
+    x = torch.tensor([1.0, 1.0 + 2.0 ** -12, 3.14159265, -1234.567, 6.0e-5]).float().double()
+    hi, lo = split_f16(x)
+    back = hi.double() + lo.double()
+    assert bool(((back - x).abs() <= x.abs() * 2.0 ** -21 + 2.0 ** -24).all())
+    assert split_scale(torch.zeros(4, 4)) == 1.0
