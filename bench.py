@@ -644,6 +644,10 @@ def main():
             "games_finished_since_start": int(fin_all),
             "mean_plies_of_all_finished_games": (round(mean_len, 1) if mean_len else None),
             "games_per_hour_from_ply_rate": (round(plies / dt * 3600.0 / mean_len, 1) if mean_len else None),
+            # (a 20-ply window finishes a dozen games; the long-run figure of the same workload and where it was measured, for comparison)
+            "games_per_hour_long_run": ({"value": 795756, "plies_timed": 5000, "games_finished": 3847, "mean_plies": 330.8,
+                                         "source": "profiles/r03_logs/r4n_bench_5000.log (bench.py --steps 5000, this workload, one MI355X)"}
+                                        if (not args.fast and G == 256 and args.sims == 800 and args.net == "10x128" and args.net_dtype == "fp32" and world == 1) else None),
             "untimed_setup_seconds": round(t_pre, 2),
             "host_fraction": round(host_frac, 4),
         }
