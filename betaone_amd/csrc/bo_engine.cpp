@@ -21,6 +21,7 @@
 #include <stdio.h>
 #include <string>
 #include <vector>
+#include <algorithm>
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) {
@@ -1001,6 +1002,38 @@ extern "C" int bo_fast_options(bo_engine *e, int32_t tree_reuse, int32_t games_p
     if (games_per_halfwave >= 0) e->f.sel_ut = games_per_halfwave == 1 ? 2 : games_per_halfwave;  // (one game per half-wave is the form for more than 16 leaves per step)
     if (select_flags >= 0) e->f.sel_flags = select_flags & (FW_SEL_NT | FW_SEL_ROOT_IN_REGS | FW_SEL_DENSE | FW_SEL_LANE | FW_SEL_OCT);
     return BO_OK;
+}
+
+#if !defined(BO_WAVE_EMU)
+__global__ void bo_k_nothing() {}
+#endif
+extern "C" int bo_event_pair_overhead(double *ms_out, int32_t samples, void *stream) {
+    if (!ms_out || samples < 1 || samples > 256) return fail(BO_E_ARG, "bad arguments");
+#if defined(BO_WAVE_EMU)
+    (void)stream;
+    *ms_out = 0.0;
+    return BO_OK;
+#else
+    hipEvent_t e0, e1;
+    RT((int)hipEventCreate(&e0));
+    RT((int)hipEventCreate(&e1));
+    std::vector<float> v;
+    int rc = 0;
+    for (int i = 0; i < samples + 4 && !rc; i++) {  // (the first few launches load the code object and warm the queue)
+        rc = (int)hipEventRecord(e0, (hipStream_t)stream);
+        hipLaunchKernelGGL(bo_k_nothing, dim3(1), dim3(64), 0, (hipStream_t)stream);
+        if (!rc) rc = (int)hipEventRecord(e1, (hipStream_t)stream);
+        if (!rc) rc = (int)hipEventSynchronize(e1);
+        float ms = 0.0f;
+        if (!rc) rc = (int)hipEventElapsedTime(&ms, e0, e1);
+        if (!rc && i >= 4) v.push_back(ms);
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    RT(rc);
+    std::sort(v.begin(), v.end());
+    *ms_out = (double)v[v.size() / 2];
+    return BO_OK;
+#endif
 }
 
 extern "C" int bo_fast_stats(bo_engine *e, uint64_t *granules_read, uint64_t *path_nodes, int32_t *arena_granules, int32_t time_select, double *select_ms,

@@ -87,6 +87,7 @@ _SYMBOLS = {
     "bo_debug_tree": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BoNode), C.c_int32, _I32P, C.c_void_p]),
     "bo_debug_fast": (C.c_int, [C.c_void_p, C.c_int, _I32P, C.c_int32, _I32P, C.c_void_p]),
     "bo_fast_options": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "bo_event_pair_overhead": (C.c_int, [_F64P, C.c_int32, C.c_void_p]),
     "bo_fast_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _I32P, C.c_int32, _F64P, C.POINTER(C.c_int64),
                                C.c_void_p]),
     "bo_engine_status": (C.c_int, [C.c_void_p, _I32P, _I32P, _I32P, _I32P, _I32P, _I32P, C.c_void_p]),
@@ -424,6 +425,12 @@ class Engine:
         self._check(self.lib.bo_fast_stats(self.h, gran.ctypes.data_as(u64), pnodes.ctypes.data_as(u64), _p(top), time_select,
                                            C.byref(ms), C.byref(n), stream))
         return dict(granules_read=gran, path_nodes=pnodes, arena_granules=top, select_ms=ms.value, select_launches=n.value)
+
+    def event_pair_overhead_ms(self, samples: int = 32, stream: int = 0) -> float:
+        """What a HIP event pair around one kernel launch measures beyond the kernel (median over `samples` empty launches), in ms."""
+        ms = C.c_double(0.0)
+        self._check(self.lib.bo_event_pair_overhead(C.byref(ms), samples, stream))
+        return ms.value
 
     def status_bits(self, stream: int = 0) -> np.ndarray:
         """Only the per-slot status words (one small copy): 0 = fine, else a combination of STATUS_BITS."""
