@@ -336,8 +336,8 @@ def fast_select_roofline(ro, drv, steps, label=""):
                         f"launch's simulations in the same kernel; arenas of 128-byte granules, {m['arena_bytes'] / 1e9:.2f} GB live); "
                         f"bytes = 12 B x children scanned + 8 B x levels + 16 B x path nodes; the kernel requests whole 128-byte record granules",
             "launches_timed": m["launches"], "avg_launch_us": round(m["t"] * 1e6, 2),
-            "timing": f"HIP event pair around every launch ({m['t_raw'] * 1e6:.2f} us) minus the pair's own cost on an empty kernel on the same "
-                      f"stream ({m['overhead'] * 1e6:.2f} us, median of 32); rocprofv3 per-dispatch durations of the same command: profiles/r03_fast_select_rocprof.md",
+            "timing": f"HIP event pair around every launch ({m['t_raw'] * 1e6:.2f} us) minus the pair's own cost calibrated on empty kernels on the same "
+                      f"stream ({m['overhead'] * 1e6:.2f} us = 2 x pair(1 launch) - pair(2 launches), medians of 32); rocprofv3 per-dispatch durations of the same command: profiles/r03_fast_select_rocprof.md",
             "alg_bytes_per_launch": int(m["alg"]),
             "moved_bytes_per_launch": int(m["moved"]), "moved_over_algorithmic": round(m["moved"] / m["alg"], 3),
             "levels_per_launch": int(m["levels"]), "children_per_level": round(m["kids"] / max(1.0, m["levels"]), 2),

@@ -224,8 +224,9 @@ int bo_fast_options(bo_engine *e, int32_t tree_reuse, int32_t games_per_halfwave
  * these are the algorithmic bytes of SURVEY.md section 8d), granules in use in the game's arena. */
 int bo_fast_stats(bo_engine *e, uint64_t *granules_read, uint64_t *path_nodes, int32_t *arena_granules, int32_t time_select, double *select_ms,
                   int64_t *select_launches, void *stream);
-/* What a pair of HIP events around ONE kernel launch measures beyond the kernel itself on this device and stream: the median over
- * `samples` (1..256) pairs around an empty one-wave kernel, in milliseconds.  bench.py subtracts it from the event-timed launches of
+/* What a pair of HIP events around ONE kernel launch measures beyond the kernel itself on this device and stream: from the medians of
+ * `samples` (1..256) pairs around one and around two empty one-wave kernels (2 * p1 - p2: the second launch's own cost taken out), in
+ * milliseconds.  bench.py subtracts it from the event-timed launches of
  * the select + backup kernel (a ~60 us kernel: the pair's own ~6 us is 10 % of it) and checks the result against rocprofv3's
  * per-dispatch durations of the same command (profiles/).  Synchronises `stream`. */
 int bo_event_pair_overhead(double *ms_out, int32_t samples, void *stream);
