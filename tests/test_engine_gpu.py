@@ -351,6 +351,18 @@ def test_fast_mode_kernels_on_gpu_match_numpy_restatement(backend):
         assert int(st["evals"][0]) == ref.n_evals and int(st["term_sims"][0]) == ref.n_term_sims
 
 
+def test_event_pair_overhead_calibration_is_a_few_microseconds(backend):
+    """bo_event_pair_overhead: what a HIP event pair around one launch measures beyond the kernel -- positive, far below the ~60 us of
+    the kernel bench.py --fast corrects with it."""
+    import torch
+    eng = E.Engine(2, num_simulations=8, mcts_batch_size=8)
+    try:
+        ms = eng.event_pair_overhead_ms(16, torch.cuda.current_stream().cuda_stream)
+        assert 0.0 <= ms < 0.05, ms
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("L,ut", [(4, 4), (4, 2), (3, 4), (2, 2)])
 def test_fast_select_kernel_variants_on_gpu_match_restatement(backend, L, ut):
     """Every instantiation of the select + backup kernel (games per half-wave x {non-temporal loads, root run in registers,
