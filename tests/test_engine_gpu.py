@@ -232,6 +232,35 @@ def test_fused_epilogue_net_matches_plain_net(backend, size, conv):
         config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = saved
 
 
+@pytest.mark.parametrize("conv,size", [("tower_split", (2, 1, 128)), ("tower_split", (1, 1, 256)), ("tower_wg", (2, 1, 128)), ("tower", (2, 1, 64))])
+def test_tower_output_buffer_matches_the_plain_residual_tower(backend, conv, size):
+    """bo_nn_tower_forward with y_dev (the tower output [B, C, 8, 8], not only the fused head planes): == relu-tower of the plain net
+    within 1e-5, for fewer and more boards than CUs."""
+    import torch
+    import torch.nn.functional as F
+    from betaone_amd import dropin
+    dropin.install()
+    import config, network
+    from betaone_amd.fused_net import FusedPolicyValueNet
+    from fake_model import hash_init_
+
+    saved = (config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS)
+    config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = size
+    try:
+        net = hash_init_(network.PolicyValueNet().eval()).to("cuda:0")
+        fused = FusedPolicyValueNet(net, conv=conv).to("cuda:0")
+        z = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "g1_net.npz"))
+        base = torch.from_numpy(z["inputs"]).to("cuda:0")
+        for nb in (5, 300):
+            x = (base.repeat(nb // 3 + 1, 1, 1, 1)[:nb] * torch.linspace(0.5, 1.0, nb, device="cuda:0")[:, None, None, None]).contiguous()
+            with torch.no_grad():
+                want = net.residual_tower(F.relu(net.bn_input(net.conv_input(x))))
+                got = fused._tower_forward(x)
+            assert got.shape == want.shape and (got - want).abs().max().item() < 1e-5, (conv, size, nb)
+    finally:
+        config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = saved
+
+
 @pytest.mark.parametrize("size", [(2, 1, 128), (3, 2, 256)])
 def test_fp16_tower_matches_half_precision_net(backend, size):
     """csrc/bo_tower_h.h (fp16 weights/activations, fp32 accumulation, two boards per workgroup) against the same net in
@@ -355,6 +384,7 @@ def test_event_pair_overhead_calibration_is_a_few_microseconds(backend):
     """bo_event_pair_overhead: what a HIP event pair around one launch measures beyond the kernel -- positive, far below the ~60 us of
     the kernel bench.py --fast corrects with it."""
     import torch
+    from betaone_amd import engine as E
     eng = E.Engine(2, num_simulations=8, mcts_batch_size=8)
     try:
         ms = eng.event_pair_overhead_ms(16, torch.cuda.current_stream().cuda_stream)
