@@ -587,6 +587,7 @@ def main():
     sims, plies, fwd, fin_timed, fin_plies_timed, fin_all, fin_plies_all = [float(x) for x in mine]
     step_ms = np.diff(np.array([t0] + step_end)) * 1e3  # host-side period of each step on this rank (a step returns when its moves are played)
     ro.eng.check_status()
+    ro.check_net()
     host_frac = (ro.host_seconds - h0) / dt
 
     opening = None

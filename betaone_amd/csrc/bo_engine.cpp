@@ -1245,6 +1245,7 @@ struct bo_tower_s {
     bo_f32x4 *wts = nullptr;
     float *params = nullptr;
     bo_tower_layer *layers = nullptr;
+    int *overflow = nullptr;  // BO_TOWER_SPLIT_F16: an activation left the fp16 range
 };
 #else
 struct bo_tower_s { int unused; };
@@ -1311,11 +1312,13 @@ extern "C" int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layer
     int rc = (int)hipMalloc((void **)&t->wts, (size_t)n_weights * 4);
     if (!rc) rc = (int)hipMalloc((void **)&t->params, (size_t)n_params * 4);
     if (!rc) rc = (int)hipMalloc((void **)&t->layers, (size_t)n_layers * sizeof(bo_tower_layer));
+    if (!rc) rc = (int)hipMalloc((void **)&t->overflow, 4);
+    if (!rc) rc = (int)hipMemset(t->overflow, 0, 4);
     if (!rc) rc = (int)hipMemcpy(t->wts, weights, (size_t)n_weights * 4, hipMemcpyHostToDevice);
     if (!rc) rc = (int)hipMemcpy(t->params, params, (size_t)n_params * 4, hipMemcpyHostToDevice);
     if (!rc) rc = (int)hipMemcpy(t->layers, layers, (size_t)n_layers * sizeof(bo_tower_layer), hipMemcpyHostToDevice);
     if (rc) {
-        (void)hipFree(t->wts); (void)hipFree(t->params); (void)hipFree(t->layers);
+        (void)hipFree(t->wts); (void)hipFree(t->params); (void)hipFree(t->layers); (void)hipFree(t->overflow);
         delete t;
         return fail(BO_E_HIP, std::string("bo_nn_tower_create: ") + rt_errstr(rc));
     }
@@ -1357,7 +1360,7 @@ extern "C" int bo_nn_tower_forward(bo_tower *t, const float *x_dev, float *y_dev
     if (t->algo == BO_TOWER_SPLIT_F16) {  // float32 in and out, fp16 (hi, lo) pairs on the matrix pipe; one board per workgroup
         bo_tower_head_s hs;
         hs.channels = t->head_channels; hs.split = t->head_split; hs.w_off8 = t->head_w_off; hs.b_off = t->head_b_off;
-        hs.out_a = (float *)head_a_dev; hs.out_b = (float *)head_b_dev;
+        hs.out_a = (float *)head_a_dev; hs.out_b = (float *)head_b_dev; hs.overflow = t->overflow;
         const bo_h8 *w8 = reinterpret_cast<const bo_h8 *>(t->wts);
         if (t->channels == 256) hipLaunchKernelGGL((bo_k_tower_s<256, 2>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
         else  // (B operands read two K-steps ahead, weight fragments requested twelve ahead: profiles/r03_split_tower.md)
@@ -1381,9 +1384,22 @@ extern "C" int bo_nn_tower_forward(bo_tower *t, const float *x_dev, float *y_dev
 extern "C" void bo_nn_tower_destroy(bo_tower *t) {
 #if !defined(BO_WAVE_EMU)
     if (!t) return;
-    (void)hipFree(t->wts); (void)hipFree(t->params); (void)hipFree(t->layers);
+    (void)hipFree(t->wts); (void)hipFree(t->params); (void)hipFree(t->layers); (void)hipFree(t->overflow);
 #endif
     delete t;
+}
+
+extern "C" int bo_nn_tower_status(bo_tower *t, int32_t *overflow_out, void *stream) {
+#if defined(BO_WAVE_EMU)
+    (void)t; (void)overflow_out; (void)stream;
+    return fail(BO_E_CONFIG, "bo_nn_tower is a gfx950-only kernel");
+#else
+    if (!t || !overflow_out) return fail(BO_E_ARG, "bad arguments");
+    RT(rt_d2h(overflow_out, t->overflow, 4, stream));
+    RT(rt_sync(stream));
+    if (*overflow_out) { RT((int)hipMemsetAsync(t->overflow, 0, 4, (hipStream_t)stream)); RT(rt_sync(stream)); }
+    return BO_OK;
+#endif
 }
 
 // ---- policy FC + softmax + value head behind the tower: two launches (bo_heads.h) ------------------------------------

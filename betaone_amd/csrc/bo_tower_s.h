@@ -29,6 +29,7 @@
 struct bo_tower_head_s {
     int channels = 0, split = 0, w_off8 = 0, b_off = 0;  // head weights: [mt][step C/16][hi|lo][lane][8 fp16] at bo_h8 offset w_off8 in wts;
     float *out_a = nullptr, *out_b = nullptr;            // params[b_off + channels] = their inverse scale
+    int *overflow = nullptr;                              // set to 1 when an activation had to be saturated to the fp16 range (the result is then wrong)
 };
 
 // hi / lo halves of 4 float32 values (saturating: |v| beyond the fp16 range would turn into inf - inf)
@@ -41,11 +42,12 @@ __device__ inline void bo_split4(const float (&v)[4], bo_h4 &hi, bo_h4 &lo) {
     }
 }
 
-// the same for values that are >= 0 already (behind a ReLU)
-__device__ inline void bo_split4_pos(const float (&v)[4], bo_h4 &hi, bo_h4 &lo) {
+// the same for values that are >= 0 already (behind a ReLU); `sat` collects whether anything was cut
+__device__ inline void bo_split4_pos(const float (&v)[4], bo_h4 &hi, bo_h4 &lo, bool &sat) {
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         const float c = fminf(v[e], 65504.0f);
+        sat = sat || !(v[e] <= 65504.0f);  // (also a NaN)
         hi[e] = (_Float16)c;
         lo[e] = (_Float16)__builtin_fmaf((float)hi[e], -1.0f, c);  // = c - hi, one rounding (v_fma_mix: the fp16 operand is widened on read)
     }
@@ -223,6 +225,7 @@ bo_k_tower_s(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
             auto write_back = [&](auto kind_c, auto y_c) {
                 constexpr int KIND = decltype(kind_c)::value;
                 constexpr bool TO_Y = decltype(y_c)::value;
+                bool sat = false;
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -242,7 +245,7 @@ bo_k_tower_s(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
                                 if (KIND != 1) skip[mt][t][r] = o[e];
                             }
                             bo_h4 hi, lo;
-                            bo_split4_pos(o, hi, lo);
+                            bo_split4_pos(o, hi, lo, sat);
                             *reinterpret_cast<bo_h4 *>(cellp) = hi;
                             *reinterpret_cast<bo_h4 *>(cellp + IMGH) = lo;
                             if (TO_Y) {
@@ -252,6 +255,9 @@ bo_k_tower_s(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
                             }
                         }
                     }
+                // an activation beyond the fp16 range cannot be carried as a (hi, lo) pair: the tower's result is wrong from here on --
+                // say so (bo_nn_tower_status) instead of returning it silently; such a net needs the fp32-pipe tower
+                if (__ballot(sat) != 0ull && lane == 0 && head.overflow) atomicOr(head.overflow, 1);
             };
             using std::integral_constant;
             if (LAB >= 4) {

@@ -88,6 +88,7 @@ _SYMBOLS = {
     "bo_debug_fast": (C.c_int, [C.c_void_p, C.c_int, _I32P, C.c_int32, _I32P, C.c_void_p]),
     "bo_fast_options": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "bo_event_pair_overhead": (C.c_int, [_F64P, C.c_int32, C.c_void_p]),
+    "bo_nn_tower_status": (C.c_int, [C.c_void_p, _I32P, C.c_void_p]),
     "bo_fast_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _I32P, C.c_int32, _F64P, C.POINTER(C.c_int64),
                                C.c_void_p]),
     "bo_engine_status": (C.c_int, [C.c_void_p, _I32P, _I32P, _I32P, _I32P, _I32P, _I32P, C.c_void_p]),

@@ -427,6 +427,20 @@ class FusedPolicyValueNet(nn.Module):
         except Exception:  # interpreter shutdown
             pass
 
+    def check_overflow(self):
+        """conv='tower_split' carries activations as fp16 pairs: raise if any forward since the last check had to saturate one (its
+        outputs were wrong) -- bo_nn_tower_status.  Synchronises; callers check at game / run boundaries, not per forward."""
+        t = self.__dict__.get("_tower")
+        if not t or self.conv != "tower_split":
+            return
+        flag = C.c_int32(0)
+        rc = self.lib.bo_nn_tower_status(t, C.byref(flag), torch.cuda.current_stream(self._tower_dev).cuda_stream)
+        if rc:
+            raise E.EngineError(self.lib.bo_last_error().decode())
+        if flag.value:
+            raise E.EngineError("tower_split: an activation left the fp16 range (|v| > 65504) and was saturated -- the evaluations of this net are "
+                                "wrong on the fp16 matrix pipe; run it with BETAONE_F32_TOWER=fp32 (best_inference_copy(..., f32_pipe=True))")
+
     def _tower_forward(self, x, heads=False):
         """Tower output [B, C, 8, 8]; with heads=True (conv='tower_wg') the ReLU'd policy / value planes, flattened."""
         if x.device != self._tower_dev or x.dtype != torch.float32 or x.shape[1:] != (120, 8, 8):

@@ -479,6 +479,8 @@ class Rollout:
         return n_moves
 
     def _finish_and_refill(self, done, term, on_finished, refill) -> None:
+        if done:
+            self.check_net()  # (finished games' records are about to be handed over: not from a net that had to saturate an activation)
         new_slots, ids, seeds, fens = [], [], [], []
         for g in done:
             fin = self._finish(g, int(term[g]))
@@ -549,7 +551,16 @@ class Rollout:
         self._graphs_n = {}
         self._logits = self._value = None
 
+    def check_net(self):
+        """Raise if the evaluate stage reports a fault of its own (the split-precision tower: an activation beyond the fp16 range)."""
+        chk = getattr(getattr(self.model, "net", self.model), "check_overflow", None)
+        if chk is not None:
+            chk()
+
     def close(self):
         self._graph = self._fgraph = None
         self._graphs_n = {}
-        self.eng.close()
+        try:
+            self.check_net()
+        finally:
+            self.eng.close()

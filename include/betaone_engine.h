@@ -359,6 +359,10 @@ int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layers, const fl
 int bo_nn_tower_forward(bo_tower *tower, const float *x_dev, float *y_dev, void *head_a_dev, void *head_b_dev, int batch, void *stream);
 int bo_nn_value_tail(const float *h_dev, const float *w_dev, const float *bias_dev, float *out_dev, int batch, int hidden, void *stream);
 void bo_nn_tower_destroy(bo_tower *tower);
+/* BO_TOWER_SPLIT_F16 carries every activation as a pair of fp16 numbers: a value beyond +-65504 is saturated and the forward's result
+ * is wrong.  *overflow_out = 1 if that happened in any forward since the last call (the flag is cleared), 0 otherwise (always 0 for
+ * the other algorithms).  Synchronises `stream`.  A net that trips it needs the fp32-pipe tower (BETAONE_F32_TOWER=fp32). */
+int bo_nn_tower_status(bo_tower *tower, int32_t *overflow_out, void *stream);
 
 #ifdef __cplusplus
 }

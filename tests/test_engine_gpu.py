@@ -261,6 +261,39 @@ def test_tower_output_buffer_matches_the_plain_residual_tower(backend, conv, siz
         config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = saved
 
 
+def test_split_precision_tower_reports_activations_beyond_the_fp16_range(backend):
+    """conv='tower_split' carries activations as (hi, lo) fp16 pairs: a net whose activations exceed 65504 cannot run on it -- the
+    kernel saturates, sets a flag (bo_nn_tower_status) and FusedPolicyValueNet.check_overflow raises instead of handing out wrong
+    evaluations; an ordinary net never trips it and the flag clears."""
+    import torch
+    from betaone_amd import dropin, engine as E
+    dropin.install()
+    import config, network
+    from betaone_amd.fused_net import FusedPolicyValueNet
+    from fake_model import hash_init_
+
+    saved = (config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS)
+    config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 2, 1, 128
+    try:
+        net = hash_init_(network.PolicyValueNet().eval()).to("cuda:0")
+        z = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "g1_net.npz"))
+        x = torch.from_numpy(z["inputs"]).to("cuda:0").repeat(4, 1, 1, 1).contiguous()
+        ok = FusedPolicyValueNet(net, conv="tower_split").to("cuda:0")
+        with torch.no_grad():
+            ok(x)
+        ok.check_overflow()  # nothing to report
+        with torch.no_grad():
+            net.conv_input.weight.mul_(3.0e5)  # activations of the first layer ~1e5
+        big = FusedPolicyValueNet(net, conv="tower_split").to("cuda:0")
+        with torch.no_grad():
+            big(x)
+        with pytest.raises(E.EngineError, match="fp16 range"):
+            big.check_overflow()
+        big.check_overflow()  # the flag was cleared by the report
+    finally:
+        config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = saved
+
+
 @pytest.mark.parametrize("size", [(2, 1, 128), (3, 2, 256)])
 def test_fp16_tower_matches_half_precision_net(backend, size):
     """csrc/bo_tower_h.h (fp16 weights/activations, fp32 accumulation, two boards per workgroup) against the same net in
