@@ -145,6 +145,7 @@ class Rollout:
         self._fgraph = None
         self._side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None  # finished games' hand-over beside the search
         self._noise_pending = False
+        self._fwd_early = False  # the next ply's root evaluation has been enqueued already (behind bo_selfplay_turn)
         self._begun = None          # (n_legal, terminal, go) of searches already begun by the previous selfplay_turn
         self._begun_want = None
         self._active = np.zeros(G, dtype=bool)
@@ -362,8 +363,11 @@ class Rollout:
         info = None
         if self._noise_pending:  # root evaluation: forward | host draws the noise meanwhile | upload | apply
             self._noise_pending = False
-            self.n_forward += 1
-            self._forward_only()
+            if self._fwd_early:  # enqueued by the previous turn, before its host-side bookkeeping
+                self._fwd_early = False
+            else:
+                self.n_forward += 1
+                self._forward_only()
             if self._begun is E.LAZY_BEGIN:  # the roots' state, now that the device has its next 0.4 ms of work
                 info = self.eng.selfplay_begun()
                 self._begun = None
@@ -393,6 +397,7 @@ class Rollout:
             if self._begun is E.LAZY_BEGIN and not extra.any():
                 lazy = True  # ... without waiting for the device: their roots' state arrives with the first evaluation below
             else:
+                self._fwd_early = False  # (games started in between: their roots are not in the forward enqueued early -- it is repeated)
                 nl, term, go = eng.selfplay_begun() if self._begun is E.LAZY_BEGIN else self._begun
                 self._begun = None
                 if extra.any():  # games started in between
@@ -451,6 +456,12 @@ class Rollout:
             eng.play(actions, stream)
         else:
             self._begun, self._begun_want, self._noise_pending = begun, want_next.copy(), not self.fast
+            if begun is E.LAZY_BEGIN and self._noise_pending and want_next.any():
+                # the next searches' roots are on their way (begun without a host round trip): their evaluation follows at once, so the
+                # device does not idle through this call's bookkeeping and the caller's time between two plies (~70 us per ply)
+                self.n_forward += 1
+                self._forward_only()
+                self._fwd_early = True
         k = max(1, int(out["n"].max()))
         # (keyed by step WITH the mask of the games that searched: a slot refilled inside a ply sits that ply out, so its new
         # game's first pi belongs to the next step -- the row of this step is still its previous occupant's)
@@ -550,6 +561,7 @@ class Rollout:
         self._graph = self._fgraph = None
         self._graphs_n = {}
         self._logits = self._value = None
+        self._fwd_early = False  # (a root evaluation enqueued early ran the old weights: it is repeated with the new ones)
 
     def check_net(self):
         """Raise if the evaluate stage reports a fault of its own (the split-precision tower: an activation beyond the fp16 range)."""
