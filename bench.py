@@ -588,6 +588,17 @@ def main():
     step_ms = np.diff(np.array([t0] + step_end)) * 1e3  # host-side period of each step on this rank (a step returns when its moves are played)
     ro.eng.check_status()
     ro.check_net()
+    if getattr(ro, "ply_profile", None):  # BO_PLY_PROFILE=1: host seconds per phase of the native ply path over the whole run
+        import collections
+        if os.environ.get("BO_PLY_PROFILE", "0") not in ("", "0", "1"):  # a path: the raw list
+            json.dump([[n, round(sec * 1e6, 1)] for n, sec in ro.ply_profile], open(os.environ["BO_PLY_PROFILE"], "w"))
+        acc = collections.defaultdict(list)
+        for name, sec in ro.ply_profile:
+            acc[name].append(sec * 1e6)
+        for name, v in acc.items():
+            v.sort()
+            print("[ply profile] %-18s n %5d  p50 %8.1f  p90 %8.1f  p99 %8.1f  max %8.1f us" % (name, len(v), v[len(v) // 2], v[int(len(v) * 0.9)], v[int(len(v) * 0.99)], v[-1]),
+                  file=sys.stderr, flush=True)
     host_frac = (ro.host_seconds - h0) / dt
 
     opening = None

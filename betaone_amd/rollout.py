@@ -146,6 +146,9 @@ class Rollout:
         self._side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None  # finished games' hand-over beside the search
         self._noise_pending = False
         self._fwd_early = False  # the next ply's root evaluation has been enqueued already (behind bo_selfplay_turn)
+        import os as _os
+        self.ply_profile = [] if _os.environ.get("BO_PLY_PROFILE", "0") not in ("", "0") else None  # [(phase, seconds)] of the native ply path
+        self._t_ret = None
         self._begun = None          # (n_legal, terminal, go) of searches already begun by the previous selfplay_turn
         self._begun_want = None
         self._active = np.zeros(G, dtype=bool)
@@ -356,6 +359,11 @@ class Rollout:
             self._fgraph, self._f_logits, self._f_value = g, logits, value
         self._fgraph.replay()
 
+    def _pp(self, name):
+        now = time.perf_counter()
+        self.ply_profile.append((name, now - self._pp_t))
+        self._pp_t = now
+
     def _run_search_steps(self, poll: bool = True):
         """The evaluate -> step iterations of one search per game.  Returns the (n_legal, terminal, go) of searches that the
         previous turn began without waiting for the device (engine.LAZY_BEGIN), else None."""
@@ -371,7 +379,9 @@ class Rollout:
             if self._begun is E.LAZY_BEGIN:  # the roots' state, now that the device has its next 0.4 ms of work
                 info = self.eng.selfplay_begun()
                 self._begun = None
+            if self.ply_profile is not None: self._pp("begun")
             self.eng.selfplay_noise(self._stream())
+            if self.ply_profile is not None: self._pp("noise")
             self.eng.step(self._f_logits.data_ptr(), self._f_value.data_ptr(), self.policy_kind, self.nn_in.data_ptr(), self._stream())
             burst -= 1
         while True:
@@ -388,6 +398,10 @@ class Rollout:
         eng, G = self.eng, self.G
         stream = self._stream()
         t0 = time.perf_counter()
+        if self.ply_profile is not None:
+            if self._t_ret is not None:
+                self.ply_profile.append(("between_calls", t0 - self._t_ret))
+            self._pp_t = t0
         want = self._active & (self._plies < self.max_game_moves)
         limit_done = np.nonzero(self._active & ~want)[0]
         self.host_seconds += time.perf_counter() - t0
@@ -412,6 +426,7 @@ class Rollout:
         # idle GPU during ~0.3 ms of host work in every ply in which a game ends.)
         if lazy:
             nl, term, go = self._run_search_steps(poll=False)
+        if self.ply_profile is not None: self._pp("enqueue_search")
         done = [int(g) for g in limit_done] + [int(g) for g in np.nonzero(want & (term != 0))[0]]
         for g in done:
             self._active[g] = False
@@ -428,8 +443,10 @@ class Rollout:
                     self._finish_and_refill(done, term, on_finished, refill)
             else:
                 self._finish_and_refill(done, term, on_finished, refill)
+        if self.ply_profile is not None: self._pp("finish_and_refill")
         if while_searching is not None:
             while_searching()
+        if self.ply_profile is not None: self._pp("while_searching")
         self.n_sims += int(np.count_nonzero(go)) * self.S
         t0 = time.perf_counter()
         move_number = self._start_full + (self._plies + self._start_black) // 2   # board.fullmove_number, self_play.py:104
@@ -443,6 +460,7 @@ class Rollout:
             if out is not None:
                 break
             self._eval_and_step()  # a search needed one more evaluation than expected
+        if self.ply_profile is not None: self._pp("turn")
         t0 = time.perf_counter()
         actions = out["action"]
         if begun is None:  # rare: a pi not sparse enough for the native sampler -- nothing was played
@@ -462,6 +480,7 @@ class Rollout:
                 self.n_forward += 1
                 self._forward_only()
                 self._fwd_early = True
+                if self.ply_profile is not None: self._pp("early_forward")
         k = max(1, int(out["n"].max()))
         # (keyed by step WITH the mask of the games that searched: a slot refilled inside a ply sits that ply out, so its new
         # game's first pi belongs to the next step -- the row of this step is still its previous occupant's)
@@ -487,6 +506,9 @@ class Rollout:
         self.host_seconds += time.perf_counter() - t0
         n_moves = int(np.count_nonzero(go))
         self.n_plies += n_moves
+        if self.ply_profile is not None:
+            self._pp("bookkeeping")
+            self._t_ret = time.perf_counter()
         return n_moves
 
     def _finish_and_refill(self, done, term, on_finished, refill) -> None:
