@@ -217,6 +217,7 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
     c.use_noise = cfg->dirichlet_alpha > 0 ? 1 : 0;
     c.root_m = root_m;
     c.profile = 0;
+    { const char *v = getenv("BETAONE_BURST_TWO_PATHS"); c.burst_two = (v && v[0] == '0') ? 0 : 1; }
     const size_t G = (size_t)c.G, N = G * (size_t)c.NCAP;
     Eng &d = e->d;
     int rc = 0;

@@ -50,6 +50,7 @@ struct EngCfg {
     int use_noise;               // DIRICHLET_ALPHA > 0
     int root_m;                  // children admitted by one root expand call: int(WIDEN*sqrt(1))
     int profile;                 // bo_debug_profile: accumulate per-phase shader cycles (s_memtime) per game
+    int burst_two;               // terminal_burst keeps the previous burst's path in a second register set (0: off -- BETAONE_BURST_TWO_PATHS=0, for A/B tests)
 };
 
 struct Eng {
@@ -410,9 +411,24 @@ BO_DEV float bo_div_count(float x, float fn, float y) {
     else if (!(a >= 1e-30f && a <= 1e30f)) q = bo_div_general(x, fn);  // (never taken in a search: |quotient| in [1e-30, 1e30])
     return q;
 }
-BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, int sims_left, float *lds, bool *staged) {
+// TWO paths: terminal simulations often ALTERNATE between two leaves under different children of an upper node (two mating
+// lines; a mate and a claimable draw).  With one path in registers every such switch ended the burst after ~2 simulations
+// and cost a descent from memory plus a burst set-up (48 of each per launch: the step kernel's p99).  `pb` / `db` / `vb`, when
+// db > 0, is the path of the PREVIOUS burst of this launch: its children are held in a second register set below the level
+// where the two paths part (the levels above are the same nodes: one set), and when the node at that level turns from one
+// path's child to the other's -- and the other path's deeper levels still choose what they chose -- the sets are swapped and
+// the loop goes on.  Everything a simulation does to the statistics is the same operation in the same order as before.
+BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, int sims_left, float *lds, bool *staged,
+                          const int *pb = nullptr, int db = 0, float vb = 0.0f, int *n_swaps = nullptr) {
     const size_t no = NOFF(e, g);
     const int lane = bo_lane(), grp = lane >> 4, j = lane & 15;
+    // common nodes of the two paths: path[0 .. c-1] == pb[0 .. c-1]; they part at level c - 1 (the children of path[c - 1])
+    int c = 0;
+    if (db > 0) {
+        while (c <= d && c <= db && path[c] == pb[c]) c++;
+        if (!(c >= 1 && c <= d - 1 && c <= db - 1)) db = 0;  // identical, or parting at a last level (the sibling logic's case): one path
+    }
+    const bool two = db > 0;
     int nv[BO_BURST_LEVELS + 1];  // uniform copies of the path nodes' visit counts
     int fc[BO_BURST_LEVELS], ncs[BO_BURST_LEVELS], chosen[BO_BURST_LEVELS];
 #pragma unroll
@@ -427,14 +443,31 @@ BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, 
 #pragma unroll
     for (int k = 0; k < BO_BURST_LEVELS; k++)
         if (grp == k) { my_fc = fc[k]; my_nc = ncs[k]; my_chosen = chosen[k]; }
-    const bool have = grp < d && j < my_nc;
+    bool have = grp < d && j < my_nc;
     const bool last = grp == d - 1;  // the level whose children are leaves of the current path
     int cn = have ? e.n_visits[no + my_fc + j] : 0;
     float cq = have ? e.q[no + my_fc + j] : 0.0f;
     const float cp = have ? e.prior[no + my_fc + j] : 0.0f;
     // at the last level any child that is ALREADY KNOWN to be a terminal leaf may take the next simulation
-    const int cterm = (have && last && e.n_children[no + my_fc + j] == 0) ? (int)e.term[no + my_fc + j] : -1;
-    float v_cur = v;
+    int cterm = (have && last && e.n_children[no + my_fc + j] == 0) ? (int)e.term[no + my_fc + j] : -1;
+    // the other path's register set: levels >= c (its own nodes); its chosen child also at level c - 1 (same node, other child)
+    int b_fc = 0, b_nc = 0, b_chosen = -1, b_cn = 0, b_cterm = -1, b_pv = 0;
+    float b_cq = 0.0f, b_cp = 0.0f;
+    bool b_have = false;
+    if (two) {
+        if (grp < db) {
+            b_fc = e.first_child[no + pb[grp]]; b_nc = e.n_children[no + pb[grp]];
+            b_chosen = pb[grp + 1] - b_fc;
+        }
+        b_have = grp >= c && grp < db && j < b_nc;
+        b_cn = b_have ? e.n_visits[no + b_fc + j] : 0;
+        b_cq = b_have ? e.q[no + b_fc + j] : 0.0f;
+        b_cp = b_have ? e.prior[no + b_fc + j] : 0.0f;
+        b_cterm = (b_have && grp == db - 1 && e.n_children[no + b_fc + j] == 0) ? (int)e.term[no + b_fc + j] : -1;
+        b_pv = grp >= 1 && grp <= db ? e.n_visits[no + pb[grp - 1]] : 0;  // (used by levels > c only: up to level c the parent-side node is common)
+    }
+    float v_cur = v, v_oth = vb;
+    int d_oth = db;
     int done = 0;
     // Per simulated visit the loop needs sqrt(parent visits) of every level and the reciprocal of the visited child's new
     // count.  Both tables (S + 2 and S + 3 floats) are staged in LDS once per launch by all lanes (one memory round trip);
@@ -453,13 +486,16 @@ BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, 
 #pragma unroll
     for (int k = 1; k < BO_BURST_LEVELS; k++)
         if (grp == k) pvl = nv[k - 1];
-    const float t1 = e.c.cpuct * cp;
+    float t1 = e.c.cpuct * cp, b_t1 = e.c.cpuct * b_cp;
     float y1 = BO_RC(1 + cn);  // RN(1 / (1 + cn)): the divisor of this child's exploration term
-    const uint64_t last_bits = d > 0 ? (0xFFFFull << (16 * (d - 1))) : 0ull;
-    int it = 0;
+    float b_y1 = BO_RC(1 + b_cn);
+    uint64_t last_bits = d > 0 ? (0xFFFFull << (16 * (d - 1))) : 0ull;
+    bool last_l = last;
+    int pv = pvl;  // parent-side visits of this lane's level on the CURRENT path; + 1 per simulation through it
     for (;;) {
-        it++;
-        const float sp = BO_SQ(pvl + it);
+        pv += 1;
+        // (levels <= c: the parent-side node is common to both paths and `pv` counts for both; deeper levels keep one count per path)
+        const float sp = BO_SQ(pv);
         // ---- apply one terminal simulation (MCTSNode.update along the path, mcts.py:120-144) ----
         if (have && j == my_chosen) {
             const float val = ((d - (grp + 1)) & 1) ? -v_cur : v_cur;  // the leaf sees v, its parent -v, ...
@@ -490,7 +526,62 @@ BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, 
         const bool beat = have && (score > cs || (score == cs && j < my_chosen));
         const bool dead = grp < d && j == 0 && !(cs > -__builtin_inff());  // the chosen child's own score is NaN
         const uint64_t mb = bo_ballot(beat), md = bo_ballot(dead);
-        if (md != 0 || (mb & ~last_bits) != 0) break;  // an upper level turns elsewhere: the next descent needs the general loop
+        if (md != 0) break;
+        if ((mb & ~last_bits) != 0) {
+            // an upper level turns elsewhere.  With the other path in registers: is it the level where the two part, does it turn
+            // to the other path's child, and does the other path from there on still choose what it chose?
+            if (!two) break;  // the next descent needs the general loop
+            const uint64_t upper = mb & ~last_bits;
+            const int kb = (int)(__builtin_ctzll(upper) >> 4);  // lowest level that turns
+            if (kb != c - 1) break;
+            int bi = j;
+            float bs = score;
+#define BO_BURST_STEP(kind)                                                                          \
+            {                                                                                        \
+                const float os = __builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, bs), kind)); \
+                const int oi = BO_ROW_XCHG(bi, kind);                                                \
+                if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }                          \
+            }
+            BO_BURST_STEP(0) BO_BURST_STEP(1) BO_BURST_STEP(2) BO_BURST_STEP(3)
+#undef BO_BURST_STEP
+            const int nb = bo_readlane(bi, 16 * (c - 1));            // the child level c - 1 now chooses
+            const int ob = bo_readlane(b_chosen, 16 * (c - 1));      // the other path's child there
+            if (nb != ob) break;
+            // the other path below: every level must still choose its recorded child (its statistics are as it left them; the
+            // parent-side count of level c is the common node's: `pv`)
+            float bscore = -__builtin_inff();
+            if (b_have) {
+                const float spb = BO_SQ(grp == c ? pv : b_pv);
+                const float t2 = b_t1 * spb;
+                float qv = 0.0f, u = t2;
+                if (b_cn > 0) { qv = b_cq; u = bo_div_count(t2, (float)(1 + b_cn), b_y1); }
+                bscore = qv + u;
+                if (!(bscore == bscore)) bscore = -__builtin_inff();
+            }
+            const float bcs = bo_shfl_f(bscore, (lane & 48) | (b_chosen & 15));
+            const bool bbeat = b_have && (bscore > bcs || (bscore == bcs && j < b_chosen));
+            const bool bdead = grp >= c && grp < d_oth && j == 0 && !(bcs > -__builtin_inff());
+            if (bo_ballot(bbeat) != 0 || bo_ballot(bdead) != 0) break;
+            // ---- swap the register sets: the other path is the current one from here on ----
+            if (grp >= c) {
+                { const int t_ = cn; cn = b_cn; b_cn = t_; }
+                { const float t_ = cq; cq = b_cq; b_cq = t_; }
+                { const float t_ = t1; t1 = b_t1; b_t1 = t_; }
+                { const float t_ = y1; y1 = b_y1; b_y1 = t_; }
+                { const bool t_ = have; have = b_have; b_have = t_; }
+                { const int t_ = cterm; cterm = b_cterm; b_cterm = t_; }
+                { const int t_ = my_fc; my_fc = b_fc; b_fc = t_; }
+                { const int t_ = my_nc; my_nc = b_nc; b_nc = t_; }
+            }
+            if (grp > c) { const int t_ = pv; pv = b_pv; b_pv = t_; }
+            if (grp >= c - 1) { const int t_ = my_chosen; my_chosen = b_chosen; b_chosen = t_; }
+            { const int t_ = d; d = d_oth; d_oth = t_; }
+            { const float t_ = v_cur; v_cur = v_oth; v_oth = t_; }
+            last_l = grp == d - 1;
+            last_bits = 0xFFFFull << (16 * (d - 1));
+            if (n_swaps) *n_swaps += 1;
+            continue;
+        }
         if ((mb & last_bits) != 0) {  // the last level moves to a sibling: fine if that one is a known terminal leaf too
             int bi = j;
             float bs = score;
@@ -510,14 +601,15 @@ BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, 
             const int src = 16 * (d - 1);  // lane 0 of the last level's group holds its argmax
             const int nb = bo_readlane(bi, src), nt = bo_readlane(bterm, src);
             if (!(nt > 0)) break;
-            if (last) my_chosen = nb;
+            if (last_l) my_chosen = nb;
             v_cur = nt == 1 ? 1.0f : 0.0f;
         }
     }
 #undef BO_SQ
 #undef BO_RC
-    // ---- write the path back ----
+    // ---- write the path(s) back ----
     if (have) { e.n_visits[no + my_fc + j] = cn; e.q[no + my_fc + j] = cq; }
+    if (two && b_have) { e.n_visits[no + b_fc + j] = b_cn; e.q[no + b_fc + j] = b_cq; }
     if (lane == 0) e.n_visits[no] = nv[0];
     bo_sync();
     return done;
@@ -638,6 +730,7 @@ struct StepShared {
     float pv[BO_MAX_MOVES];
     int path[BO_PATH_CAP];
     int path2[BO_PATH_CAP];  // scratch of parent-link walks (path keeps the last descent)
+    int bpath[8];            // the path of the launch's previous terminal burst (terminal_burst's second path)
     float probs[BO_NUM_ACTIONS];
     int rank_of[2 * BO_CH_CAP];
     ChainBuf chain;
@@ -777,7 +870,7 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
 
     const bool prof = e.c.profile != 0;
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int n_iter = 0, n_first = 0, n_burst = 0, n_burst_sims = 0, n_general = 0;
+    int n_iter = 0, n_first = 0, n_burst = 0, n_burst_sims = 0, n_general = 0, n_swaps = 0;
     unsigned long long tk = prof ? bo_clock() : 0ull;
     const unsigned long long t_start = tk;
 #define BO_PROF(slot)                                                    \
@@ -799,6 +892,8 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
     // evaluated and ignored) and carries on in the next launch.  Results are unchanged (the same operations in the same
     // order), and the search needs no more launches than one that spends those simulations on a batch of 96 rows would.
     int term_budget = e.c.B;
+    int b_depth = 0;      // depth of sh.bpath (0: none)
+    float b_tv = 0.0f;    // its leaf's terminal value
     int path_leaf = -1, path_depth = -1;  // the leaf whose descent sh.path holds (none yet in this launch)
     for (;;) {
         if (sims >= e.c.S) {  // mcts.py:256-257
@@ -834,7 +929,16 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
             for (int k = 0; k < depth && small; k++) small = e.n_children[no + sh.path[k]] <= 16;
             BO_PROF(6)
             const int may = e.c.S - sims < term_budget ? e.c.S - sims : term_budget;
-            if (small) { applied = terminal_burst(e, g, sh.path, depth, tv, may, sh.probs, &burst_tables_staged); n_burst++; n_burst_sims += applied; }
+            if (small) {
+                bool small_b = b_depth > 0 && e.c.burst_two != 0;  // the previous burst's path may ride along if it still fits the registers
+                for (int k = 0; k < b_depth && small_b; k++) small_b = e.n_children[no + sh.bpath[k]] <= 16;
+                applied = terminal_burst(e, g, sh.path, depth, tv, may, sh.probs, &burst_tables_staged, sh.bpath, small_b ? b_depth : 0, b_tv, &n_swaps);
+                n_burst++; n_burst_sims += applied;
+                bo_sync();
+                if (lane <= depth) sh.bpath[lane] = sh.path[lane];
+                b_depth = depth; b_tv = tv;
+                bo_sync();
+            }
             else { backup_run(e, g, leaf, tv, 1, sh.path2, &flags, sh.path, depth); n_general++; }  // deep or wide path: one simulation the general way
             BO_PROF(7)
             sims += applied;
@@ -869,7 +973,7 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
         if (e.c.profile == 1 || total > (unsigned long long)e.c.profile) {
             unsigned long long *pp = e.prof + (size_t)g * BO_PROF_SLOTS;
             pp[10] += (unsigned long long)n_burst; pp[11] += (unsigned long long)n_burst_sims; pp[12] += (unsigned long long)n_general;
-            pp[13] += pc[6]; pp[14] += pc[7];
+            pp[13] += pc[6]; pp[14] += pc[7]; pp[15] += (unsigned long long)n_swaps;
             for (int i = 0; i < 6; i++) pp[i] += pc[i];
             pp[6] += total;
             pp[7] += 1;

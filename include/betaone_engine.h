@@ -249,7 +249,7 @@ int bo_engine_status(bo_engine *e, int32_t *status, int32_t *evals, int32_t *flu
  *   [0] apply, [1] select, [2] first visit (move generation + draw rules), [3] terminal backups, [4] leaf encode, [5] flush,
  *   [6] total, [7] game-steps counted, [8] simulation-loop iterations, [9] first visits, [10] terminal-burst calls,
  *   [11] simulations applied inside bursts, [12] terminal simulations on the general path, [13] cycles in burst set-up,
- *   [14] cycles in the burst loop, [15] reserved (0).
+ *   [14] cycles in the burst loop, [15] switches between the two paths a burst holds in registers.
  * enable: 1 = every game-step, N > 1 = only game-steps longer than N cycles, 0 = off (a 0->on switch clears the
  * counters), -1 = only read.  A captured hipGraph keeps the setting it
  * was captured with.  Synchronises when cycles_out != NULL. */

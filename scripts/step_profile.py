@@ -33,6 +33,7 @@ if thr > 1:
     print(f"  loop iterations per slow step {tot[8] / max(n, 1):.1f}, first visits {tot[9] / max(n, 1):.1f}")
     print(f"  terminal iterations per slow step: burst calls {tot[10] / max(n, 1):.1f} applying {tot[11] / max(n, 1):.1f} simulations, "
           f"general-path simulations {tot[12] / max(n, 1):.1f}; cycles before the burst (path check) {tot[13] / max(n, 1):.0f}, inside burst / general backup {tot[14] / max(n, 1):.0f}")
+    print(f"  switches between the burst's two register-resident paths: {tot[15] / max(n, 1):.1f} per slow step ({int(tot[15])} in all)")
     sys.exit(0)
 per_step = p[:, :7] / np.maximum(p[:, 7:8], 1)
 print("cycles per step per game (100 MHz s_memtime ticks? shader clock): mean over games / max over games")
@@ -40,3 +41,4 @@ for i, n in enumerate(names[:7]):
     print(f"  {n:16s} mean {per_step[:, i].mean():10.0f}   max {per_step[:, i].max():10.0f}")
 st = ro.eng.status()
 print("term_sims per game-step:", st["term_sims"].sum() / max(1, p[:, 7].sum()), " evals:", st["evals"].sum())
+print("burst calls", int(p[:, 10].sum()), "simulations applied in bursts", int(p[:, 11].sum()), "switches between the two register-resident paths", int(p[:, 15].sum()))

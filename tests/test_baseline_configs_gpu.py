@@ -144,6 +144,54 @@ def _bench_like_run(net, G, sims, max_game_moves, preroll, steps, watch, record)
     return fins, fens, rec, slot_of, n_graphs
 
 
+def test_two_path_terminal_burst_plays_the_same_games_as_the_one_path_form(env, monkeypatch):
+    """terminal_burst (csrc/bo_tree.h) keeps the previous burst's path in a second register set and switches between the two
+    without a descent from memory.  The bench-like run (256 slots x 800 sims, real net, refills, late-game start positions)
+    with the second set on and off (BETAONE_BURST_TWO_PATHS=0): every finished game identical -- moves, pi bits, z, terminal --
+    and the switches do occur (profile counter 15)."""
+    import torch
+    import network
+    from betaone_amd.fused_net import FusedPolicyValueNet
+    from betaone_amd.rollout import Rollout
+
+    config = env
+    config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 8, 2, 128
+    G, SIMS, LIMIT, PREROLL, STEPS = 256, 800, 28, 40, 36
+    torch.manual_seed(0)
+    net = FusedPolicyValueNet(network.PolicyValueNet().to("cuda:0").eval(), conv="tower_split").to("cuda:0")
+    runs = {}
+    for two in ("1", "0"):
+        monkeypatch.setenv("BETAONE_BURST_TWO_PATHS", two)
+        switches = []
+        orig_close = Rollout.close
+
+        def close_and_count(self, _sw=switches, _orig=orig_close):
+            _sw.append(int(self.eng.profile(0)[:, 15].sum()))
+            _orig(self)
+
+        orig_init = Rollout.__init__
+
+        def init_and_profile(self, *a, _orig=orig_init, **k):
+            _orig(self, *a, **k)
+            self.eng.profile(1, read=False)
+
+        monkeypatch.setattr(Rollout, "close", close_and_count)
+        monkeypatch.setattr(Rollout, "__init__", init_and_profile)
+        fins, fens, _, _, _ = _bench_like_run(net, G, SIMS, LIMIT, PREROLL, STEPS, (), record=False)
+        monkeypatch.setattr(Rollout, "close", orig_close)
+        monkeypatch.setattr(Rollout, "__init__", orig_init)
+        runs[two] = (fins, switches[0])
+    (on, sw_on), (off, sw_off) = runs["1"], runs["0"]
+    assert sw_on > 0 and sw_off == 0, (sw_on, sw_off)
+    assert set(on) == set(off) and len(on) > 100
+    for gid in on:
+        a, b = on[gid], off[gid]
+        assert list(a.moves) == list(b.moves) and a.terminal == b.terminal and a.outcome == b.outcome, gid
+        assert len(a.pis) == len(b.pis)
+        for (ia, va), (ib, vb) in zip(a.pis, b.pis):
+            assert np.array_equal(ia, ib) and np.array_equal(np.asarray(va).view(np.uint32), np.asarray(vb).view(np.uint32)), gid
+
+
 def test_bench_steady_state_path_with_refills_and_late_game_positions_matches_oracle(env):
     """The timed region of bench.py, oracle-checked at size: 256 slots x 800 sims x 8+2 x 128 on the Winograd tower, hipGraph
     on, native RNG, staggered starts, games ending (move limit 28, mates, claimed draws) and their slots refilled on the side
