@@ -428,7 +428,7 @@ BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, 
         while (c <= d && c <= db && path[c] == pb[c]) c++;
         if (!(c >= 1 && c <= d - 1 && c <= db - 1)) db = 0;  // identical, or parting at a last level (the sibling logic's case): one path
     }
-    const bool two = db > 0;
+    bool two = db > 0;
     int nv[BO_BURST_LEVELS + 1];  // uniform copies of the path nodes' visit counts
     int fc[BO_BURST_LEVELS], ncs[BO_BURST_LEVELS], chosen[BO_BURST_LEVELS];
 #pragma unroll
@@ -440,9 +440,15 @@ BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, 
         chosen[k] = k < d ? path[k + 1] - fc[k] : -1;
     }
     int my_fc = 0, my_nc = 0, my_chosen = -1;  // this lane's child: group = level, j = child index
+    // (the other path's loads are issued side by side with this path's: two dependent round trips for both, not four)
+    int b_fc = 0, b_nc = 0, b_chosen = -1;
+    if (two && grp < db) { b_fc = e.first_child[no + pb[grp]]; b_nc = e.n_children[no + pb[grp]]; }
+    int b_pv = (two && grp >= 1 && grp <= db) ? e.n_visits[no + pb[grp - 1]] : 0;  // (used by levels > c only: up to level c the parent-side node is common)
 #pragma unroll
     for (int k = 0; k < BO_BURST_LEVELS; k++)
         if (grp == k) { my_fc = fc[k]; my_nc = ncs[k]; my_chosen = chosen[k]; }
+    if (two && grp < db) b_chosen = pb[grp + 1] - b_fc;
+    if (two && bo_ballot(grp < db && b_nc > 16) != 0) { two = false; db = 0; }  // the other path no longer fits 16 lanes per level
     bool have = grp < d && j < my_nc;
     const bool last = grp == d - 1;  // the level whose children are leaves of the current path
     int cn = have ? e.n_visits[no + my_fc + j] : 0;
@@ -451,20 +457,15 @@ BO_DEV int terminal_burst(const Eng &e, int g, const int *path, int d, float v, 
     // at the last level any child that is ALREADY KNOWN to be a terminal leaf may take the next simulation
     int cterm = (have && last && e.n_children[no + my_fc + j] == 0) ? (int)e.term[no + my_fc + j] : -1;
     // the other path's register set: levels >= c (its own nodes); its chosen child also at level c - 1 (same node, other child)
-    int b_fc = 0, b_nc = 0, b_chosen = -1, b_cn = 0, b_cterm = -1, b_pv = 0;
+    int b_cn = 0, b_cterm = -1;
     float b_cq = 0.0f, b_cp = 0.0f;
     bool b_have = false;
     if (two) {
-        if (grp < db) {
-            b_fc = e.first_child[no + pb[grp]]; b_nc = e.n_children[no + pb[grp]];
-            b_chosen = pb[grp + 1] - b_fc;
-        }
         b_have = grp >= c && grp < db && j < b_nc;
         b_cn = b_have ? e.n_visits[no + b_fc + j] : 0;
         b_cq = b_have ? e.q[no + b_fc + j] : 0.0f;
         b_cp = b_have ? e.prior[no + b_fc + j] : 0.0f;
         b_cterm = (b_have && grp == db - 1 && e.n_children[no + b_fc + j] == 0) ? (int)e.term[no + b_fc + j] : -1;
-        b_pv = grp >= 1 && grp <= db ? e.n_visits[no + pb[grp - 1]] : 0;  // (used by levels > c only: up to level c the parent-side node is common)
     }
     float v_cur = v, v_oth = vb;
     int d_oth = db;
@@ -930,8 +931,7 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
             BO_PROF(6)
             const int may = e.c.S - sims < term_budget ? e.c.S - sims : term_budget;
             if (small) {
-                bool small_b = b_depth > 0 && e.c.burst_two != 0;  // the previous burst's path may ride along if it still fits the registers
-                for (int k = 0; k < b_depth && small_b; k++) small_b = e.n_children[no + sh.bpath[k]] <= 16;
+                const bool small_b = b_depth > 0 && e.c.burst_two != 0;  // the previous burst's path rides along (terminal_burst checks that it still fits)
                 applied = terminal_burst(e, g, sh.path, depth, tv, may, sh.probs, &burst_tables_staged, sh.bpath, small_b ? b_depth : 0, b_tv, &n_swaps);
                 n_burst++; n_burst_sims += applied;
                 bo_sync();
