@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--f32-tower", default=None, choices=["split", "fp32"],
                     help="float32 nets: 'split' (default, or BETAONE_F32_TOWER) = the tower on the fp16 matrix pipe with (hi, lo) operand pairs "
                          "(csrc/bo_tower_s.h); 'fp32' = the fp32-MFMA Winograd tower of rounds 1-2 (csrc/bo_tower_wg.h)")
+    ap.add_argument("--cohorts", type=int, default=None,
+                    help="the resident games as K phase-shifted cohorts, each with its own engine, HIP stream and captured graphs "
+                         "(betaone_amd.rollout.CohortRollout); results per game are identical for every K; default: 1")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -89,11 +92,13 @@ def parse():
     args = ap.parse_args()
     # --fast is priced on its own workload: enough resident games for the select + backup kernel to be
     # bandwidth-bound (a descent is a chain of dependent reads), a small fp16 net so that the evaluate stage does not starve it
-    d_ref = dict(games=256, sims=800, net="10x128", net_dtype="fp32", preroll=640, max_game_moves=16384)
-    d_fast = dict(games=32768, sims=800, net="10x128", net_dtype="fp16", preroll=3, max_game_moves=510)
+    d_ref = dict(games=256, sims=800, net="10x128", net_dtype="fp32", preroll=640, max_game_moves=16384, cohorts=1)
+    d_fast = dict(games=32768, sims=800, net="10x128", net_dtype="fp16", preroll=3, max_game_moves=510, cohorts=1)
     for k, v in (d_fast if args.fast else d_ref).items():
         if getattr(args, k) is None:
             setattr(args, k, v)
+    if args.cohorts < 1 or args.games % args.cohorts or (args.fast and args.cohorts > 1):
+        ap.error("--cohorts must divide --games (and is 1 with --fast)")
     if args.fast and args.steps == 20 and args.warmup == 3:
         args.steps, args.warmup = 1, 0  # (a ply of 32768 games x 800 simulations is 26 M evaluations: ~12 s)
     return args
@@ -191,8 +196,10 @@ def select_roofline(args, device):
             "levels_per_launch": levels, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(t * 1e3, 4)}
 
 
-TOWER_S_PMC_BYTES = 110_849_000   # rocprofv3 --pmc FETCH_SIZE (x 2) + WRITE_SIZE of bo_k_tower_s<128>, 256 boards (profiles/r03_tower_split_pmc.md)
-TOWER_WG_PMC_BYTES = 187_641_000  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of bo_k_tower_wg<128>, 256 boards (profiles/r02_tower_wg_pmc.md)
+# HBM-side bytes per launch come from separate `rocprofv3 --pmc` passes (counters cannot be read from inside the process): the line
+# carries `traffic: null` and names the committed pass; no constant from an earlier run is printed as if this run had measured it.
+TOWER_PMC_SOURCE = {"tower_split": "profiles/r03_tower_split_pmc.md (separate rocprofv3 --pmc pass of this kernel, 256 boards of the 10x128 net: 2 x FETCH_SIZE + WRITE_SIZE per launch)",
+                    "tower_wg": "profiles/r02_tower_wg_pmc.md (separate rocprofv3 --pmc pass of this kernel, 256 boards x 128 filters)"}
 
 
 def nn_roofline(net, batch, device, ro=None, drv=None, plies=3):
@@ -247,31 +254,27 @@ def nn_roofline(net, batch, device, ro=None, drv=None, plies=3):
             n_timed, how = len(ev), f"event pair around every launch of {plies} more plies of this workload (eager launches)"
     per_mac = 16 * 16 if conv == "tower_wg" else 3 * 9 * 64 if conv == "tower_split" else 9 * 64  # multiplies per (c_in, c_out) pair and board
     executed = 2.0 * per_mac * C * (128 + (n_conv - 1) * C) * batch
+    # SURVEY.md section 8d's per-unit figure: 2 x MACs of the direct 3x3 convolutions of the tower, per board (input conv: 120 planes)
     algorithmic = 2.0 * 9 * 64 * C * (120 + (n_conv - 1) * C) * batch
+    # `achieved` / `frac` = ALGORITHMIC flops per launch / the measured launch duration against the dense peak of the pipe the kernel
+    # multiplies on; what the kernel EXECUTES on that pipe (three fp16 MFMAs per float32 product; Winograd: 16 multiplies per 2x2
+    # tile; the input conv padded to 128 channels) is reported beside it as `pipe_utilisation`.
     if conv == "tower_split":
-        # the pipe actually used: fp16 MFMA, ~2.5 PFLOP/s dense (MI355X_MICROARCH.md); three fp16 MFMAs per float32 product are all counted
-        # as executed flops.  (A bare chain of this instruction on all 1024 SIMDs sustains 1.74 PFLOP/s on this part: the matrix pipe
-        # under load clocks below the 2.4 GHz the peak is quoted at -- scripts/split_lab.hip, profiles/r03_split_tower.md.)
-        return {"bound": "mfma", "kernel": "bo_k_tower_s", "achieved": round(executed / us / 1e6, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                "frac": round(executed / us / 1e6 / 2500.0, 4), "traffic": TOWER_S_PMC_BYTES if batch == 256 and C == 128 and n_conv == 21 else None,
-                "traffic_source": "constant from the committed PMC pass profiles/r03_tower_split_pmc.md (2 x FETCH_SIZE + WRITE_SIZE per launch: every XCD's L2 "
-                                  "streams the 12 MB of split weights once); valid for 256 boards of the 10x128 net only, null otherwise",
-                "avg_launch_us": round(us, 1), "launches_timed": n_timed, "timing": how,
-                "back_to_back_us": round(b2b, 1), "boards_per_launch": batch, "conv_layers": n_conv,
-                "algorithmic_direct_conv_tflops": round(algorithmic / us / 1e6, 1),
-                "float32_equivalent_tflops": round(executed / 3.0 / us / 1e6, 1),
-                "note": "float32 planes in and out; every float32 operand a (hi, lo) fp16 pair, every product three v_mfma_f32_32x32x16_f16 with "
-                        "float32 accumulation (direct 3x3 form); one workgroup per board, activations LDS-resident for the whole tower; "
-                        "the fp32-pipe Winograd tower of rounds 1-2 (BETAONE_F32_TOWER=fp32 / --f32-tower fp32) ran 0.80 of the 157 TFLOP/s fp32 peak"}
-    peak = 157.3  # TFLOP/s dense fp32 MFMA: 256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz (MI355X_MICROARCH.md)
-    return {"bound": "mfma", "kernel": "bo_k_tower_wg" if conv == "tower_wg" else "bo_k_tower", "achieved": round(executed / us / 1e6, 1), "peak": peak,
-            "unit": "TFLOP/s", "frac": round(executed / us / 1e6 / peak, 4), "traffic": TOWER_WG_PMC_BYTES if conv == "tower_wg" and batch == 256 and C == 128 else None,
-            "traffic_source": "constant from the committed PMC pass profiles/r02_tower_wg_pmc.md (2 x FETCH_SIZE + WRITE_SIZE per launch: every XCD's L2 streams "
-                              "the 21 MB of weights once); valid for 256 boards x 128 filters only, null for any other shape -- counters cannot be read from inside the process",
+        peak, kernel = 2500.0, "bo_k_tower_s"   # fp16 MFMA dense (MI355X_MICROARCH.md)
+        note = ("float32 planes in and out; every float32 operand a (hi, lo) fp16 pair, every product three v_mfma_f32_32x32x16_f16 with "
+                "float32 accumulation (direct 3x3 form); one workgroup per board, activations LDS-resident for the whole tower")
+    else:
+        peak, kernel = 157.3, ("bo_k_tower_wg" if conv == "tower_wg" else "bo_k_tower")  # fp32 MFMA dense: 256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz
+        note = "fp32 v_mfma_f32_16x16x4_f32; one workgroup per board, activations LDS-resident for the whole tower"
+    ach = algorithmic / us / 1e6
+    return {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "traffic": None, "traffic_source": TOWER_PMC_SOURCE.get(conv),
+            "basis": "algorithmic flops = 2 x MACs of the tower's direct 3x3 convolutions (2*9*64*C*(120 + (layers-1)*C) per board) x boards per launch",
+            "alg_flops_per_launch": algorithmic, "executed_mfma_flops_per_launch": executed,
+            "pipe_utilisation": round(executed / us / 1e6 / peak, 4),
+            "executed_tflops": round(executed / us / 1e6, 1),
             "avg_launch_us": round(us, 1), "launches_timed": n_timed, "timing": how, "back_to_back_us": round(b2b, 1),
-            "boards_per_launch": batch, "conv_layers": n_conv,
-            "algorithmic_direct_conv_tflops": round(algorithmic / us / 1e6, 1),
-            "note": "fp32 v_mfma_f32_16x16x4_f32; one workgroup per board, activations LDS-resident for the whole tower"}
+            "boards_per_launch": batch, "conv_layers": n_conv, "note": note}
 
 
 def _fast_counters(eng):
@@ -494,6 +497,12 @@ class Driver:
 
 def main():
     args = parse()
+    if args.share_gpu and args.gpus > 1 and args.dist_backend == "nccl":
+        # More ranks than devices: RCCL (like NCCL) rejects a communicator with two ranks on one device.  Refused here, before
+        # any rank is started or any GPU call is made -- not found out by starting ranks that are expected to fail.
+        print("bench.py: --share-gpu puts every rank on cuda:0 and RCCL does not form a communicator with two ranks on one device; "
+              "use --dist-backend gloo for the one-GPU rehearsal of the N>1 path", file=sys.stderr)
+        sys.exit(2)
     env_world = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and env_world is None:
         sys.exit(self_launch(args))
@@ -519,19 +528,20 @@ def main():
 
     from betaone_amd import engine as E
     from betaone_amd import records
-    from betaone_amd.rollout import Rollout
+    from betaone_amd.rollout import CohortRollout, Rollout
 
     E.load_hip_library()
-    _, net = make_net(args.net, device, args.net_dtype, args.games * (args.leaves if args.fast else 1),
+    _, net = make_net(args.net, device, args.net_dtype, (args.games // args.cohorts) * (args.leaves if args.fast else 1),
                       f32_pipe=None if args.f32_tower is None else args.f32_tower == "fp32")
     net_layout = getattr(net, "layout", "nchw")
     if args.net_dtype != "fp32":
         net = CastIn(net, {"fp16": torch.float16, "bf16": torch.bfloat16}[args.net_dtype])
     G = args.games
-    ro = Rollout(net, G, num_simulations=args.sims, mcts_batch_size=args.batch, device=str(device), use_graph=not args.no_graph,
+    ro_kw = dict(num_simulations=args.sims, mcts_batch_size=args.batch, device=str(device), use_graph=not args.no_graph,
                  rng_mode="native", max_game_moves=args.max_game_moves, fast=args.fast, leaves_per_step=args.leaves,
                  fast_arena_granules=(args.arena_granules_per_expansion * (args.sims + args.leaves + 2) if args.fast else 0),
                  policy_kind="probs" if args.softmax == "torch" else "logits")
+    ro = CohortRollout(net, G, cohorts=args.cohorts, **ro_kw) if args.cohorts > 1 else Rollout(net, G, **ro_kw)
     if args.fast and G * args.leaves > 65536:
         ro.MAX_GRAPH_ITERATIONS = 4 if G * args.leaves <= 131072 else 2  # (every iteration of a captured graph keeps its own logits / probabilities: 6.5 GB at 131072 rows)
     if args.fast and (args.select_games_per_halfwave is not None or args.select_flags is not None):
@@ -576,11 +586,18 @@ def main():
     t_flush = time.perf_counter() - t_flush
     mine = [ro.n_sims - s0, ro.n_plies - p0, ro.n_forward - f0, drv.n_finished - n0, drv.plies_finished - pf0,
             drv.n_finished, drv.plies_finished]
+    per_rank_ms = None
     if dist is not None:
         rdev = device if args.dist_backend == "nccl" else torch.device("cpu")
         t = torch.tensor([dt], dtype=torch.float64, device=rdev)
+        every = torch.zeros(world, dtype=torch.float64, device=rdev)
+        dist.all_gather_into_tensor(every, t)   # each rank's own time over the K steps: stragglers show in the line
+        per_rank_ms = [round(float(x) / args.steps * 1e3, 3) for x in every.cpu().tolist()]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        blocked = torch.tensor([float(exchange.blocked_ticks if exchange is not None else 0)], dtype=torch.float64, device=rdev)
+        dist.all_reduce(blocked, op=dist.ReduceOp.SUM)
+        blocked_all = int(blocked.item())
         tot = torch.tensor(mine, dtype=torch.float64, device=rdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         mine = tot.tolist()
@@ -601,6 +618,8 @@ def main():
                   file=sys.stderr, flush=True)
     host_frac = (ro.host_seconds - h0) / dt
 
+    if hasattr(ro, "drain"):
+        ro.drain()  # (cohorts: the plies still outstanding after the timed steps are ended; nothing new is begun)
     opening = None
     if rank == 0 and args.opening_steps > 0 and args.preroll > 0 and dist is None:
         # labelled extra: every game at the start position (what round 1 reported as the headline)
@@ -615,6 +634,8 @@ def main():
             drv.step()
         torch.cuda.synchronize(device)
         do = time.perf_counter() - to
+        if hasattr(ro, "drain"):
+            ro.drain()
         opening = {"nodes_per_sec": round((ro.n_sims - so) / do, 1), "ms_per_step": round(do / args.opening_steps * 1e3, 3),
                    "steps": args.opening_steps, "note": "all games within their first ~25 plies; not the headline"}
 
@@ -629,7 +650,7 @@ def main():
         if fast_roof is not None and args.select_sweep:
             fast_roof["variants"] = sweep
     if rank == 0 and not args.no_roofline and not args.fast and args.net_dtype == "fp32":
-        rn = nn_roofline(net, G, device, ro if dist is None else None, drv)  # (more plies of this workload, after everything reported)
+        rn = nn_roofline(net, G // args.cohorts, device, ro if dist is None else None, drv)  # (more plies of this workload, after everything reported)
 
     out = None
     if rank == 0:
@@ -648,7 +669,7 @@ def main():
                                    + (f"steady state (games at every stage after {args.preroll} untimed pre-roll plies with staggered starts; finished games are "
                                       f"exported and their slots refilled inside the timed region); " if args.preroll > 0 else "opening phase (all games start together); ")
                                    + cfg_name,
-                       "games_per_gpu": G, "sims_per_move": args.sims, "net": args.net, "net_dtype": args.net_dtype,
+                       "games_per_gpu": G, "cohorts": args.cohorts, "sims_per_move": args.sims, "net": args.net, "net_dtype": args.net_dtype,
                        "hipgraph": not args.no_graph, "net_layout": net_layout, "policy_softmax": softmax_site(net, args, G * (args.leaves if args.fast else 1)), "evaluate_stage": getattr(getattr(net, "net", net), "route", net_layout), "hw_queues": betaone_amd.hw_queues(), "preroll_plies": args.preroll,
                        "search_mode": ("fast: virtual loss, %d leaves/step, full-width expansion (NOT the reference's semantics)" % args.leaves)
                                       if args.fast else "reference semantics (bit-exact)",
@@ -663,10 +684,6 @@ def main():
             "games_finished_since_start": int(fin_all),
             "mean_plies_of_all_finished_games": (round(mean_len, 1) if mean_len else None),
             "games_per_hour_from_ply_rate": (round(plies / dt * 3600.0 / mean_len, 1) if mean_len else None),
-            # (a 20-ply window finishes a dozen games; the long-run figure of the same workload and where it was measured, for comparison)
-            "games_per_hour_long_run": ({"value": 795756, "plies_timed": 5000, "games_finished": 3847, "mean_plies": 330.8,
-                                         "source": "profiles/r03_logs/r4n_bench_5000.log (bench.py --steps 5000, this workload, one MI355X)"}
-                                        if (not args.fast and G == 256 and args.sims == 800 and args.net == "10x128" and args.net_dtype == "fp32" and world == 1) else None),
             "untimed_setup_seconds": round(t_pre, 2),
             "host_fraction": round(host_frac, 4),
         }
@@ -674,9 +691,14 @@ def main():
             out["opening_phase"] = opening
         if exchange is not None:
             out["record_exchange"] = {"size_gathers": exchange.n_size_gathers, "payload_gathers": exchange.n_payload_gathers,
-                                      "ticks_that_blocked": exchange.blocked_ticks, "records_received_rank0": drv.n_received,
+                                      "ticks_that_blocked": exchange.blocked_ticks, "ticks_that_blocked_all_ranks": blocked_all,
+                                      "records_received_rank0": drv.n_received,
                                       "host_seconds_in_exchange_rank0": round(drv.exchange_seconds, 4),
-                                      "seconds_draining_the_pipeline_after_the_timed_steps_rank0": round(t_flush, 4)}
+                                      "seconds_draining_the_pipeline_after_the_timed_steps_rank0": round(t_flush, 4),
+                                      "backend": args.dist_backend,
+                                      "hardware_coverage": "the builder's pool hands out one-GPU boxes: RCCL between DISTINCT GPUs has never run before this "
+                                                           "command; covered so far: gloo world 2/4/8 on CPU, RCCL at N=1, two gloo ranks sharing one GPU"}
+            out["per_rank_ms_per_step"] = {"min": min(per_rank_ms), "max": max(per_rank_ms), "ranks": per_rank_ms}
     if rank == 0 and not args.no_roofline:
         sr = step_roofline(ro, args.steps)
         out["roofline_step"] = {"bound": "latency", "note": "parity-mode trees are cache-resident (a few KB per game)",
@@ -713,4 +735,14 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except Exception as ex:
+        from betaone_amd.records import ExchangeError
+
+        if not isinstance(ex, ExchangeError):
+            raise
+        # a peer rank died or hangs mid-period: say so and leave with a non-zero code at once (no waiting in the process group's
+        # teardown for the peer; the launcher ends the other ranks)
+        print(f"bench.py rank {os.environ.get('RANK', '0')}: {ex}", file=sys.stderr, flush=True)
+        os._exit(3)

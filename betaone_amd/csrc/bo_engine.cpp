@@ -57,6 +57,7 @@ struct bo_engine {
     //   info = [phase | req_node | root_nlegal | root_term | ply]
     int *d_res_blk = nullptr, *d_info_blk = nullptr;
     int *h_res = nullptr, *h_info = nullptr;  // pinned
+    int watch_seen = 0;                        // OR of the watched status word over the fetched result blocks (bo_engine_watch)
     double *h_noise = nullptr;                // pinned [G][256]
     int *h_go = nullptr;                      // pinned [G]
     std::vector<int> h_nl, h_term;
@@ -227,11 +228,12 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
                      &d.trk_n, &d.n_hist, &d.ctx_mode, &d.root_nch, &d.stat_evals,
                      &d.stat_flushes, &d.stat_term_sims, &d.stat_levels, &d.stat_children_scanned, &e->d_go, &e->d_action};
     for (int **p : iscal) rc |= e->alloc(p, G);
-    const size_t res_ints = G * (4 + 2 * (size_t)BO_RES_CAP), info_ints = G * 5;
+    const size_t res_ints = G * (4 + 2 * (size_t)BO_RES_CAP) + 4, info_ints = G * 5;  // (+ 4: the watched status word, bo_engine_watch)
     rc |= e->alloc(&e->d_res_blk, res_ints); rc |= e->alloc(&e->d_info_blk, info_ints);
     if (!rc) {
         d.res_n = e->d_res_blk; d.res_best_idx = e->d_res_blk + G; d.res_best_mv = e->d_res_blk + 2 * G; d.res_total = e->d_res_blk + 3 * G;
         d.res_idx = e->d_res_blk + 4 * G; d.res_val = reinterpret_cast<float *>(e->d_res_blk + 4 * G + G * BO_RES_CAP);
+        d.res_watch = e->d_res_blk + G * (4 + 2 * (size_t)BO_RES_CAP); d.watch = nullptr;
         d.phase = e->d_info_blk; d.req_node = e->d_info_blk + G; d.root_nlegal = e->d_info_blk + 2 * G; d.root_term = e->d_info_blk + 3 * G;
         d.ply = e->d_info_blk + 4 * G;
         rt_memset(e->d_res_blk, 0, res_ints * 4, nullptr); rt_memset(e->d_info_blk, 0, info_ints * 4, nullptr);
@@ -574,7 +576,7 @@ static int result_enqueue(bo_engine *e, void *stream) {
     const size_t G = (size_t)e->d.c.G;
     if (e->fast) RT(RT_LAUNCH(bo_k_fw_result, e->d.c.G, stream, e->d, e->f));
     else RT(RT_LAUNCH(bo_k_result, e->d.c.G, stream, e->d));
-    RT(rt_d2h(e->h_res, e->d_res_blk, G * (4 + 2 * (size_t)BO_RES_CAP) * 4, stream));  // the whole result block in one copy
+    RT(rt_d2h(e->h_res, e->d_res_blk, (G * (4 + 2 * (size_t)BO_RES_CAP) + 4) * 4, stream));  // the whole result block (+ the watched word) in one copy
     return BO_OK;
 }
 
@@ -588,6 +590,22 @@ static int result_unpack(bo_engine *e, int32_t *res_n, int32_t *res_idx, float *
     if (total_visits) memcpy(total_visits, h + 3 * G, G * 4);
     if (res_idx) memcpy(res_idx, h + 4 * G, G * BO_RES_CAP * 4);
     if (res_val) memcpy(res_val, h + 4 * G + G * BO_RES_CAP, G * BO_RES_CAP * 4);
+    e->watch_seen |= h[G * (4 + 2 * (size_t)BO_RES_CAP)];
+    return BO_OK;
+}
+
+// A device status word of the evaluate stage (the split-precision tower's "an activation left the fp16 range", bo_nn_tower_word)
+// rides along with every fetched result block: the ply's one host round trip checks it, no copy or wait of its own.
+extern "C" int bo_engine_watch(bo_engine *e, int32_t *dev_word) {
+    if (!e) return fail(BO_E_ARG, "null engine");
+    e->d.watch = dev_word;
+    return BO_OK;
+}
+// OR of the watched word over every result block fetched since the last call with clear != 0 (host state; nothing is enqueued)
+extern "C" int bo_engine_watch_seen(bo_engine *e, int32_t *seen_out, int32_t clear) {
+    if (!e || !seen_out) return fail(BO_E_ARG, "bad arguments");
+    *seen_out = e->watch_seen;
+    if (clear) e->watch_seen = 0;
     return BO_OK;
 }
 
@@ -1313,8 +1331,8 @@ extern "C" int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layer
     int rc = (int)hipMalloc((void **)&t->wts, (size_t)n_weights * 4);
     if (!rc) rc = (int)hipMalloc((void **)&t->params, (size_t)n_params * 4);
     if (!rc) rc = (int)hipMalloc((void **)&t->layers, (size_t)n_layers * sizeof(bo_tower_layer));
-    if (!rc) rc = (int)hipMalloc((void **)&t->overflow, 4);
-    if (!rc) rc = (int)hipMemset(t->overflow, 0, 4);
+    if (!rc) rc = (int)hipMalloc((void **)&t->overflow, 8);  // [status word | scratch of bo_nn_tower_status's exchange]
+    if (!rc) rc = (int)hipMemset(t->overflow, 0, 8);
     if (!rc) rc = (int)hipMemcpy(t->wts, weights, (size_t)n_weights * 4, hipMemcpyHostToDevice);
     if (!rc) rc = (int)hipMemcpy(t->params, params, (size_t)n_params * 4, hipMemcpyHostToDevice);
     if (!rc) rc = (int)hipMemcpy(t->layers, layers, (size_t)n_layers * sizeof(bo_tower_layer), hipMemcpyHostToDevice);
@@ -1390,15 +1408,34 @@ extern "C" void bo_nn_tower_destroy(bo_tower *t) {
     delete t;
 }
 
+#if !defined(BO_WAVE_EMU)
+__global__ void bo_k_word_exchange(int *word, int *out) { *out = atomicExch(word, 0); }
+#endif
+
+// Read AND clear the tower's status word in one atomic exchange on `stream` -- the stream the tower is launched on: ordered behind
+// the forwards it reports on, and a forward that sets the word while it is being read is not lost between a copy and a memset.
 extern "C" int bo_nn_tower_status(bo_tower *t, int32_t *overflow_out, void *stream) {
 #if defined(BO_WAVE_EMU)
     (void)t; (void)overflow_out; (void)stream;
     return fail(BO_E_CONFIG, "bo_nn_tower is a gfx950-only kernel");
 #else
     if (!t || !overflow_out) return fail(BO_E_ARG, "bad arguments");
-    RT(rt_d2h(overflow_out, t->overflow, 4, stream));
+    hipLaunchKernelGGL(bo_k_word_exchange, dim3(1), dim3(1), 0, (hipStream_t)stream, t->overflow, t->overflow + 1);
+    RT((int)hipGetLastError());
+    RT(rt_d2h(overflow_out, t->overflow + 1, 4, stream));
     RT(rt_sync(stream));
-    if (*overflow_out) { RT((int)hipMemsetAsync(t->overflow, 0, 4, (hipStream_t)stream)); RT(rt_sync(stream)); }
+    return BO_OK;
+#endif
+}
+
+// Device address of the tower's status word (non-zero: an activation left the fp16 range), for bo_engine_watch.
+extern "C" int bo_nn_tower_word(bo_tower *t, void **dev_word_out) {
+#if defined(BO_WAVE_EMU)
+    (void)t; (void)dev_word_out;
+    return fail(BO_E_CONFIG, "bo_nn_tower is a gfx950-only kernel");
+#else
+    if (!t || !dev_word_out) return fail(BO_E_ARG, "bad arguments");
+    *dev_word_out = t->overflow;
     return BO_OK;
 #endif
 }

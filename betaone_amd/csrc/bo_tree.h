@@ -85,6 +85,8 @@ struct Eng {
     // search results
     int *res_n, *res_idx, *res_best_idx, *res_best_mv, *res_total;
     float *res_val;
+    int *watch, *res_watch;           // bo_engine_watch: a device status word of the evaluate stage (NULL: none); the result kernels copy it behind
+                                      // the result block, so the ply's one host round trip brings it along
     int *played_now;                  // [G] or NULL: bo_k_play notes the move it played (0: refused) -- read by the fast mode's re-rooting
     unsigned long long *prof;         // [G][BO_PROF_SLOTS] cycles: apply, select, first-visit (movegen+draw rules), terminal backups, encode, flush, total; steps,
                                       // loop iterations, first visits.  profile = N > 1 counts only game-steps longer than N cycles
@@ -1114,6 +1116,7 @@ BO_KERNEL void bo_k_stop(Eng e, const int *mask) {
 // pi and best move of a finished search (mcts.py:259-280)
 BO_KERNEL void bo_k_result(Eng e) {
     const int g = bo_block(), lane = bo_lane();
+    if (g == 0 && lane == 0) e.res_watch[0] = e.watch ? *e.watch : 0;
     if (e.phase[g] != PH_DONE) return;
     const size_t no = NOFF(e, g);
     const int nch = e.n_children[no], fc = e.first_child[no], n = e.root_nlegal[g];

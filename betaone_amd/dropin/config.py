@@ -40,7 +40,10 @@ _TABLES = {
     #   POLICY_SOFTMAX  "torch" = torch.softmax(logits, dim=1) exactly where the reference calls it (mcts.py:185,287), inside
     #                 the captured graph; the engine gathers probabilities (the seam the parity tests record).
     #                 "engine" = the step kernel's own softmax over the logits row (hardware exp; within 1e-5 relative)
-    "engine": dict(AUTOCAST=False, SEARCH_MODE="reference", FAST_LEAVES=16, ENGINE_MAX_PLIES=None, POLICY_SOFTMAX="torch"),
+    #   COHORTS       run_self_play_games: the resident games as this many phase-shifted cohorts, each on its own HIP stream
+    #                 (rollout.CohortRollout: one cohort's tower overlaps another's tree step, heads and ply boundary); 1 = one Rollout.
+    #                 Results do not depend on it (games are independent).  Used when it divides the slot count.
+    "engine": dict(AUTOCAST=False, SEARCH_MODE="reference", FAST_LEAVES=16, ENGINE_MAX_PLIES=None, POLICY_SOFTMAX="torch", COHORTS=1),
 }
 for _group in _TABLES.values():
     globals().update(_group)

@@ -17,7 +17,7 @@ import torch
 import config
 from betaone_amd import engine as E
 from betaone_amd import sampling
-from betaone_amd.rollout import FinishedGame, Rollout
+from betaone_amd.rollout import CohortRollout, FinishedGame, Rollout
 
 SelfPlayData = Tuple[torch.Tensor, np.ndarray, float]
 
@@ -40,17 +40,24 @@ def _inference_copy(model, n_slots: int):
     return model
 
 
-def _rollout(model, n_slots: int, rng_mode: str = "python") -> Rollout:
+def _cohorts(n_slots: int, rng_mode: str) -> int:
+    k = int(getattr(config, "COHORTS", 1))
+    return k if (k > 1 and rng_mode == "native" and n_slots % k == 0 and n_slots // k >= 1) else 1
+
+
+def _rollout(model, n_slots: int, rng_mode: str = "python"):
     dev = E.runtime_device(config.DEVICE)
-    model = _inference_copy(model, n_slots)
-    return Rollout(model, n_slots, num_simulations=config.NUM_SIMULATIONS, mcts_batch_size=config.MCTS_BATCH_SIZE,
-                   cpuct=config.CPUCT, widen_coeff=config.WIDEN_COEFF, dirichlet_alpha=config.DIRICHLET_ALPHA,
-                   dirichlet_epsilon=config.DIRICHLET_EPSILON, max_plies=config.ENGINE_MAX_PLIES,  # None = room for MAX_GAME_MOVES
-                   max_game_moves=config.MAX_GAME_MOVES,
-                   temperature=(config.TEMPERATURE_THRESHOLD, config.TEMPERATURE_INITIAL, config.TEMPERATURE_FINAL),
-                   device=dev, autocast=config.AUTOCAST, rng_mode=rng_mode,
-                   policy_kind="probs" if config.POLICY_SOFTMAX == "torch" else "logits",
-                   fast=config.SEARCH_MODE == "fast", leaves_per_step=config.FAST_LEAVES)
+    k = _cohorts(n_slots, rng_mode)
+    model = _inference_copy(model, n_slots // k)
+    kw = dict(num_simulations=config.NUM_SIMULATIONS, mcts_batch_size=config.MCTS_BATCH_SIZE,
+              cpuct=config.CPUCT, widen_coeff=config.WIDEN_COEFF, dirichlet_alpha=config.DIRICHLET_ALPHA,
+              dirichlet_epsilon=config.DIRICHLET_EPSILON, max_plies=config.ENGINE_MAX_PLIES,  # None = room for MAX_GAME_MOVES
+              max_game_moves=config.MAX_GAME_MOVES,
+              temperature=(config.TEMPERATURE_THRESHOLD, config.TEMPERATURE_INITIAL, config.TEMPERATURE_FINAL),
+              device=dev, autocast=config.AUTOCAST, rng_mode=rng_mode,
+              policy_kind="probs" if config.POLICY_SOFTMAX == "torch" else "logits",
+              fast=config.SEARCH_MODE == "fast", leaves_per_step=config.FAST_LEAVES)
+    return CohortRollout(model, n_slots, cohorts=k, **kw) if k > 1 else Rollout(model, n_slots, **kw)
 
 
 def _records(ro: Rollout, fin: FinishedGame) -> List[SelfPlayData]:
@@ -65,13 +72,15 @@ def _records(ro: Rollout, fin: FinishedGame) -> List[SelfPlayData]:
 
 def run_self_play_games(model, game_ids: Sequence[int], seeds: Optional[Sequence[int]] = None,
                         n_slots: Optional[int] = None, start_fens: Optional[Sequence[Optional[str]]] = None,
-                        on_game=None, dense: bool = True, reload_model=None
+                        on_game=None, dense: bool = True, reload_model=None, on_records=None
                         ) -> Dict[int, Optional[List[SelfPlayData]]]:
     """Play len(game_ids) games, n_slots at a time, on one GPU.  Game i draws its Dirichlet noise and its
     moves from numpy.random.RandomState(seeds[i]) -- the stream the reference consumes after
     np.random.seed(seeds[i]) -- so results do not depend on n_slots or on which GPU a game lands on.
     on_game(FinishedGame): called for every finished game while it is still resident in its slot (compact records:
     betaone_amd.records.save_games); dense=False skips the reference's dense tuples (the result values are then empty lists).
+    on_records(game_id, tuples) -> what to keep in the result for that game: called with a finished game's dense tuples as soon
+    as they exist (selfplay_main pickles them there and keeps an empty list, so an iteration's tuples never pile up in memory).
     reload_model() -> None | a new PolicyValueNet: polled once per ply; a returned model replaces the evaluate stage for every
     evaluation from the next ply on (main.py:147-148 hands weights to its workers through best_model.pth: betaone_amd.selfplay_main
     watches that file)."""
@@ -93,16 +102,17 @@ def run_self_play_games(model, game_ids: Sequence[int], seeds: Optional[Sequence
             print(f"Game {fin.game_id} aborted after {len(fin.moves)} moves (max).")  # self_play.py:186-187
         if on_game is not None:
             on_game(fin)
-        results[fin.game_id] = _records(ro, fin) if dense else []
+        data = _records(ro, fin) if dense else []
+        results[fin.game_id] = on_records(fin.game_id, data) if (on_records is not None and dense) else data
 
     first = [next_game(s) for s in range(n_slots)]
     ro.start_games(list(range(n_slots)), [f[0] for f in first], [f[1] for f in first], [f[2] for f in first])
     try:
-        while any(g is not None for g in ro.games):
+        while any(g is not None for g in ro.games):  # (cohorts: a call ends each cohort's outstanding ply and begins its next one)
             if reload_model is not None:
                 fresh = reload_model()
                 if fresh is not None:
-                    ro.swap_model(_inference_copy(fresh, n_slots))
+                    ro.swap_model(_inference_copy(fresh, n_slots // _cohorts(n_slots, "native")))
             ro.play_ply(on_finished=finished, refill=next_game)
             _settle_status(ro, results, finished, next_game)
     finally:
@@ -160,8 +170,9 @@ def save_game_data(game_data: List[SelfPlayData], iteration: int, game_id: int):
     data_dir = os.path.join(config.DATA_DIR, f"iter_{iteration}")
     os.makedirs(data_dir, exist_ok=True)
     filepath = os.path.join(data_dir, f"game_{game_id}.pkl")
-    try:
-        with open(filepath, "wb") as f:
+    try:  # (through a temporary name: a killed writer leaves no half pickle that a resume would count as a finished game)
+        with open(filepath + ".tmp", "wb") as f:
             pickle.dump(game_data, f)
+        os.replace(filepath + ".tmp", filepath)
     except Exception as e:
         print(f"Error saving game data to {filepath}: {e}")

@@ -89,6 +89,9 @@ _SYMBOLS = {
     "bo_fast_options": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "bo_event_pair_overhead": (C.c_int, [_F64P, C.c_int32, C.c_void_p]),
     "bo_nn_tower_status": (C.c_int, [C.c_void_p, _I32P, C.c_void_p]),
+    "bo_nn_tower_word": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bo_engine_watch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bo_engine_watch_seen": (C.c_int, [C.c_void_p, _I32P, C.c_int32]),
     "bo_fast_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _I32P, C.c_int32, _F64P, C.POINTER(C.c_int64),
                                C.c_void_p]),
     "bo_engine_status": (C.c_int, [C.c_void_p, _I32P, _I32P, _I32P, _I32P, _I32P, _I32P, C.c_void_p]),
@@ -126,7 +129,7 @@ def bind(cdll: C.CDLL) -> C.CDLL:
 
 
 _hip_lib: Optional[C.CDLL] = None
-ABI_VERSION = 3   # BO_ABI_VERSION of include/betaone_engine.h this binding was written against (tests/test_abi.py compares)
+ABI_VERSION = 4   # BO_ABI_VERSION of include/betaone_engine.h this binding was written against (tests/test_abi.py compares)
 PROF_SLOTS = 16   # BO_PROF_SLOTS
 
 
@@ -432,6 +435,15 @@ class Engine:
         ms = C.c_double(0.0)
         self._check(self.lib.bo_event_pair_overhead(C.byref(ms), samples, stream))
         return ms.value
+
+    def watch(self, dev_word_ptr: int):
+        """Have every fetched result block bring the int32 device word at `dev_word_ptr` along (0: none) -- bo_engine_watch."""
+        self._check(self.lib.bo_engine_watch(self.h, dev_word_ptr or None))
+
+    def watch_seen(self, clear: bool = True) -> int:
+        seen = C.c_int32(0)
+        self._check(self.lib.bo_engine_watch_seen(self.h, C.byref(seen), 1 if clear else 0))
+        return seen.value
 
     def status_bits(self, stream: int = 0) -> np.ndarray:
         """Only the per-slot status words (one small copy): 0 = fine, else a combination of STATUS_BITS."""

@@ -429,7 +429,9 @@ class FusedPolicyValueNet(nn.Module):
 
     def check_overflow(self):
         """conv='tower_split' carries activations as fp16 pairs: raise if any forward since the last check had to saturate one (its
-        outputs were wrong) -- bo_nn_tower_status.  Synchronises; callers check at game / run boundaries, not per forward."""
+        outputs were wrong) -- bo_nn_tower_status: the word is read and cleared by one atomic exchange on torch's CURRENT stream,
+        which must be the stream the forwards were launched on (it is ordered behind them there).  Synchronises that stream.  The
+        self-play loop does not call this per ply: it watches the word through the engine's result block (overflow_word_ptr)."""
         t = self.__dict__.get("_tower")
         if not t or self.conv != "tower_split":
             return
@@ -438,8 +440,21 @@ class FusedPolicyValueNet(nn.Module):
         if rc:
             raise E.EngineError(self.lib.bo_last_error().decode())
         if flag.value:
-            raise E.EngineError("tower_split: an activation left the fp16 range (|v| > 65504) and was saturated -- the evaluations of this net are "
-                                "wrong on the fp16 matrix pipe; run it with BETAONE_F32_TOWER=fp32 (best_inference_copy(..., f32_pipe=True))")
+            raise E.EngineError(self.OVERFLOW_MESSAGE)
+
+    OVERFLOW_MESSAGE = ("tower_split: an activation left the fp16 range (|v| > 65504) and was saturated -- the evaluations of this net are "
+                        "wrong on the fp16 matrix pipe; run it with BETAONE_F32_TOWER=fp32 (best_inference_copy(..., f32_pipe=True))")
+
+    def overflow_word_ptr(self) -> int:
+        """Device address of the split-precision tower's status word (0 for every other evaluate stage): Rollout hands it to
+        bo_engine_watch, so each ply's result block brings it along and a saturating net stops the run at that ply."""
+        t = self.__dict__.get("_tower")
+        if not t or self.conv != "tower_split":
+            return 0
+        p = C.c_void_p()
+        if self.lib.bo_nn_tower_word(t, C.byref(p)):
+            raise E.EngineError(self.lib.bo_last_error().decode())
+        return p.value or 0
 
     def _tower_forward(self, x, heads=False):
         """Tower output [B, C, 8, 8]; with heads=True (conv='tower_wg') the ReLU'd policy / value planes, flattened."""

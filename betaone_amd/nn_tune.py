@@ -4,43 +4,12 @@ betaone_amd/nn_tune.py -- pick the evaluate stage's memory layout for the batch 
 The engine writes NN input rows as NCHW float32.  The evaluate stage is chosen by SHAPE (kernel_route): the hand-written gfx950
 kernels wherever they exist; the library path (PyTorch-ROCm / MIOpen: NCHW at a few hundred positions per batch, channels-last
 from about a thousand -- measured on MI355X, net 8+2x128 fp32: 1.48 vs 2.29 ms at 256, 4.49 vs 4.41 ms at 1024) only for shapes
-without one, and then with a warning.  The timing race of rounds 1-2 is kept behind BETAONE_NN_TUNE=1 as a debugging aid.
+without one, and then with a warning.  (The start-up timing race of rounds 1-2 is not part of the package any more: it lives on as
+the lab script scripts/nn_layout_race.py.)
 """
 from __future__ import annotations
 
-import time
-
 import torch
-
-
-def _time_forward(net, x, reps: int = 8) -> float:
-    """Seconds per forward: best of three timed rounds after at least 50 ms of warm-up (the first launches after the
-    host-side weight packing of a candidate run at idle clocks and would misrank it)."""
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        n = 0
-        while n < 3 or time.perf_counter() - t0 < 0.05:
-            net(x)
-            torch.cuda.synchronize(x.device)
-            n += 1
-        replay = None
-        try:  # time what the rollout runs: a captured hipGraph of the forward (eager timing at batch 1 is launch-bound)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                net(x)
-            replay = g.replay
-        except Exception:
-            torch.cuda.synchronize(x.device)
-        run = replay if replay is not None else (lambda: net(x))
-        best = None
-        for _ in range(3):
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                run()
-            torch.cuda.synchronize(x.device)
-            t = (time.perf_counter() - t0) / reps
-            best = t if best is None or t < best else best
-    return best
 
 
 def f32_pipe_default() -> bool:
@@ -78,12 +47,10 @@ def kernel_route(filters: int, batch: int, dtype: torch.dtype, f32_pipe: bool = 
     return None
 
 
-def best_inference_copy(model, batch: int, device, dtype: torch.dtype = torch.float32, verbose: bool = False, tune=None, f32_pipe=None):
+def best_inference_copy(model, batch: int, device, dtype: torch.dtype = torch.float32, verbose: bool = False, f32_pipe=None):
     """BN-folded inference copy of a PolicyValueNet for `batch` rows: the hand-written kernels chosen by kernel_route(); where
     there are none (other filter counts, bfloat16) the PyTorch-ROCm copy in NCHW up to 512 rows and channels-last beyond, with
-    a warning naming the library path.  tune=True (or BETAONE_NN_TUNE=1) runs the start-up timing race of rounds 1-2 instead
-    (a debugging aid: it can keep MIOpen where that measures faster)."""
-    import os
+    a warning naming the library path."""
     import warnings
 
     device = torch.device(device)
@@ -91,10 +58,6 @@ def best_inference_copy(model, batch: int, device, dtype: torch.dtype = torch.fl
         return model
     if device.type != "cuda":
         return model.for_inference(dtype=dtype, channels_last=False)
-    if tune is None:
-        tune = os.environ.get("BETAONE_NN_TUNE", "0") not in ("", "0")
-    if tune:
-        return timed_inference_copy(model, batch, device, dtype, verbose)
     from . import engine as E
     from .fused_net import FusedPolicyValueNet
 
@@ -118,48 +81,3 @@ def best_inference_copy(model, batch: int, device, dtype: torch.dtype = torch.fl
     warnings.warn(f"betaone_amd: the evaluate stage of this net runs on PyTorch-ROCm library kernels (MIOpen / hipBLASLt), {net.layout}: {why}",
                   RuntimeWarning, stacklevel=2)
     return net
-
-
-def timed_inference_copy(model, batch: int, device, dtype: torch.dtype = torch.float32, verbose: bool = False):
-    """The start-up timing race (debugging aid): every candidate layout / kernel set is timed on the real batch shape."""
-    device = torch.device(device)
-    x = torch.zeros((batch, 120, 8, 8), dtype=dtype, device=device)
-    best, best_t, best_cl = None, None, None
-    for cl in (False, True):
-        net = model.to(device).for_inference(dtype=dtype, channels_last=cl)
-        t = _time_forward(net, x)
-        if verbose:
-            print(f"[nn_tune] batch={batch} channels_last={cl}: {t * 1e3:.3f} ms")
-        if best_t is None or t < best_t:
-            best, best_t, best_cl = net, t, cl
-    best.layout = "channels_last" if best_cl else "nchw"
-    if dtype == torch.float32:  # NCHW fp32 with the hand-written kernels (csrc/bo_nn_fused.h, csrc/bo_conv.h)
-        from . import engine as E
-        from .fused_net import FusedPolicyValueNet
-
-        for conv in (("miopen", "mfma_small") if batch <= 16 else ("miopen", "mfma", "tower", "tower_wg")):
-            try:
-                fused = FusedPolicyValueNet(model.to(device), conv=conv).to(device)
-            except E.EngineError:
-                if conv != "miopen":  # filter count without an MFMA instantiation
-                    continue
-                raise
-            t = _time_forward(fused, x)
-            if verbose:
-                print(f"[nn_tune] batch={batch} nchw fused epilogues, conv={conv}: {t * 1e3:.3f} ms")
-            if t < best_t:
-                best, best_t = fused, t
-    if dtype == torch.float16:  # fp16 tower, two boards per workgroup (csrc/bo_tower_h.h); it takes the float32 planes itself
-        from . import engine as E
-        from .fused_net import FusedPolicyValueNet
-
-        try:
-            fused = FusedPolicyValueNet(model.to(device), conv="tower_f16").to(device)
-            t = _time_forward(fused, x)
-            if verbose:
-                print(f"[nn_tune] batch={batch} fp16 tower: {t * 1e3:.3f} ms")
-            if t < best_t:
-                best = fused
-        except E.EngineError:
-            pass
-    return best

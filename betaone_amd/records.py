@@ -110,16 +110,33 @@ def compact_path(data_dir: str, iteration: int, rank: int = 0) -> str:
     return os.path.join(data_dir, f"iter_{iteration}", f"games_rank{rank}{COMPACT_SUFFIX}")
 
 
+def complete_prefix_bytes(path: str) -> int:
+    """Length of the leading run of complete games in the compact file `path` (0 for a missing / empty file): where the next
+    game has to be appended.  A writer killed inside a write leaves a partial record behind the last complete game."""
+    import os
+
+    if not os.path.exists(path):
+        return 0
+    with open(path, "rb") as fh:
+        idx = scan_games(fh.read())
+    return idx[-1][2] + idx[-1][3] if idx else 0
+
+
 def save_games(path: str, finished: Sequence, append: bool = True) -> int:
     """Append the compact records of `finished` (rollout.FinishedGame objects, or already packed bytes) to `path`; returns the
-    bytes written.  One write per call, flushed: a reader (or a resume) never sees half a game from a finished call."""
+    bytes written.  One write per call, flushed: a reader (or a resume) never sees half a game from a finished call.  A
+    partial record left at the tail by a writer that was killed inside its write is cut off first (the file is truncated to
+    its last complete game): bytes appended behind it would be read as the rest of that record, and every later game lost."""
     import os
 
     blob = b"".join(f if isinstance(f, (bytes, bytearray)) else pack_game(f) for f in finished)
     if not blob:
         return 0
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-    with open(path, "ab" if append else "wb") as fh:
+    keep = complete_prefix_bytes(path) if append else 0
+    with open(path, "r+b" if (append and os.path.exists(path)) else "wb") as fh:
+        fh.truncate(keep)
+        fh.seek(keep)
         fh.write(blob)
         fh.flush()
         os.fsync(fh.fileno())
@@ -247,6 +264,16 @@ def all_gather_games(finished: Sequence, device: Optional[torch.device] = None, 
     return games
 
 
+class ExchangeError(RuntimeError):
+    """The record exchange cannot complete (a peer rank died or hangs): the caller must stop -- exit non-zero -- not wait."""
+
+
+def exchange_timeout_s() -> float:
+    import os
+
+    return float(os.environ.get("BETAONE_EXCHANGE_TIMEOUT", "120"))
+
+
 class _Gather:
     """One all-gather in flight: `src` (uint8 / int64, equal length on every rank) -> host array, without a blocking call
     on the issuing side.  RCCL: H2D, collective and D2H all run on a side stream behind an event, through pinned and
@@ -291,12 +318,27 @@ class _Gather:
     def done(self) -> bool:
         return self.event.query() if self.event is not None else self.work.is_completed()
 
-    def result(self) -> np.ndarray:
-        """[world, n] view of the staging buffer: consume (copy out) before the next gather of the same dtype starts."""
+    def result(self, timeout_s: Optional[float] = None) -> np.ndarray:
+        """[world, n] view of the staging buffer: consume (copy out) before the next gather of the same dtype starts.  A
+        collective that is still unfinished after `timeout_s` (a peer rank died or hangs mid-period) raises ExchangeError
+        instead of waiting for ever: RCCL path = the completion event is polled; gloo = the work handle's own timeout."""
+        import datetime
+        import time as _time
+
+        timeout_s = exchange_timeout_s() if timeout_s is None else float(timeout_s)
         if self.event is not None:
-            self.event.synchronize()  # already complete when a whole exchange period of plies ran in between
+            deadline = _time.monotonic() + timeout_s  # already complete when a whole exchange period of plies ran in between
+            while not self.event.query():
+                if _time.monotonic() > deadline:
+                    raise ExchangeError(f"record all-gather still unfinished after {timeout_s:.0f} s: a peer rank died or hangs")
+                _time.sleep(0.0005)
         else:
-            self.work.wait()
+            try:
+                ok = self.work.wait(datetime.timedelta(seconds=timeout_s))
+            except Exception as ex:  # gloo reports a dead peer ("Connection closed by peer") or its timeout as an exception
+                raise ExchangeError(f"record all-gather failed: {type(ex).__name__}: {str(ex).splitlines()[0] if str(ex) else ''}") from ex
+            if ok is False:
+                raise ExchangeError(f"record all-gather still unfinished after {timeout_s:.0f} s: a peer rank died or hangs")
         return self.h_out.numpy().reshape(self.world, self.n)
 
 
@@ -309,12 +351,15 @@ class PeriodicGameExchange:
         tick t+2  : payload read, records of ALL ranks returned from push()
     Nothing in a ply's loop blocks on a collective: RCCL work, its H2D / D2H staging and their completion event live on a side
     stream, and a period in which no rank finished a game costs one 8-byte all-gather and no payload step.  `flush()`
-    drains the pipeline at the end (three ticks, the same on every rank)."""
+    drains the pipeline at the end (three ticks, the same on every rank).  A rank that dies mid-period does not hang the others:
+    a tick that finds its collective still unfinished after `timeout_s` raises ExchangeError (the caller exits non-zero; it
+    must not re-exec a process that has touched the GPU -- start a fresh child or exit)."""
 
-    def __init__(self, device: Optional[torch.device] = None, group=None, every: int = 16):
+    def __init__(self, device: Optional[torch.device] = None, group=None, every: int = 16, timeout_s: Optional[float] = None):
         import torch.distributed as dist
 
         self.group, self.every = group, max(1, int(every))
+        self.timeout_s = timeout_s  # None = BETAONE_EXCHANGE_TIMEOUT (default 120 s); a collective unfinished for that long raises ExchangeError
         self.dist_on = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.dist_on else 1
         nccl = self.dist_on and dist.get_backend(group) == "nccl"
@@ -338,14 +383,14 @@ class PeriodicGameExchange:
         if self._payload is not None:
             sizes, g = self._payload
             self.blocked_ticks += 0 if g.done() else 1
-            rows = g.result()
+            rows = g.result(self.timeout_s)
             for r in range(self.world):
                 out.extend(unpack_games(rows[r, :sizes[r]].tobytes()))
             self._payload = None
         if self._sizes is not None:
             payload, g = self._sizes
             self.blocked_ticks += 0 if g.done() else 1
-            sizes = [int(x) for x in g.result().reshape(-1)]
+            sizes = [int(x) for x in g.result(self.timeout_s).reshape(-1)]
             self._sizes = None
             mx = max(sizes)
             if mx > 0:  # every rank sees the same sizes, so every rank takes (or skips) the payload step together

@@ -96,14 +96,30 @@ def _fen_meta(fen: Optional[str]):
     return full, white
 
 
+def _on_main(fn):
+    """Entry points of a Rollout that was given its own stream issue everything they launch to that stream."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        if self._main is None:
+            return fn(self, *a, **kw)
+        with torch.cuda.stream(self._main):
+            return fn(self, *a, **kw)
+    return wrapped
+
+
 class Rollout:
     def __init__(self, model: torch.nn.Module, n_games: int, *, num_simulations: int = 250, mcts_batch_size: int = 96,
                  cpuct: float = 1.0, widen_coeff: float = 1.5, dirichlet_alpha: float = 0.1,
                  dirichlet_epsilon: float = 0.25, max_plies: Optional[int] = None, max_game_moves: int = 16384,
                  temperature=(30, 1.0, 0.1), device: str = "cuda:0", use_graph: bool = True, autocast: bool = False,
                  rng_mode: str = "python", policy_kind: str = "logits", fast: bool = False, leaves_per_step: int = 16,
-                 fast_arena_granules: int = 0):
-        self.device = E.runtime_device(device)  # 'cuda' -> cuda:<current device>: engine, NN rows and model on ONE GPU
+                 fast_arena_granules: int = 0, stream: Optional["torch.cuda.Stream"] = None):
+        self.device = E.runtime_device(device)
+        # `stream`: every launch of this Rollout goes to that HIP stream (CohortRollout: one stream per cohort of games, so that
+        # one cohort's tower runs while another's tree step / head kernels / host turn are in progress); None = torch's current one
+        self._main = stream  # 'cuda' -> cuda:<current device>: engine, NN rows and model on ONE GPU
         self.G = int(n_games)
         self.S, self.B = int(num_simulations), int(mcts_batch_size)
         self.alpha = float(dirichlet_alpha)
@@ -150,6 +166,7 @@ class Rollout:
         self.ply_profile = [] if _os.environ.get("BO_PLY_PROFILE", "0") not in ("", "0") else None  # [(phase, seconds)] of the native ply path
         self._t_ret = None
         self._begun = None          # (n_legal, terminal, go) of searches already begun by the previous selfplay_turn
+        self._turn_due = None       # go[G] of a ply whose searches ply_begin enqueued and ply_end has not turned yet
         self._begun_want = None
         self._active = np.zeros(G, dtype=bool)
         self._plies = np.zeros(G, dtype=np.int64)
@@ -166,6 +183,20 @@ class Rollout:
         self._pi_val = np.zeros((G, 256, max(1, self._pk)), np.float32)
         self._out = dict(n=np.zeros(G, np.int32), idx=np.zeros((G, E.RES_CAP), np.int32), val=np.zeros((G, E.RES_CAP), np.float32),
                          best_idx=np.zeros(G, np.int32), action=np.zeros(G, np.int32))
+        self._watch_net()
+
+    def _watch_net(self):
+        """The evaluate stage's own fault word (the split-precision tower: an activation beyond the fp16 range) travels with every
+        result block the engine fetches (bo_engine_watch): checked once per ply by _check_watch, behind the copy the ply waits for
+        anyway -- a net that saturates stops the run before a record made from its evaluations is handed out."""
+        inner = getattr(self.model, "net", self.model)
+        ptr = getattr(inner, "overflow_word_ptr", None)
+        self._watch_msg = getattr(inner, "OVERFLOW_MESSAGE", "the evaluate stage reported a fault")
+        self.eng.watch(ptr() if ptr is not None else 0)
+
+    def _check_watch(self):
+        if self.eng.watch_seen():
+            raise E.EngineError(self._watch_msg)
 
     # ---- evaluate + step -------------------------------------------------------------------------
     def _stream(self) -> int:
@@ -248,8 +279,12 @@ class Rollout:
         g[0].replay()
 
     # ---- game slots ---------------------------------------------------------------------------------
+    @_on_main
     def start_games(self, slots: Sequence[int], game_ids: Sequence[int], rngs: Sequence, fens: Optional[Sequence] = None,
                     moves: Optional[Sequence] = None):
+        self._start_games(slots, game_ids, rngs, fens, moves)
+
+    def _start_games(self, slots, game_ids, rngs, fens=None, moves=None):  # (on torch's current stream: the refill path runs it on the side stream)
         self.eng.reset(list(slots), fens, moves, stream=self._stream())
         for i, s in enumerate(slots):
             fen = fens[i] if fens is not None else None
@@ -268,6 +303,7 @@ class Rollout:
                 self.eng.rng_seed(s, int(rngs[i]))
 
     # ---- one search for every active slot (run_mcts) ----------------------------------------------------
+    @_on_main
     def search(self, go: np.ndarray, n_legal: np.ndarray, terminal: np.ndarray) -> Dict[str, np.ndarray]:
         t0 = time.perf_counter()
         noise = None
@@ -289,9 +325,12 @@ class Rollout:
                 break
             burst = 1
         self.n_sims += int(np.count_nonzero(go)) * self.S
-        return self.eng.result(self._stream())
+        res = self.eng.result(self._stream())
+        self._check_watch()
+        return res
 
     # ---- one ply for every active game (the body of self_play.py:101-184) --------------------------------
+    @_on_main
     def play_ply(self, on_finished: Optional[Callable[[FinishedGame], None]] = None,
                  refill: Optional[Callable[[int], Optional[tuple]]] = None,
                  while_searching: Optional[Callable[[], None]] = None) -> int:
@@ -319,7 +358,7 @@ class Rollout:
                 if nxt is not None:
                     new_slots.append(g); ids.append(nxt[0]); rngs.append(nxt[1]); fens.append(nxt[2])
             if new_slots:
-                self.start_games(new_slots, ids, rngs, fens)
+                self._start_games(new_slots, ids, rngs, fens)
                 n_legal, terminal, ply = self.eng.root_info(self._stream())
         go = np.array([1 if (self.games[g] is not None and terminal[g] == 0) else 0 for g in range(self.G)], dtype=np.int32)
         if not go.any():
@@ -395,6 +434,20 @@ class Rollout:
 
     def _play_ply_native(self, on_finished, refill, while_searching=None) -> int:
         """play_ply with the per-move host work done inside the library (same streams, same results)."""
+        if self._turn_due is not None:  # (a ply begun through ply_begin and not ended yet)
+            self.ply_end()
+        if not self.ply_begin(on_finished, refill, while_searching):
+            return 0
+        return self.ply_end()
+
+    @_on_main
+    def ply_begin(self, on_finished=None, refill=None, while_searching=None) -> bool:
+        """First half of a ply (native RNG mode): enqueue the ply's searches -- every evaluate -> step iteration the searches are
+        expected to need -- hand finished games over and refill their slots beside the search, run the caller's `while_searching`,
+        and RETURN WITHOUT WAITING for the device.  True: a turn is due (ply_end); False: no game searched this ply.
+        play_ply() is ply_begin() + ply_end(); CohortRollout drives several Rollouts by ending one cohort's ply and beginning
+        its next before it turns to the next cohort, so the device always holds enqueued work of the other cohorts."""
+        assert self.rng_mode == "native" and self._turn_due is None
         eng, G = self.eng, self.G
         stream = self._stream()
         t0 = time.perf_counter()
@@ -434,7 +487,7 @@ class Rollout:
             self._finish_and_refill(done, term, on_finished, refill)
             if while_searching is not None:
                 while_searching()
-            return 0
+            return False
         if not lazy:
             self._run_search_steps(poll=False)
         if done:
@@ -447,8 +500,19 @@ class Rollout:
         if while_searching is not None:
             while_searching()
         if self.ply_profile is not None: self._pp("while_searching")
+        self._turn_due = go
+        return True
+
+    @_on_main
+    def ply_end(self) -> int:
+        """Second half of a ply: wait for the searches ply_begin enqueued (the ply's ONE host round trip), sample and play the
+        moves, begin the next searches on the device and enqueue their root evaluation.  Returns the number of moves played."""
+        eng, G = self.eng, self.G
+        stream = self._stream()
+        go, self._turn_due = self._turn_due, None
         self.n_sims += int(np.count_nonzero(go)) * self.S
         t0 = time.perf_counter()
+        if self.ply_profile is not None: self._pp_t = t0
         move_number = self._start_full + (self._plies + self._start_black) // 2   # board.fullmove_number, self_play.py:104
         want_next = self._active & ((self._plies + go) < self.max_game_moves)     # the next call's `want`
         self.host_seconds += time.perf_counter() - t0
@@ -460,6 +524,7 @@ class Rollout:
             if out is not None:
                 break
             self._eval_and_step()  # a search needed one more evaluation than expected
+        self._check_watch()  # (the evaluate stage's fault word arrived with the result block)
         if self.ply_profile is not None: self._pp("turn")
         t0 = time.perf_counter()
         actions = out["action"]
@@ -512,8 +577,6 @@ class Rollout:
         return n_moves
 
     def _finish_and_refill(self, done, term, on_finished, refill) -> None:
-        if done:
-            self.check_net()  # (finished games' records are about to be handed over: not from a net that had to saturate an activation)
         new_slots, ids, seeds, fens = [], [], [], []
         for g in done:
             fin = self._finish(g, int(term[g]))
@@ -525,7 +588,7 @@ class Rollout:
             if nxt is not None:
                 new_slots.append(g); ids.append(nxt[0]); seeds.append(nxt[1]); fens.append(nxt[2])
         if new_slots:
-            self.start_games(new_slots, ids, seeds, fens)  # (bo_games_reset synchronises its stream before it returns)
+            self._start_games(new_slots, ids, seeds, fens)  # (bo_games_reset synchronises its stream before it returns)
 
     def _finish(self, g: int, terminal: int) -> FinishedGame:
         gs = self.games[g]
@@ -558,6 +621,7 @@ class Rollout:
             self.eng.encode_game(g, first_ply, n_records, out.data_ptr(), self._stream())
         return out[:n_records]
 
+    @_on_main
     def retire(self, g: int, on_finished: Optional[Callable[[FinishedGame], None]] = None,
                refill: Optional[Callable[[int], Optional[tuple]]] = None) -> None:
         """Take the game in slot g out of play between two plies -- the reference's per-game abort paths
@@ -573,6 +637,7 @@ class Rollout:
         if nxt is not None:
             self.start_games([g], [nxt[0]], [nxt[1]], [nxt[2]])  # its first search is begun by the next play_ply
 
+    @_on_main
     def swap_model(self, model: torch.nn.Module) -> None:
         """Replace the evaluate stage between two plies (weights handed over by the training side, main.py:147-148): every
         evaluation from the next play_ply on runs `model`; the captured graphs hold the old module's kernels and weight
@@ -584,13 +649,19 @@ class Rollout:
         self._graphs_n = {}
         self._logits = self._value = None
         self._fwd_early = False  # (a root evaluation enqueued early ran the old weights: it is repeated with the new ones)
+        self._watch_net()
 
+    @_on_main
     def check_net(self):
-        """Raise if the evaluate stage reports a fault of its own (the split-precision tower: an activation beyond the fp16 range)."""
+        """Raise if the evaluate stage reports a fault of its own (the split-precision tower: an activation beyond the fp16 range).
+        Reads the word on torch's current stream -- the one the forwards run on -- and waits for it: for the end of a run; during
+        play the word is checked with every ply's result block (_check_watch)."""
+        self._check_watch()
         chk = getattr(getattr(self.model, "net", self.model), "check_overflow", None)
         if chk is not None:
             chk()
 
+    @_on_main
     def close(self):
         self._graph = self._fgraph = None
         self._graphs_n = {}
@@ -598,3 +669,148 @@ class Rollout:
             self.check_net()
         finally:
             self.eng.close()
+
+
+class _CohortEngines:
+    """The `eng` of a CohortRollout: the per-slot queries callers make on Rollout.eng, spread over the cohorts' engines."""
+
+    def __init__(self, parts):
+        self._parts = parts
+
+    @staticmethod
+    def _beside(p) -> int:  # a stream that does not queue behind the cohort's enqueued searches (the status words are sticky ORs)
+        return p._side.cuda_stream if p._side is not None else 0
+
+    def status_bits(self, stream: int = 0) -> np.ndarray:
+        return np.concatenate([p.eng.status_bits(self._beside(p)) for p in self._parts])
+
+    def status(self, stream: int = 0) -> Dict[str, np.ndarray]:
+        st = [p.eng.status(self._beside(p)) for p in self._parts]
+        return {k: np.concatenate([s[k] for s in st]) for k in st[0]}
+
+    @staticmethod
+    def describe_status(bits: int) -> str:
+        return E.Engine.describe_status(bits)
+
+    def check_status(self):
+        for p in self._parts:
+            p.eng.check_status()
+
+
+class CohortRollout:
+    """G concurrent games as K cohorts of G / K slots, each cohort a Rollout of its own (engine, NN rows, captured graphs) on its
+    own HIP stream, driven round-robin by one host thread with the plies software-pipelined: a call of play_ply ENDS each
+    cohort's outstanding ply (the one host round trip: results, sampled moves, the next searches begun) and at once BEGINS its next
+    one (every evaluate -> step iteration enqueued) before it turns to the next cohort.  While the host waits for cohort k and while
+    cohort k runs its tree step, head kernels and ply boundary, the other cohorts' towers are on the device -- one cohort's serial
+    chain tower -> heads -> step -> tower no longer leaves the matrix pipe dark.  Games are independent (the reference runs
+    them in separate processes, main.py:160-175), so every game plays exactly the moves it plays in a single Rollout: same
+    engine code, same per-game RNG streams; only WHEN a game's kernels run differs.
+
+    Slot s belongs to cohort s // (G / K).  The interface is Rollout's (start_games / play_ply / retire / swap_model / close,
+    games, n_sims, ...); play_ply returns the moves played by the plies it ENDED (0 on the first call, which only begins).
+    `drain()` ends the outstanding plies without beginning new ones."""
+
+    def __init__(self, model, n_games: int, cohorts: int = 2, **kw):
+        K = int(cohorts)
+        if K < 1 or n_games % K:
+            raise ValueError(f"CohortRollout: {n_games} games do not split into {K} equal cohorts")
+        if kw.get("rng_mode", "native") != "native":
+            raise ValueError("CohortRollout needs rng_mode='native' (the ply is split into ply_begin / ply_end)")
+        kw["rng_mode"] = "native"
+        self.device = E.runtime_device(kw.get("device", "cuda:0"))
+        self.G, self.K, self.Gc = int(n_games), K, int(n_games) // K
+        models = list(model) if isinstance(model, (list, tuple)) else [model] * K
+        # (cohort 0 keeps torch's current stream semantics only when it is alone; with K > 1 every cohort gets a stream of its own)
+        self.parts: List[Rollout] = []
+        for k in range(K):
+            st = torch.cuda.Stream(self.device) if (K > 1 and self.device.type == "cuda") else None
+            self.parts.append(Rollout(models[k], self.Gc, stream=st, **kw))
+        if K > 1 and self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)  # (buffers zeroed on the constructing stream are used on the cohorts' streams from here on)
+        self.eng = _CohortEngines(self.parts)
+        p0 = self.parts[0]
+        self.S, self.B, self.L, self.fast = p0.S, p0.B, p0.L, p0.fast
+        self.expected_evals, self.rng_mode, self.max_game_moves = p0.expected_evals, p0.rng_mode, p0.max_game_moves
+        self.ply_profile = None
+
+    # ---- Rollout's counters and per-slot views --------------------------------------------------------------------------------
+    n_sims = property(lambda self: sum(p.n_sims for p in self.parts))
+    n_plies = property(lambda self: sum(p.n_plies for p in self.parts))
+    n_forward = property(lambda self: sum(p.n_forward for p in self.parts))
+    host_seconds = property(lambda self: sum(p.host_seconds for p in self.parts))
+    games = property(lambda self: [g for p in self.parts for g in p.games])
+
+    @property
+    def use_graph(self):
+        return self.parts[0].use_graph
+
+    @use_graph.setter
+    def use_graph(self, v):
+        for p in self.parts:
+            p.use_graph = v
+
+    def _split(self, slots):
+        """global slots -> {cohort: [positions in `slots`]}"""
+        by = {}
+        for i, s in enumerate(slots):
+            by.setdefault(int(s) // self.Gc, []).append(i)
+        return by
+
+    def start_games(self, slots, game_ids, rngs, fens=None, moves=None):
+        for k, pos in self._split(slots).items():
+            pick = lambda seq: [seq[i] for i in pos] if seq is not None else None
+            self.parts[k].start_games([int(slots[i]) - k * self.Gc for i in pos], pick(game_ids), pick(rngs), pick(fens), pick(moves))
+
+    def _callbacks(self, k, on_finished, refill):
+        base = k * self.Gc
+
+        def fin_cb(fin):
+            fin.slot += base  # (the slot the CALLER knows; encode_finished_in_slot maps it back)
+            on_finished(fin)
+
+        return (fin_cb if on_finished is not None else None), ((lambda s: refill(s + base)) if refill is not None else None)
+
+    def play_ply(self, on_finished=None, refill=None, while_searching=None) -> int:
+        moved = 0
+        for k, p in enumerate(self.parts):
+            if p._turn_due is not None:
+                moved += p.ply_end()
+            fin_cb, refill_cb = self._callbacks(k, on_finished, refill)
+            p.ply_begin(fin_cb, refill_cb)
+        if while_searching is not None:
+            while_searching()
+        return moved
+
+    def drain(self) -> int:
+        """End every outstanding ply (no new searches are enqueued): the state then is what a sequence of whole plies leaves."""
+        return sum(p.ply_end() for p in self.parts if p._turn_due is not None)
+
+    def encode_finished_in_slot(self, g: int, n_records: int, first_ply: int = 0):
+        return self.parts[g // self.Gc].encode_finished_in_slot(g % self.Gc, n_records, first_ply)
+
+    def retire(self, g: int, on_finished=None, refill=None) -> None:
+        k = g // self.Gc
+        fin_cb, refill_cb = self._callbacks(k, on_finished, refill)
+        if self.parts[k]._turn_due is not None:
+            self.parts[k].ply_end()  # (a game leaves between two plies: its cohort's outstanding ply is ended first)
+        self.parts[k].retire(g % self.Gc, fin_cb, refill_cb)
+
+    def swap_model(self, model) -> None:
+        models = list(model) if isinstance(model, (list, tuple)) else [model] * self.K
+        for p, m in zip(self.parts, models):
+            p.swap_model(m)
+
+    def check_net(self):
+        for p in self.parts:
+            p.check_net()
+
+    def close(self):
+        err = None
+        for p in self.parts:
+            try:
+                p.close()
+            except Exception as ex:  # (close every engine; report the first fault)
+                err = err or ex
+        if err is not None:
+            raise err

@@ -30,15 +30,24 @@ def game_seed(iteration: int, game_id: int) -> int:
 
 
 def pending_game_ids(data_dir: str, iteration: int, n_games: int, records: str = "pickle") -> List[int]:
-    """Game ids of the iteration with no result on disk yet (main.py:26-36): no game_{j}.pkl and, when compact records are
-    written, no record in any games_rank*.bog either."""
+    """Game ids of the iteration whose result is not on disk yet (main.py:26-36) in the form(s) `records` asks for: "pickle" =
+    no game_{j}.pkl; "compact" = no record in any games_rank*.bog; "both" = missing in EITHER form (a run killed between a
+    game's two writes plays that game again and writes only the form that is missing)."""
     d = os.path.join(data_dir, f"iter_{iteration}")
-    have = set()
+    compact = set()
     if records in ("compact", "both"):
         from betaone_amd import records as R
 
-        have = R.game_ids_on_disk(data_dir, iteration)
-    return [j for j in range(n_games) if j not in have and not os.path.exists(os.path.join(d, f"game_{j}.pkl"))]
+        compact = R.game_ids_on_disk(data_dir, iteration)
+
+    def pickled(j):
+        return os.path.exists(os.path.join(d, f"game_{j}.pkl"))
+
+    if records == "compact":
+        return [j for j in range(n_games) if j not in compact]
+    if records == "both":
+        return [j for j in range(n_games) if not (j in compact and pickled(j))]
+    return [j for j in range(n_games) if not pickled(j)]
 
 
 class ModelFileWatcher:
@@ -102,19 +111,24 @@ def run_iteration(model, iteration: int, n_games: int, n_slots: int, rank: int =
     done: Dict[int, int] = {}
     path = R.compact_path(config.DATA_DIR, iteration, rank)
 
+    have_compact = R.game_ids_on_disk(config.DATA_DIR, iteration) if records == "both" else set()
+
     def on_game(fin):  # one append per finished game: a killed run keeps every game it finished
         done[fin.game_id] = len(fin.pis)
-        if records != "pickle" and len(fin.pis):
+        if records != "pickle" and len(fin.pis) and fin.game_id not in have_compact:
             R.save_games(path, [fin])
+
+    def on_records(game_id, data):  # the reference's pickle, written the moment the game's dense tuples exist (not after the
+        if data:                    # whole iteration: a killed run keeps these too, and the tuples need not stay in memory)
+            self_play.save_game_data(data, iteration, game_id)
+        return []
 
     results = self_play.run_self_play_games(model, todo, seeds=[game_seed(iteration, j) for j in todo],
                                             n_slots=min(n_slots, len(todo)), on_game=on_game, dense=records != "compact",
-                                            reload_model=reload_model)
+                                            reload_model=reload_model, on_records=on_records if records != "compact" else None)
     for j, data in results.items():
         if data is None:
             done.pop(j, None)  # aborted game (self_play.py:167): no record
-        elif records != "compact" and data:
-            self_play.save_game_data(data, iteration, j)
     done = {j: n for j, n in done.items() if n}
     dt = time.time() - t0
     plies = sum(done.values())

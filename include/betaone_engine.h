@@ -28,7 +28,7 @@ extern "C" {
  * [G][BO_PROF_SLOTS = 16] counters, the BO_TOWER_WINOGRAD packed-weight K order for 128 filters is winograd_k_order's;
  * 3: fast-mode arenas are allocated in 128-byte granules of 8 records, bo_fast_stats counts granules).  A caller checks
  * bo_abi_version() == BO_ABI_VERSION before anything else (tests/c_abi_smoke.c). */
-#define BO_ABI_VERSION 3
+#define BO_ABI_VERSION 4
 #define BO_PROF_SLOTS 16             /* uint64 counters per game returned by bo_debug_profile */
 #define BO_NUM_ACTIONS 4672          /* config.NUM_ACTIONS, config.py:29 */
 #define BO_INPUT_CHANNELS 120        /* config.INPUT_CHANNELS, config.py:28 */
@@ -363,6 +363,14 @@ void bo_nn_tower_destroy(bo_tower *tower);
  * is wrong.  *overflow_out = 1 if that happened in any forward since the last call (the flag is cleared), 0 otherwise (always 0 for
  * the other algorithms).  Synchronises `stream`.  A net that trips it needs the fp32-pipe tower (BETAONE_F32_TOWER=fp32). */
 int bo_nn_tower_status(bo_tower *tower, int32_t *overflow_out, void *stream);
+/* (ABI 4) Device address of that status word, for bo_engine_watch: the self-play loop then checks it with every ply's result block
+ * instead of only when finished games are handed over (the reference has no counterpart: its float32 net cannot saturate). */
+int bo_nn_tower_word(bo_tower *tower, void **dev_word_out);
+/* (ABI 4) Let the engine's result kernels copy `*dev_word` (any int32 device word, NULL: none) behind the result block, so that
+ * bo_search_result / bo_selfplay_turn bring it to the host in the round trip they make anyway; bo_engine_watch_seen returns the OR
+ * of the values seen since the last call with clear != 0.  Nothing is enqueued and nothing waits in either call. */
+int bo_engine_watch(bo_engine *engine, int32_t *dev_word);
+int bo_engine_watch_seen(bo_engine *engine, int32_t *seen_out, int32_t clear);
 
 #ifdef __cplusplus
 }

@@ -415,3 +415,25 @@ def check_long_terminal_runs_vs_oracle(backend, case):
     exp = {"/".join(k): list(v) for k, v in O.canonical_tree(r["nodes"]).items()}
     assert canonical_tree(eng.debug_tree(0)) == exp
     assert int(eng.status()["term_sims"][0]) == r["n_terminal_sims"]
+
+
+def check_watched_status_word(backend):
+    """bo_engine_watch: an int32 device word named to the engine arrives with every fetched result block (no copy or wait of its
+    own); bo_engine_watch_seen reports the OR of the values seen and clears on request.  This is how the self-play loop learns
+    once per ply that the split-precision tower had to saturate an activation."""
+    eng = make_engine(backend, 2, dict(num_simulations=20, batch_size=8, dirichlet_alpha=0.0))
+    eng.reset([0, 1])
+    sr = Searcher(backend, eng)
+    ev = lambda planes: (np.full((1, E.NUM_ACTIONS), 1.0 / E.NUM_ACTIONS, np.float32), np.zeros(1, np.float32))
+    word = Buf(backend, (4,))          # any 4-byte device word (its bits are what is watched)
+    eng.watch(word.ptr)
+    go = np.ones(2, np.int32)
+    sr.search(go, [ev, ev], [None, None], 0.0)
+    assert eng.watch_seen() == 0
+    word.set(np.array([1, 0, 0, 0], np.int32).view(np.float32))
+    sr.search(go, [ev, ev], [None, None], 0.0)
+    assert eng.watch_seen(clear=False) == 1 and eng.watch_seen() == 1 and eng.watch_seen() == 0
+    eng.watch(0)                          # unwatched again: the word's value no longer arrives
+    sr.search(go, [ev, ev], [None, None], 0.0)
+    assert eng.watch_seen() == 0
+    eng.close()

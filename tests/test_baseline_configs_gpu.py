@@ -112,16 +112,17 @@ LATE_GAME_FENS = [
 ]
 
 
-def _bench_like_run(net, G, sims, max_game_moves, preroll, steps, watch, record):
+def _bench_like_run(net, G, sims, max_game_moves, preroll, steps, watch, record, cohorts=1):
     """bench.py's own step loop (bench.Driver: staggered pre-roll, finished games exported and their slots refilled on the side
     stream inside the run, n-iteration graphs, native RNG), with every 8th refilled game starting from a late-game position.
     record=True: the same run with the evaluate stage launched one iteration at a time and the seam of the `watch` slots read
     back.  Returns (finished games by id, start FEN by id, recorder)."""
     import bench
-    from betaone_amd.rollout import Rollout
+    from betaone_amd.rollout import CohortRollout, Rollout
 
-    ro = Rollout(net, G, num_simulations=sims, mcts_batch_size=96, device="cuda:0", use_graph=True, rng_mode="native",
-                 policy_kind="probs", max_game_moves=max_game_moves)
+    kw = dict(num_simulations=sims, mcts_batch_size=96, device="cuda:0", use_graph=True, rng_mode="native", policy_kind="probs",
+              max_game_moves=max_game_moves)
+    ro = CohortRollout(net, G, cohorts=cohorts, **kw) if cohorts > 1 else Rollout(net, G, **kw)
     rec = SeamRecorder(ro, watch) if record else None
     fens = {}
 
@@ -137,9 +138,11 @@ def _bench_like_run(net, G, sims, max_game_moves, preroll, steps, watch, record)
     drv.preroll(preroll, G)
     for _ in range(steps):
         drv.step()
+    if cohorts > 1:
+        ro.drain()
     ro.eng.check_status()
     slot_of = {gid: f.slot for gid, f in fins.items()}
-    n_graphs = len(ro._graphs_n)
+    n_graphs = sum(len(p._graphs_n) for p in ro.parts) if cohorts > 1 else len(ro._graphs_n)
     ro.close()
     return fins, fens, rec, slot_of, n_graphs
 
@@ -246,6 +249,39 @@ def test_bench_steady_state_path_with_refills_and_late_game_positions_matches_or
             assert rz == z and np.signbit(rz) == np.signbit(z), gid
         n_checked += 1
     assert n_checked >= 8 and late, (n_checked, late)
+
+
+@pytest.mark.parametrize("cohorts", [2, 4])
+def test_cohorts_on_their_own_streams_finish_the_games_of_the_single_rollout(env, cohorts):
+    """rollout.CohortRollout (bench.py --cohorts K): the 256 slots as K cohorts, each with its own engine, HIP stream and captured
+    graphs, the plies software-pipelined (ply_end of one ply followed at once by ply_begin of the next, cohort after cohort).
+    Games are independent (main.py:160-175), so the bench-like steady-state run -- refills on the side streams, late-game start
+    positions, game ids handed out in the order slots fall free -- must finish the very games the single Rollout finishes (which
+    the test above replays through the oracle): moves, pi bits, z, terminal code, for every game id both runs finished."""
+    import torch
+    import network
+    from betaone_amd.fused_net import FusedPolicyValueNet
+
+    config = env
+    config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 8, 2, 128
+    G, SIMS, LIMIT, PREROLL, STEPS = 256, 800, 28, 40, 36
+    torch.manual_seed(0)
+    net = FusedPolicyValueNet(network.PolicyValueNet().to("cuda:0").eval(), conv="tower_split").to("cuda:0")
+    one, fens1, _, _, _ = _bench_like_run(net, G, SIMS, LIMIT, PREROLL, STEPS, (), record=False)
+    many, fensk, _, slots, n_graphs = _bench_like_run(net, G, SIMS, LIMIT, PREROLL, STEPS + 1, (), record=False, cohorts=cohorts)
+    assert n_graphs >= cohorts and set(slots.values()) == set(range(G))   # every cohort replayed graphs; finished games carry global slots
+    # a game's id, seed and start position are handed out when a slot falls free: the ORDER in which slots are refilled differs
+    # between the two schedules only among games that end in the same ply, so ids can be attached to different start positions
+    # there -- compare every id whose start position is the same in both runs (all first occupants, and nearly all refills)
+    both = [gid for gid in one if gid in many and fens1.get(gid) == fensk.get(gid)]
+    assert len(both) >= G and sum(1 for gid in both if gid >= G) >= G // 4
+    assert sum(1 for gid in both if one[gid].terminal != 0) >= 4
+    for gid in both:
+        a, b = one[gid], many[gid]
+        assert list(a.moves) == list(b.moves) and a.terminal == b.terminal and a.outcome == b.outcome, gid
+        assert len(a.pis) == len(b.pis) == len(a.moves) - a.first_ply, gid
+        for (ia, va), (ib, vb) in zip(a.pis, b.pis):
+            assert ia.tolist() == ib.tolist() and va.view(np.uint32).tolist() == vb.view(np.uint32).tolist(), gid
 
 
 def test_iterations_in_one_graph_launch_play_the_same_games(env):

@@ -1,5 +1,5 @@
 """CPU tests of the N>1 path: games shard by id over ranks (no data-path collective), finished games
-travel as compact records through ONE all-gather (gloo here, RCCL on the GPUs).  world_size = 2 and 4."""
+travel as compact records through ONE all-gather (gloo here, RCCL on the GPUs).  world_size = 2, 4 and 8."""
 import os
 import socket
 import sys
@@ -56,6 +56,8 @@ def _worker(rank, world, port, out_dir, every=0):
         ticks = n_steps // every
         assert ex.n_size_gathers == ticks + 1                     # one 8-byte all-gather per period (+ the flush's)
         assert ex.n_payload_gathers <= ticks + 1 and ex.n_payload_gathers >= 1
+        if every > n_steps:  # (8, 16): the node's shape with the bench's default period -- everything travels in the final drain
+            assert ex.n_size_gathers == 1 and ex.n_payload_gathers == 1
         if every == 1:  # periods in which NO rank finished a game took no payload step
             assert ex.n_payload_gathers <= world
     assert not any(g is not None for g in ro.games)
@@ -72,7 +74,7 @@ def _worker(rank, world, port, out_dir, every=0):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,every", [(2, 0), (2, 1), (2, 3), (4, 2)])
+@pytest.mark.parametrize("world,every", [(2, 0), (2, 1), (2, 3), (4, 2), (8, 1), (8, 16)])
 def test_ranks_shard_games_and_all_gather_records(tmp_path, world, every):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path), every), nprocs=world, join=True)
@@ -156,3 +158,56 @@ def test_launch_ranks_starts_one_process_per_rank(tmp_path):
     bad = tmp_path / "bad.py"
     bad.write_text("import sys; sys.exit(3)\n")
     assert launch_ranks(2, [str(bad)]) != 0
+
+
+_DYING_RANK = r"""
+import os, sys, time
+sys.path[:0] = [{root!r}]
+import numpy as np
+import torch.distributed as dist
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo", rank=rank, world_size=2)
+from betaone_amd import records
+ex = records.PeriodicGameExchange(every=1, timeout_s=float(sys.argv[1]))
+ex.push([])                       # tick 0: both ranks start the 8-byte size gather
+if rank == 1:
+    if sys.argv[2] == "die":
+        os._exit(7)               # dies mid-period, without a word to its peers
+    time.sleep(600)               # ... or hangs
+t0 = time.monotonic()
+try:
+    for _ in range(4):
+        ex.push([])               # rank 0 carries on: its next collective has no partner
+        time.sleep(0.05)
+except records.ExchangeError as e:
+    print("ExchangeError after %.1f s: %s" % (time.monotonic() - t0, e), flush=True)
+    os._exit(3)                   # loud: a non-zero exit, no lingering in destroy_process_group
+os._exit(0)
+"""
+
+
+@pytest.mark.parametrize("how", ["die", "hang"])
+def test_a_rank_that_dies_or_hangs_mid_period_makes_its_peer_fail_loudly_not_wait(tmp_path, how):
+    """PeriodicGameExchange must not hang when a rank dies (or stops answering) inside an exchange
+    period.  Rank 1 goes away after the first size gather; rank 0's next ticks find their collective without a partner and
+    raise records.ExchangeError within the timeout (gloo reports the closed connection at once; a hanging peer runs into
+    `timeout_s`), and the process exits non-zero."""
+    import subprocess
+    import time
+
+    script = tmp_path / "rank.py"
+    script.write_text(_DYING_RANK.format(root=ROOT))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2")
+        procs.append(subprocess.Popen([sys.executable, str(script), "4", how], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    t0 = time.monotonic()
+    try:
+        out0, _ = procs[0].communicate(timeout=90)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert procs[0].returncode == 3, out0[-2000:]
+    assert "ExchangeError" in out0 and time.monotonic() - t0 < 60

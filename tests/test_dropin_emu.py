@@ -33,7 +33,7 @@ from oracle import oracle as O  # noqa: E402
 def _emu_backend(request):
     """Every test of this file drives the drop-in modules on the wave-emulator build of the device code (patched in from
     the outside, see engine_harness.emulator_backend) -- except those marked `product_backend`."""
-    saved = {k: getattr(config, k) for k in ("NUM_SIMULATIONS", "MCTS_BATCH_SIZE", "MAX_GAME_MOVES", "DIRICHLET_ALPHA", "DATA_DIR")}
+    saved = {k: getattr(config, k) for k in ("NUM_SIMULATIONS", "MCTS_BATCH_SIZE", "MAX_GAME_MOVES", "DIRICHLET_ALPHA", "DATA_DIR", "COHORTS")}
     mcts._ctx.clear()
     if request.node.get_closest_marker("product_backend"):
         yield
@@ -286,6 +286,54 @@ def test_compact_records_on_disk_yield_what_the_reference_pickles_yield(tmp_path
         assert a[j]["moves"].tolist() == b[j]["moves"].tolist() and bytes(a[j]["positions"]) == bytes(b[j]["positions"])
 
 
+def test_compact_file_survives_a_writer_killed_inside_a_write_and_both_mode_resumes_the_missing_form(tmp_path):
+    """(i) a writer killed inside its write leaves a partial record at the tail; the next append must cut it off
+    first, or every game appended behind it is read as the rest of that record and lost (N games, file chopped mid-record, M
+    games appended -> N - 1 + M games back).  (ii) --records both: a game is finished only when BOTH forms are on disk; a run
+    killed between the compact append and the pickle plays the game again and writes only the pickle (no duplicate record)."""
+    from betaone_amd import records as R
+    from betaone_amd import selfplay_main as M
+
+    config.NUM_SIMULATIONS, config.MCTS_BATCH_SIZE, config.MAX_GAME_MOVES = 30, 16, 6
+    config.DATA_DIR = str(tmp_path / "data")
+    model = FakeNet(scale=2.0, salt=4)
+    done = M.run_iteration(model, 3, n_games=4, n_slots=2, log=lambda s: None, records="both")
+    assert sorted(done) == [0, 1, 2, 3]
+    d = tmp_path / "data" / "iter_3"
+    assert sorted(p.name for p in d.glob("*.pkl")) == [f"game_{j}.pkl" for j in range(4)] and not list(d.glob("*.tmp"))
+    path = R.compact_path(config.DATA_DIR, 3, 0)
+    blob = open(path, "rb").read()
+    idx = R.scan_games(blob)
+    assert len(idx) == 4
+    order = [g[0] for g in idx]
+    # (i) chop the file in the middle of its last record, then append two more games
+    last_off, last_size = idx[-1][2], idx[-1][3]
+    with open(path, "r+b") as fh:
+        fh.truncate(last_off + last_size // 2)
+    assert R.complete_prefix_bytes(path) == last_off and len(R.load_games(path)) == 3
+    extra = R.unpack_games(blob)[:2]
+    packed = [blob[g[2]:g[2] + g[3]] for g in idx[:2]]
+    R.save_games(path, packed)
+    got = R.load_games(path)
+    assert [g["game_id"] for g in got] == order[:3] + order[:2]                 # N - 1 + M, nothing hidden behind the partial record
+    assert os.path.getsize(path) == last_off + sum(len(b) for b in packed)
+    assert got[-1]["moves"].tolist() == extra[1]["moves"].tolist()
+    # (ii) the chopped game (compact form lost, pickle present) and a game whose pickle is lost (compact present) are both pending
+    with open(path, "wb") as fh:
+        fh.write(blob[:last_off])
+    lost_compact, lost_pickle = order[3], order[0]
+    os.remove(d / f"game_{lost_pickle}.pkl")
+    assert sorted(M.pending_game_ids(config.DATA_DIR, 3, 4, records="both")) == sorted([lost_compact, lost_pickle])
+    assert M.pending_game_ids(config.DATA_DIR, 3, 4, records="compact") == [lost_compact]
+    again = M.run_iteration(model, 3, n_games=4, n_slots=2, log=lambda s: None, records="both")
+    assert sorted(again) == sorted([lost_compact, lost_pickle])
+    ids = [g["game_id"] for g in R.load_games(path)]
+    assert sorted(ids) == [0, 1, 2, 3] and len(ids) == 4                         # no duplicate record of the game that only lacked its pickle
+    assert (d / f"game_{lost_pickle}.pkl").exists() and M.pending_game_ids(config.DATA_DIR, 3, 4, records="both") == []
+    replayed = {g["game_id"]: g for g in R.load_games(path)}[lost_compact]
+    assert replayed["moves"].tolist() == R.unpack_games(blob)[3]["moves"].tolist()  # per-game seeds: the replay is the same game
+
+
 def test_weights_are_swapped_inside_a_living_process(tmp_path):
     """Row f4: main.py:147-148 hands new weights to its workers through best_model.pth.  ModelFileWatcher notices the changed file,
     run_self_play_games swaps the evaluate stage between two plies (Rollout.swap_model): plies before the swap are those of the
@@ -336,6 +384,33 @@ def test_weights_are_swapped_inside_a_living_process(tmp_path):
     assert w2.poll() is None and w2.n_reloads == 0
     torch.save(Net(3).state_dict(), path)
     assert int(w2.poll().w.item()) == 3 and w2.n_reloads == 1
+
+
+@pytest.mark.parametrize("cohorts", [2, 3])
+def test_cohorts_of_games_play_exactly_the_games_one_rollout_plays(cohorts):
+    """rollout.CohortRollout (config.COHORTS): the resident games as K phase-shifted cohorts, each a Rollout with its own engine,
+    driven through ply_begin / ply_end with the plies software-pipelined.  Games are independent (main.py:160-175 runs them in
+    separate processes), so every game must come out exactly as from one Rollout: states, pi, z -- with refills, games of uneven
+    length (a position that is over at once, a game from a FEN) and more games than slots."""
+    config.NUM_SIMULATIONS, config.MCTS_BATCH_SIZE, config.MAX_GAME_MOVES = 30, 16, 7
+    model = FakeNet(scale=3.0, salt=9)
+    ids = list(range(11))
+    seeds = [40 + i for i in ids]
+    mate = "k6R/8/1K6/8/8/8/8/8 b - - 1 1"
+    fens = [None, None, mate, "r3k2r/p1ppqpb1/bn2pnp1/3PN3/1p2P3/2N2Q1p/PPPBBPPP/R3K2R w KQkq - 0 1"] + [None] * 7
+    seen = []
+    one = self_play.run_self_play_games(model, ids, seeds=seeds, n_slots=6, start_fens=fens)
+    config.COHORTS = cohorts
+    try:
+        many = self_play.run_self_play_games(model, ids, seeds=seeds, n_slots=6, start_fens=fens, on_game=lambda fin: seen.append((fin.game_id, fin.slot)))
+    finally:
+        config.COHORTS = 1
+    assert sorted(many) == sorted(one) == ids and many[2] == one[2] == []
+    assert sorted(g for g, _ in seen) == ids and {s for _, s in seen} <= set(range(6)) and len({s for _, s in seen}) > 6 // cohorts  # global slot numbers
+    for g in ids:
+        assert len(many[g]) == len(one[g])
+        for (s1, p1, z1), (s2, p2, z2) in zip(many[g], one[g]):
+            assert torch.equal(s1, s2) and np.array_equal(p1, p2) and z1 == z2 and np.signbit(z1) == np.signbit(z2)
 
 
 def test_one_overlong_game_does_not_end_the_others():

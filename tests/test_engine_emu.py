@@ -58,3 +58,7 @@ def test_games_from_special_start_positions_match_oracle(backend):
 @pytest.mark.parametrize("case", EC.LONG_TERMINAL_RUN_CASES, ids=lambda c: f"{c[0].split()[0][:12]}-{c[2]}")
 def test_long_runs_of_terminal_simulations_match_oracle(backend, case):
     EC.check_long_terminal_runs_vs_oracle(backend, case)
+
+
+def test_watched_status_word_arrives_with_the_result_block(backend):
+    EC.check_watched_status_word(backend)

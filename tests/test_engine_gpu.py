@@ -192,11 +192,15 @@ def test_mfma_conv3x3_matches_float64_convolution(backend, shape):
 
 
 @pytest.mark.parametrize("conv", ["miopen", "mfma", "mfma_small", "tower", "tower_wg", "tower_split"])
-@pytest.mark.parametrize("size", [(3, 1, 64), (8, 2, 128), (2, 2, 256), (0, 3, 128), (4, 0, 64)])
+@pytest.mark.parametrize("size", [(3, 1, 64), (8, 2, 128), (15, 5, 256), (2, 2, 256), (0, 3, 128), (4, 0, 64)])
 def test_fused_epilogue_net_matches_plain_net(backend, size, conv):
     """csrc/bo_nn_fused.h, csrc/bo_conv.h, csrc/bo_tower.h, csrc/bo_tower_s.h: conv (MIOpen, the fp32-MFMA direct kernel, the
     whole tower as one persistent kernel on the fp32 matrix pipe, or on the fp16 pipe with (hi, lo) operand pairs) with fused
-    epilogues == PolicyValueNet.forward, within 1e-5.  33 and 300 boards: fewer and more boards than CUs (the tower kernel loops)."""
+    epilogues == PolicyValueNet.forward, within 1e-5.  33 and 300 boards: fewer and more boards than CUs (the tower kernel loops).
+    The three sizes the reference's own outputs were recorded for (fixture G1: 3+1x64, 8+2x128 and the reference-default 15+5x256,
+    config.py:44-46) are also compared with THOSE, through every kernel route that takes the size (1e-4, north_star)."""
+    if size == (15, 5, 256) and conv == "miopen":
+        pytest.skip("(the library route at the reference-default size is the plain net itself; the hand-written routes are the subject)")
     if conv in ("tower", "tower_wg") and size[2] == 256:
         pytest.skip("two padded 256-channel boards do not fit in LDS; the tower kernel is for 64/128 filters")
     if conv == "tower_split" and size[2] == 64:
@@ -224,7 +228,7 @@ def test_fused_epilogue_net_matches_plain_net(backend, size, conv):
                 la, va = net(xx)
                 lb, vb = fused(xx)
                 assert (la - lb).abs().max().item() < 1e-5 and (va - vb).abs().max().item() < 1e-5
-        name = {(3, 1, 64): "3+1x64", (8, 2, 128): "8+2x128"}.get(size)
+        name = {(3, 1, 64): "3+1x64", (8, 2, 128): "8+2x128", (15, 5, 256): "15+5x256"}.get(size)
         if name:  # and against the reference's own outputs (fixture G1)
             assert np.abs(l1[:3].cpu().numpy() - z[f"logits_{name}"]).max() < 1e-4
             assert np.abs(v1[:3].cpu().numpy() - z[f"value_{name}"]).max() < 1e-4
@@ -515,6 +519,10 @@ def test_full_games_to_termination_match_oracle(backend):
 
 def test_edge_cases_maximum_sizes_and_error_paths(backend):
     EC.check_edge_cases(backend)
+
+
+def test_watched_status_word_arrives_with_the_result_block(backend):
+    EC.check_watched_status_word(backend)
 
 
 def test_evaluate_stage_is_routed_by_shape_to_the_hand_written_kernels(backend):

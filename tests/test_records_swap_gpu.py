@@ -1,0 +1,193 @@
+"""GPU tests of the rows SURVEY.md section 8 marks "next" that had only emulator coverage:
+  f3  records.save_games / CompactDataset on the product library (device="cuda:0"), bit-equal to the reference's pickles;
+  f4  Rollout.swap_model under captured hipGraphs (graphs dropped and re-captured): plies before the swap are the old weights',
+      plies after it the new weights' -- each compared with a run that never swaps;
+  the split-precision tower's fault word reaches the self-play loop with the ply's own result block."""
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture()
+def env():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from betaone_amd import dropin
+    from betaone_amd import engine as E
+
+    E.load_hip_library()
+    dropin.install()
+    import config
+
+    keys = ("RESIDUAL_BLOCKS", "SE_RESIDUAL_BLOCKS", "CONV_FILTERS", "NUM_SIMULATIONS", "MCTS_BATCH_SIZE", "DATA_DIR", "MAX_GAME_MOVES")
+    saved = {k: getattr(config, k) for k in keys}
+    yield config
+    for k, v in saved.items():
+        setattr(config, k, v)
+
+
+def _net(config, size, seed):
+    import torch
+    import network
+
+    config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = size
+    torch.manual_seed(seed)
+    return network.PolicyValueNet().to("cuda").eval()
+
+
+def test_compact_dataset_on_the_gpu_yields_what_the_reference_pickles_yield(env, tmp_path):
+    """Row f3 on the product path: selfplay_main --records both on cuda:0 writes the reference's pickles (dense planes from
+    bo_k_encode_game in the slot) and the compact records; records.CompactDataset(device="cuda:0") re-expands the planes with
+    bo_records_encode on the GPU and yields, item by item, ChessDataset.__getitem__'s triple (train.py:179-184) bit for bit."""
+    import torch
+    from betaone_amd import records as R
+    from betaone_amd import selfplay_main as M
+
+    config = env
+    model = _net(config, (3, 1, 64), 0)
+    config.NUM_SIMULATIONS, config.MCTS_BATCH_SIZE, config.MAX_GAME_MOVES = 100, 96, 14
+    config.DATA_DIR = str(tmp_path / "data")
+    done = M.run_iteration(model, 2, n_games=20, n_slots=8, log=lambda s: None, records="both")
+    assert sorted(done) == list(range(20))
+    path = R.compact_path(config.DATA_DIR, 2, 0)
+    games = R.load_games(path)
+    assert sorted(g["game_id"] for g in games) == list(range(20))
+    plies = sum(done.values())
+    assert os.path.getsize(path) < 400 * plies and R.complete_prefix_bytes(path) == os.path.getsize(path)
+    ds = R.CompactDataset([path], device="cuda:0", cache_games=3)
+    assert len(ds) == plies
+    k = 0
+    for g in games:
+        dense = pickle.load(open(tmp_path / "data" / "iter_2" / f"game_{g['game_id']}.pkl", "rb"))
+        assert len(dense) == g["n_plies"] == done[g["game_id"]]
+        for state, policy, value in dense:
+            got = ds[k]
+            assert got[0].dtype == torch.float32 and got[0].device.type == "cpu" and torch.equal(got[0], state)
+            assert torch.equal(got[1], torch.from_numpy(policy).float())
+            assert torch.equal(got[2], torch.tensor([value], dtype=torch.float32))
+            assert np.signbit(got[2].numpy()[0]) == np.signbit(np.float32(value))
+            k += 1
+    assert k == len(ds)
+    # random access across the small cache (games are re-expanded on demand), and a DataLoader batch forms
+    order = np.random.RandomState(0).permutation(len(ds))[:40]
+    first = [g for g in games]
+    for i in order:
+        gi, ki = ds.game_of(int(i))
+        dense = pickle.load(open(tmp_path / "data" / "iter_2" / f"game_{first[gi]['game_id']}.pkl", "rb"))
+        assert torch.equal(ds[int(i)][0], dense[ki][0])
+    batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=16, shuffle=False)))
+    assert tuple(batch[0].shape) == (16, 120, 8, 8) and tuple(batch[1].shape) == (16, 4672) and tuple(batch[2].shape) == (16, 1)
+    # a writer killed inside a write: the partial record is cut off by the next append
+    blob = open(path, "rb").read()
+    idx = R.scan_games(blob)
+    with open(path, "r+b") as fh:
+        fh.truncate(idx[-1][2] + 50)
+    R.save_games(path, [blob[idx[0][2]:idx[0][2] + idx[0][3]]])
+    assert [g["game_id"] for g in R.load_games(path)] == [g[0] for g in idx[:-1]] + [idx[0][0]]
+
+
+def _play(ro, n_plies, fins, upto=None):
+    for _ in range(n_plies):
+        ro.play_ply(on_finished=fins.append)
+
+
+def test_swap_model_under_captured_graphs_plays_old_weights_before_and_new_weights_after(env):
+    """Row f4 on the product path (main.py:147-148 hands new weights to living workers): Rollout.swap_model between two plies
+    with hipGraphs on -- the captured graphs hold the old module's kernels and weight addresses, so they are dropped and
+    re-captured.  Run C swaps after 3 plies.  Its first 3 plies equal run A (old weights, never swapping); its plies 4..7 equal
+    run D, which never swaps either: the NEW weights from C's own positions and RNG states at the swap."""
+    import torch
+    from betaone_amd import engine as E
+    from betaone_amd.nn_tune import best_inference_copy
+    from betaone_amd.rollout import Rollout
+
+    config = env
+    G, K, T = 24, 3, 7
+    old = best_inference_copy(_net(config, (2, 1, 128), 1), G, "cuda:0")
+    new = best_inference_copy(_net(config, (2, 1, 128), 2), G, "cuda:0")
+    assert old.conv == new.conv == "tower_split"
+    kw = dict(num_simulations=100, mcts_batch_size=32, device="cuda:0", use_graph=True, rng_mode="native", max_game_moves=T,
+              policy_kind="probs")
+    ids = list(range(G))
+
+    def run(model, plies, swap_to=None, swap_at=None, moves=None, rng_states=None):
+        ro = Rollout(model, G, **kw)
+        ro.start_games(ids, ids, [1000 + i for i in ids], None, moves)
+        if rng_states is not None:
+            for g, st in enumerate(rng_states):
+                ro.eng.rng_set_state(g, st)
+        fins, snap = [], None
+        for p in range(plies):
+            if swap_at is not None and p == swap_at:
+                torch.cuda.synchronize()
+                snap = [ro.eng.rng_get_state(g) for g in range(G)]
+                assert ro._graphs_n or ro._graph is not None          # graphs were captured and used before the swap ...
+                ro.swap_model(swap_to)
+                assert ro._graph is None and not ro._graphs_n          # ... and are gone after it
+            ro.play_ply(on_finished=fins.append)
+        if swap_at is not None:
+            assert ro._graph is not None or ro._graphs_n              # re-captured with the new module
+        while any(g is not None for g in ro.games):
+            ro.play_ply(on_finished=fins.append)
+        ro.close()
+        return {f.game_id: f for f in fins}, snap
+
+    a, _ = run(old, T + 1)
+    c, snap = run(old, T + 1, swap_to=new, swap_at=K)
+    assert sorted(a) == sorted(c) == ids
+    prefixes = [" ".join(E.move_to_uci(m) for m in c[g].moves[:K]) for g in ids]
+    d, _ = run(new, T + 1 - K, moves=prefixes, rng_states=snap)
+    differs = 0
+    for g in ids:
+        assert len(c[g].moves) == len(a[g].moves) == T and len(d[g].moves) == T and d[g].first_ply == K
+        assert c[g].moves[:K] == a[g].moves[:K]                                        # before the swap: the old weights' plies
+        for k in range(K):
+            assert c[g].pis[k][0].tolist() == a[g].pis[k][0].tolist() and c[g].pis[k][1].tobytes() == a[g].pis[k][1].tobytes()
+        assert c[g].moves[K:] == d[g].moves[K:]                                        # after it: the new weights' plies
+        for k in range(K, T):
+            assert c[g].pis[k][0].tolist() == d[g].pis[k - K][0].tolist() and c[g].pis[k][1].tobytes() == d[g].pis[k - K][1].tobytes()
+        differs += c[g].moves[K:] != a[g].moves[K:]
+    assert differs >= G // 2  # the two nets do play differently
+
+
+def test_a_net_that_saturates_the_split_tower_stops_self_play_at_that_ply(env):
+    """VERDICT round 3, next 4(iv) / ADVICE: the split-precision tower's fault word is checked once per ply, behind the copy the
+    ply waits for anyway (bo_engine_watch) -- not only when finished games are handed over: a net whose activations leave the fp16
+    range raises in its first ply, before any record exists; an ordinary net plays on."""
+    import torch
+    from betaone_amd import engine as E
+    from betaone_amd.nn_tune import best_inference_copy
+    from betaone_amd.rollout import Rollout
+
+    config = env
+    net = _net(config, (2, 1, 128), 3)
+    G = 24
+    kw = dict(num_simulations=64, mcts_batch_size=32, device="cuda:0", use_graph=True, rng_mode="native", max_game_moves=4, policy_kind="probs")
+    fine = Rollout(best_inference_copy(net, G, "cuda:0"), G, **kw)
+    fine.start_games(list(range(G)), list(range(G)), list(range(G)))
+    fins = []
+    for _ in range(5):
+        fine.play_ply(on_finished=fins.append)
+    assert len(fins) == G
+    fine.close()
+    with torch.no_grad():
+        net.conv_input.weight.mul_(3.0e5)
+    big = best_inference_copy(net, G, "cuda:0")
+    assert big.conv == "tower_split" and big.overflow_word_ptr() != 0
+    ro = Rollout(big, G, **kw)
+    ro.start_games(list(range(G)), list(range(G)), list(range(G)))
+    handed = []
+    with pytest.raises(E.EngineError, match="fp16 range"):
+        for _ in range(3):
+            ro.play_ply(on_finished=handed.append)
+    assert ro.n_plies == 0 and not handed   # stopped inside the first ply: no move played from a saturated evaluation, no record handed out
+    ro._graph = ro._fgraph = None
+    ro._graphs_n = {}
+    ro.eng.close()
