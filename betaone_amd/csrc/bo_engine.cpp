@@ -14,6 +14,7 @@
 #include "bo_tower_h.h"
 #include "bo_tower_s.h"
 #include "bo_heads.h"
+#include "bo_tower_b1.h"
 #include "bo_rt.h"
 #include "bo_hostrng.h"
 
@@ -1438,6 +1439,105 @@ extern "C" int bo_nn_tower_word(bo_tower *t, void **dev_word_out) {
     *dev_word_out = t->overflow;
     return BO_OK;
 #endif
+}
+
+// ---- the tower of one board (a few boards) as ONE launch spread over the chip (bo_tower_b1.h): uci.py's batch-1 evaluations ------
+struct bo_b1_s {
+#if !defined(BO_WAVE_EMU)
+    int device = 0, C = 0, n_layers = 0, max_batch = 0;
+    bo_b1_layer *layers = nullptr;  // device table
+    float *bufs = nullptr, *pool = nullptr;
+    unsigned *sync = nullptr;       // [max_batch counters | status word | padding], a block of its own (zeroed before every launch)
+    size_t sync_bytes = 0;
+#endif
+};
+
+extern "C" int bo_nn_b1_create(const bo_b1_layer_desc *layers, int n_layers, int channels, int max_batch, int device, bo_b1 **out) {
+#if defined(BO_WAVE_EMU)
+    (void)layers; (void)n_layers; (void)channels; (void)max_batch; (void)device; (void)out;
+    return fail(BO_E_CONFIG, "bo_nn_b1 is a gfx950-only kernel");
+#else
+    if (!layers || !out || n_layers < 1 || n_layers > BO_B1_MAX_LAYERS || (n_layers & 1) == 0) return fail(BO_E_ARG, "bo_nn_b1_create: 1 + 2 x blocks layers");
+    if (channels != 64 && channels != 128 && channels != 256) return fail(BO_E_CONFIG, "bo_nn_b1: 64, 128 or 256 filters");
+    const int tiles = (channels / 16) * 4;
+    if (max_batch < 1 || max_batch * tiles > 256) return fail(BO_E_CONFIG, "bo_nn_b1: (filters / 16) x 4 x batch workgroups must be resident at once (<= 256)");
+    std::vector<bo_b1_layer> tab((size_t)n_layers);
+    for (int l = 0; l < n_layers; l++) {
+        const bo_b1_layer_desc &d = layers[l];
+        if (!d.weights_dev || !d.bias_dev) return fail(BO_E_ARG, "bo_nn_b1_create: null weights");
+        const int want_cin = l == 0 ? 128 : channels, want_mode_lo = (l == 0 || (l & 1)) ? 0 : 1;
+        if (d.c_in != want_cin || d.c_in_x < 1 || d.c_in_x > d.c_in || (l > 0 && d.c_in_x != channels)) return fail(BO_E_ARG, "bo_nn_b1_create: layer channel counts");
+        if ((l == 0 || (l & 1)) ? d.mode != 0 : (d.mode != 1 && d.mode != 2)) return fail(BO_E_ARG, "bo_nn_b1_create: layer modes must be 0, then (0, 1 | 2) per block");
+        (void)want_mode_lo;
+        if (d.mode == 2 && (!d.se_w1_dev || !d.se_w2_dev || d.se_hidden < 1 || d.se_hidden > 16)) return fail(BO_E_CONFIG, "bo_nn_b1: SE hidden width 1..16");
+        tab[l].w = (const bo_f32x4 *)d.weights_dev; tab[l].bias = d.bias_dev; tab[l].se_w1 = d.se_w1_dev; tab[l].se_w2 = d.se_w2_dev;
+        tab[l].cin = d.c_in; tab[l].cin_x = d.c_in_x; tab[l].mode = d.mode; tab[l].se_h = d.se_hidden;
+    }
+    RT((int)hipSetDevice(device));
+    bo_b1 *t = new bo_b1();
+    t->device = device; t->C = channels; t->n_layers = n_layers; t->max_batch = max_batch;
+    t->sync_bytes = (((size_t)max_batch + 1) * 4 + 63) / 64 * 64;
+    int rc = (int)hipMalloc((void **)&t->layers, tab.size() * sizeof(bo_b1_layer));
+    if (!rc) rc = (int)hipMemcpy(t->layers, tab.data(), tab.size() * sizeof(bo_b1_layer), hipMemcpyHostToDevice);
+    if (!rc) rc = (int)hipMalloc((void **)&t->bufs, (size_t)3 * max_batch * channels * 64 * 4);
+    if (!rc) rc = (int)hipMalloc((void **)&t->pool, (size_t)max_batch * 4 * channels * 4);
+    if (!rc) rc = (int)hipMalloc((void **)&t->sync, t->sync_bytes);
+    if (!rc) rc = (int)hipMemset(t->sync, 0, t->sync_bytes);
+    if (rc) {
+        (void)hipFree(t->layers); (void)hipFree(t->bufs); (void)hipFree(t->pool); (void)hipFree(t->sync);
+        delete t;
+        return fail(BO_E_HIP, std::string("bo_nn_b1_create: ") + hipGetErrorString((hipError_t)rc));
+    }
+    *out = t;
+    return BO_OK;
+#endif
+}
+
+// One evaluation's tower: x [batch,120,8,8] -> y [batch,C,8,8] on `stream`.  The handle's buffers are used by the launch: one launch
+// of a handle at a time (launches on ONE stream are in order; two streams need two handles).  Capturable (memset node + kernel node).
+extern "C" int bo_nn_b1_forward(bo_b1 *t, const float *x_dev, float *y_dev, int batch, void *stream) {
+#if defined(BO_WAVE_EMU)
+    (void)t; (void)x_dev; (void)y_dev; (void)batch; (void)stream;
+    return fail(BO_E_CONFIG, "bo_nn_b1 is a gfx950-only kernel");
+#else
+    if (!t || !x_dev || !y_dev) return fail(BO_E_ARG, "null argument");
+    if (batch < 1 || batch > t->max_batch) return fail(BO_E_ARG, "bo_nn_b1_forward: batch beyond the handle's max_batch");
+    hipStream_t st = (hipStream_t)stream;
+    // counters and the status word start from zero in EVERY launch (a memset node when captured; a block of its own, a multiple of 16 bytes)
+    RT((int)hipMemsetAsync(t->sync, 0, t->sync_bytes, st));
+    bo_b1_args a;
+    a.x = x_dev; a.y = y_dev; a.bufs = t->bufs; a.pool = t->pool; a.sync = t->sync; a.layers = t->layers; a.n_layers = t->n_layers; a.B = batch;
+    // the status word sits behind max_batch counters whatever the batch: the kernel indexes it by B, so hand it the handle's layout
+    a.sync = t->sync + (t->max_batch - batch);
+    const dim3 grid((unsigned)((t->C / 16) * 4), (unsigned)batch);
+    if (t->C == 256) hipLaunchKernelGGL(bo_k_tower_b1<256>, grid, dim3(256), 0, st, a);
+    else if (t->C == 128) hipLaunchKernelGGL(bo_k_tower_b1<128>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(bo_k_tower_b1<64>, grid, dim3(256), 0, st, a);
+    RT((int)hipGetLastError());
+    return BO_OK;
+#endif
+}
+
+// *code_out = 0, or 1 + the phase of a hand-off wait that gave up in the LAST launch (the evaluation's output is then invalid).
+// Synchronises `stream` (the stream the launches went to).
+extern "C" int bo_nn_b1_status(bo_b1 *t, int32_t *code_out, void *stream) {
+#if defined(BO_WAVE_EMU)
+    (void)t; (void)code_out; (void)stream;
+    return fail(BO_E_CONFIG, "bo_nn_b1 is a gfx950-only kernel");
+#else
+    if (!t || !code_out) return fail(BO_E_ARG, "bad arguments");
+    RT(rt_d2h(code_out, t->sync + t->max_batch, 4, stream));
+    RT(rt_sync(stream));
+    return BO_OK;
+#endif
+}
+
+extern "C" void bo_nn_b1_destroy(bo_b1 *t) {
+#if !defined(BO_WAVE_EMU)
+    if (!t) return;
+    (void)hipFree(t->layers); (void)hipFree(t->bufs); (void)hipFree(t->pool); (void)hipFree(t->sync);
+#endif
+    delete t;
 }
 
 // ---- policy FC + softmax + value head behind the tower: two launches (bo_heads.h) ------------------------------------

@@ -42,8 +42,9 @@ _TABLES = {
     #                 "engine" = the step kernel's own softmax over the logits row (hardware exp; within 1e-5 relative)
     #   COHORTS       run_self_play_games: the resident games as this many phase-shifted cohorts, each on its own HIP stream
     #                 (rollout.CohortRollout: one cohort's tower overlaps another's tree step, heads and ply boundary); 1 = one Rollout.
-    #                 Results do not depend on it (games are independent).  Used when it divides the slot count.
-    "engine": dict(AUTOCAST=False, SEARCH_MODE="reference", FAST_LEAVES=16, ENGINE_MAX_PLIES=None, POLICY_SOFTMAX="torch", COHORTS=1),
+    #                 Results do not depend on it (games are independent).  Used when it divides the slot count and leaves every
+    #                 cohort at least 64 slots (below that a cohort's kernels no longer fill their share of the CUs).
+    "engine": dict(AUTOCAST=False, SEARCH_MODE="reference", FAST_LEAVES=16, ENGINE_MAX_PLIES=None, POLICY_SOFTMAX="torch", COHORTS=2),
 }
 for _group in _TABLES.values():
     globals().update(_group)

@@ -48,6 +48,11 @@ class BoPosition(C.Structure):
                 ("ep_key", C.c_int32), ("halfmove_clock", C.c_int32), ("fullmove_number", C.c_int32)]
 
 
+class BoB1LayerDesc(C.Structure):
+    _fields_ = [("weights_dev", C.c_void_p), ("bias_dev", C.c_void_p), ("se_w1_dev", C.c_void_p), ("se_w2_dev", C.c_void_p),
+                ("c_in", C.c_int32), ("c_in_x", C.c_int32), ("mode", C.c_int32), ("se_hidden", C.c_int32)]
+
+
 class BoNode(C.Structure):
     _fields_ = [("parent", C.c_int32), ("n_visits", C.c_int32), ("first_child", C.c_int32), ("n_children", C.c_int32),
                 ("q_value", C.c_float), ("prior", C.c_float), ("move", C.c_int32), ("terminal", C.c_int32)]
@@ -90,6 +95,10 @@ _SYMBOLS = {
     "bo_event_pair_overhead": (C.c_int, [_F64P, C.c_int32, C.c_void_p]),
     "bo_nn_tower_status": (C.c_int, [C.c_void_p, _I32P, C.c_void_p]),
     "bo_nn_tower_word": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bo_nn_b1_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "bo_nn_b1_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "bo_nn_b1_status": (C.c_int, [C.c_void_p, _I32P, C.c_void_p]),
+    "bo_nn_b1_destroy": (None, [C.c_void_p]),
     "bo_engine_watch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bo_engine_watch_seen": (C.c_int, [C.c_void_p, _I32P, C.c_int32]),
     "bo_fast_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _I32P, C.c_int32, _F64P, C.POINTER(C.c_int64),

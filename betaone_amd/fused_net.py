@@ -12,6 +12,9 @@ elementwise launches PyTorch issues (bias, ReLU, residual add, SE pooling / FCs 
 
   conv="mfma_small": the small-batch form of "mfma" (bo_k_conv3x3_small: a board's layer is spread over (c_out/16) x 4
                  workgroups) for uci.py's single-position searches (BASELINE.json configs[3]).
+  conv="tower_b1": the whole tower of ONE board (up to 256 / ((filters/16)*4) boards) as ONE launch of the same (c_out/16) x 4 workgroups
+                 per board, the layers handed over inside the launch (csrc/bo_tower_b1.h) instead of one launch per layer: uci.py's
+                 single-position searches (BASELINE.json configs[3]); larger batches fall back to "mfma_small" launches.
   conv="tower":  input conv + all residual blocks are ONE persistent kernel that keeps each board's activations in
                  LDS (csrc/bo_tower.h); 64 or 128 filters.
   conv="tower_wg": the same with Winograd F(2x2,3x3) convolutions (csrc/bo_tower_wg.h), 2.25x fewer MFMA cycles.
@@ -142,7 +145,7 @@ class FusedPolicyValueNet(nn.Module):
         self.conv = conv
         # policy FC + softmax + value head as one kernel behind the Winograd tower (needs contiguous float32 Linear weights of the
         # reference's head shapes: 2 policy planes, 32 value planes, 256 hidden units)
-        self.fused_heads = conv in ("tower_wg", "tower", "mfma", "mfma_small", "tower_f16", "tower_split")
+        self.fused_heads = conv in ("tower_wg", "tower", "mfma", "mfma_small", "tower_b1", "tower_f16", "tower_split")
         f = net.for_inference(dtype=torch.float32, channels_last=False)
         dev = next(f.parameters()).device
         if dev.type != "cuda":
@@ -188,10 +191,10 @@ class FusedPolicyValueNet(nn.Module):
                 self.packed.append((p1, p2))
             self.zero_bias = nn.Parameter(torch.zeros(self.c, device=dev), requires_grad=False)
             self.layout = "nchw+mfma"
-        elif conv == "mfma_small":
+        elif conv in ("mfma_small", "tower_b1"):
             c = self.w_in.shape[0]
             if c not in (64, 128, 256) or self.w_in.shape[1] != 120:
-                raise E.EngineError("conv='mfma_small' supports 120 input planes and 64, 128 or 256 filters")
+                raise E.EngineError(f"conv='{conv}' supports 120 input planes and 64, 128 or 256 filters")
             self.c = c
             w0 = torch.zeros((c, 128, 3, 3), device=dev)
             w0[:, :120] = self.w_in
@@ -204,7 +207,9 @@ class FusedPolicyValueNet(nn.Module):
                 self.register_parameter(f"blk{i}_p2", p2)
                 self.packed.append((p1, p2))
             self.zero_bias = nn.Parameter(torch.zeros(c, device=dev), requires_grad=False)
-            self.layout = "nchw+mfma_small"
+            self.layout = "nchw+" + conv
+            if conv == "tower_b1":
+                self._build_b1(dev)
         elif conv in ("tower", "tower_wg"):
             self._build_tower(dev, winograd=conv == "tower_wg")
             self.layout = "nchw+" + conv
@@ -215,7 +220,58 @@ class FusedPolicyValueNet(nn.Module):
             self._build_tower_split(dev)
             self.layout = "nchw+tower_split"
         elif conv != "miopen":
-            raise ValueError("conv must be 'miopen', 'mfma', 'mfma_small', 'tower', 'tower_wg', 'tower_split' or 'tower_f16'")
+            raise ValueError("conv must be 'miopen', 'mfma', 'mfma_small', 'tower_b1', 'tower', 'tower_wg', 'tower_split' or 'tower_f16'")
+
+    def _build_b1(self, dev):
+        """bo_nn_b1_create over the SAME device tensors the per-layer route uses (pack_conv_weight_small layout): the handle keeps
+        their addresses, the module keeps them alive."""
+        c = self.c
+        descs = []
+
+        def desc(wp, bias, c_in, c_in_x, mode, se=None):
+            d = E.BoB1LayerDesc(wp.data_ptr(), bias.data_ptr(), se[0].data_ptr() if se else None, se[1].data_ptr() if se else None,
+                                c_in, c_in_x, mode, se[0].shape[0] if se else 0)
+            descs.append(d)
+
+        desc(self.p_in, self.b_in, 128, 120, 0)
+        for (w1, b1, w2, b2, se), (p1, p2) in zip(self.blocks, self.packed):
+            if se is not None and se[0].shape[0] > 16:
+                raise E.EngineError("conv='tower_b1' supports SE hidden widths up to 16")
+            desc(p1, b1, c, c, 0)
+            desc(p2, b2, c, c, 2 if se is not None else 1, se)
+        arr = (E.BoB1LayerDesc * len(descs))(*descs)
+        self._b1_max = 256 // ((c // 16) * 4)
+        handle = C.c_void_p()
+        rc = self.lib.bo_nn_b1_create(arr, len(descs), c, self._b1_max, dev.index if dev.index is not None else torch.cuda.current_device(), C.byref(handle))
+        if rc:
+            raise E.EngineError(self.lib.bo_last_error().decode())
+        self._b1, self._b1_dev = handle, dev
+
+    def _tower_b1(self, x):
+        """Tower output [B, C, 8, 8] from ONE launch (bo_nn_b1_forward); batches beyond the resident grid take the per-layer launches."""
+        B = x.shape[0]
+        if B > self._b1_max:
+            return self._tower_small(x)
+        if x.device != self._b1_dev or x.dtype != torch.float32 or x.shape[1:] != (120, 8, 8):
+            raise E.EngineError("tower_b1: x must be float32 [B, 120, 8, 8] on the net's device")
+        x = x.contiguous()
+        y = torch.empty((B, self.c, 8, 8), dtype=torch.float32, device=x.device)
+        rc = self.lib.bo_nn_b1_forward(self._b1, x.data_ptr(), y.data_ptr(), B, torch.cuda.current_stream(x.device).cuda_stream)
+        if rc:
+            raise E.EngineError(self.lib.bo_last_error().decode())
+        return y
+
+    def check_b1(self):
+        """Raise if a hand-off wait inside the last tower_b1 launch gave up (its bounded spin ran out: the evaluation is invalid).
+        Synchronises torch's current stream."""
+        t = self.__dict__.get("_b1")
+        if not t:
+            return
+        code = C.c_int32(0)
+        if self.lib.bo_nn_b1_status(t, C.byref(code), torch.cuda.current_stream(self._b1_dev).cuda_stream):
+            raise E.EngineError(self.lib.bo_last_error().decode())
+        if code.value:
+            raise E.EngineError(f"tower_b1: a hand-off inside the launch timed out (phase {code.value - 1}); the evaluation is invalid")
 
     def _build_tower_split(self, dev):
         """float32 tower on the fp16 matrix pipe (bo_nn_tower_create, BO_TOWER_SPLIT_F16): (hi, lo) fp16 pairs of the scaled weights,
@@ -424,6 +480,10 @@ class FusedPolicyValueNet(nn.Module):
             if t:
                 self.__dict__["_tower"] = None
                 self.lib.bo_nn_tower_destroy(t)
+            t = self.__dict__.get("_b1")
+            if t:
+                self.__dict__["_b1"] = None
+                self.lib.bo_nn_b1_destroy(t)
         except Exception:  # interpreter shutdown
             pass
 
@@ -522,7 +582,7 @@ class FusedPolicyValueNet(nn.Module):
     def _se(self, x, bias, se, res):
         B, C = x.shape[0], x.shape[1]
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        if self.conv == "mfma_small" and C % 16 == 0 and se[0].shape[0] <= 16:  # few boards: C/16 workgroups per board, result into `res`
+        if self.conv in ("mfma_small", "tower_b1") and C % 16 == 0 and se[0].shape[0] <= 16:  # few boards: C/16 workgroups per board, result into `res`
             rc = self.lib.bo_nn_se_residual_small(x.data_ptr(), bias.data_ptr(), se[0].data_ptr(), se[1].data_ptr(), res.data_ptr(), B, C,
                                                   se[0].shape[0], stream)
             if rc:
@@ -590,8 +650,9 @@ class FusedPolicyValueNet(nn.Module):
                 logits = torch.softmax(logits.float(), dim=1)
             cur.wait_stream(side)
             return logits, value
-        if self.conv in ("mfma", "tower", "mfma_small"):
-            x = self._tower_mfma(x) if self.conv == "mfma" else self._tower_small(x) if self.conv == "mfma_small" else self._tower_forward(x)
+        if self.conv in ("mfma", "tower", "mfma_small", "tower_b1"):
+            x = (self._tower_mfma(x) if self.conv == "mfma" else self._tower_small(x) if self.conv == "mfma_small"
+                 else self._tower_b1(x) if self.conv == "tower_b1" else self._tower_forward(x))
             h = self._epi(F.conv2d(x, self.w_head, None), self.b_head)
             p = h[:, :self.n_policy_ch].flatten(1)
             v = h[:, self.n_policy_ch:].flatten(1)

@@ -25,7 +25,9 @@ def f32_pipe_default() -> bool:
 def kernel_route(filters: int, batch: int, dtype: torch.dtype, f32_pipe: bool = None):
     """Which hand-written evaluate stage (betaone_amd/fused_net.py `conv=`) a net of this shape runs on -- decided by shape, not by a
     timing race -- or None where none exists (the net then stays under PyTorch-ROCm's library kernels, and says so):
-      float32, 128 / 256 filters: batch <= 16 -> 'mfma_small' (a board's layer cut into c_out/16 x 4 workgroups), else 'tower_split'
+      float32, 64 / 128 / 256 filters: batch <= 256 / ((filters/16)*4) (1-4 boards at 256 filters: uci.py's searches) -> 'tower_b1' (the
+                                 whole tower as ONE launch of c_out/16 x 4 workgroups per board, layers handed over inside the launch);
+      float32, 128 / 256 filters: batch <= 16 -> 'mfma_small' (a board's layer cut into c_out/16 x 4 workgroups, one launch per layer), else 'tower_split'
                                  (the LDS-resident tower on the fp16 matrix pipe, float32 operands as (hi, lo) fp16 pairs);
                                  with f32_pipe (or BETAONE_F32_TOWER=fp32): 'tower_wg' (fp32-MFMA Winograd tower, 128 filters) /
                                  'mfma' (per-layer implicit GEMM on the fp32 pipe, 256 filters);
@@ -34,6 +36,8 @@ def kernel_route(filters: int, batch: int, dtype: torch.dtype, f32_pipe: bool = 
     if f32_pipe is None:
         f32_pipe = f32_pipe_default()
     if dtype == torch.float32:
+        if filters in (64, 128, 256) and batch * (filters // 16) * 4 <= 256:
+            return "tower_b1"
         if filters in (64, 128, 256) and batch <= 16:
             return "mfma_small"
         if filters in (128, 256) and not f32_pipe:

@@ -732,7 +732,6 @@ class CohortRollout:
         p0 = self.parts[0]
         self.S, self.B, self.L, self.fast = p0.S, p0.B, p0.L, p0.fast
         self.expected_evals, self.rng_mode, self.max_game_moves = p0.expected_evals, p0.rng_mode, p0.max_game_moves
-        self.ply_profile = None
 
     # ---- Rollout's counters and per-slot views --------------------------------------------------------------------------------
     n_sims = property(lambda self: sum(p.n_sims for p in self.parts))
@@ -740,6 +739,12 @@ class CohortRollout:
     n_forward = property(lambda self: sum(p.n_forward for p in self.parts))
     host_seconds = property(lambda self: sum(p.host_seconds for p in self.parts))
     games = property(lambda self: [g for p in self.parts for g in p.games])
+
+    @property
+    def ply_profile(self):  # BO_PLY_PROFILE=1: the cohorts' host phases, one list
+        if self.parts[0].ply_profile is None:
+            return None
+        return [x for p in self.parts for x in p.ply_profile]
 
     @property
     def use_graph(self):

@@ -372,6 +372,29 @@ int bo_nn_tower_word(bo_tower *tower, void **dev_word_out);
 int bo_engine_watch(bo_engine *engine, int32_t *dev_word);
 int bo_engine_watch_seen(bo_engine *engine, int32_t *seen_out, int32_t clear);
 
+
+/* ---- (ABI 4) the residual tower of ONE board (a few boards) as ONE launch spread over the chip: csrc/bo_tower_b1.h ----------------
+ * Replaces, for uci.py's single-position searches (/root/reference/uci.py:60-93 -> mcts.py:183-185: PolicyValueNet.forward at
+ * batch 1, /root/reference/network.py:167-185), the per-layer launches of bo_nn_conv3x3_small / bo_nn_se_residual_small.
+ * Layer l = 0 is the input convolution (weights packed for 128 input channels, c_in_x = 120 present), then (conv1, conv2) per
+ * residual block: mode 0 = relu(conv + bias), 1 = relu(conv + bias + block input), 2 = relu((conv + bias) * SE gate + block input)
+ * with se_w1 [hidden][C], se_w2 [C][hidden] (network.py:33-45), hidden <= 16.  Weights: the layout of bo_nn_conv3x3_small.
+ * All pointers are device addresses that must stay valid for the handle's life.  (filters / 16) * 4 * batch <= 256. */
+typedef struct bo_b1_layer_desc {
+    const void *weights_dev;
+    const float *bias_dev;
+    const float *se_w1_dev, *se_w2_dev;
+    int32_t c_in, c_in_x, mode, se_hidden;
+} bo_b1_layer_desc;
+typedef struct bo_b1_s bo_b1;
+int bo_nn_b1_create(const bo_b1_layer_desc *layers, int n_layers, int channels, int max_batch, int device, bo_b1 **out);
+/* x [batch,120,8,8] -> y [batch,channels,8,8] float32 on `stream`; capturable; one launch of a handle in flight at a time. */
+int bo_nn_b1_forward(bo_b1 *tower, const float *x_dev, float *y_dev, int batch, void *stream);
+/* *code_out = 0, or 1 + the phase of a hand-off wait that gave up in the last launch (bounded spins: the kernel always ends; its
+ * output is invalid then).  Synchronises `stream`. */
+int bo_nn_b1_status(bo_b1 *tower, int32_t *code_out, void *stream);
+void bo_nn_b1_destroy(bo_b1 *tower);
+
 #ifdef __cplusplus
 }
 #endif

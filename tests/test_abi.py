@@ -86,7 +86,8 @@ def test_evaluate_stage_route_is_a_shape_rule():
 
     assert R(128, 256, torch.float32) == R(128, 100000, torch.float32) == R(256, 17, torch.float32) == "tower_split"
     assert R(128, 256, torch.float32, f32_pipe=True) == "tower_wg" and R(64, 17, torch.float32) == "tower_wg"
-    assert R(128, 1, torch.float32) == R(256, 16, torch.float32) == R(64, 8, torch.float32) == "mfma_small"
+    assert R(256, 1, torch.float32) == R(256, 4, torch.float32) == R(128, 8, torch.float32) == R(64, 16, torch.float32) == "tower_b1"  # resident grids
+    assert R(256, 5, torch.float32) == R(256, 16, torch.float32) == R(128, 9, torch.float32) == "mfma_small"
     assert R(256, 17, torch.float32, f32_pipe=True) == "mfma"
     assert R(128, 4096, torch.float16) == R(256, 512, torch.float16) == R(256, 1, torch.float16) == "tower_f16"
     assert R(64, 4096, torch.float16) is None and R(96, 32, torch.float32) is None and R(128, 256, torch.bfloat16) is None

@@ -399,12 +399,14 @@ def test_cohorts_of_games_play_exactly_the_games_one_rollout_plays(cohorts):
     mate = "k6R/8/1K6/8/8/8/8/8 b - - 1 1"
     fens = [None, None, mate, "r3k2r/p1ppqpb1/bn2pnp1/3PN3/1p2P3/2N2Q1p/PPPBBPPP/R3K2R w KQkq - 0 1"] + [None] * 7
     seen = []
+    config.COHORTS = 1
     one = self_play.run_self_play_games(model, ids, seeds=seeds, n_slots=6, start_fens=fens)
-    config.COHORTS = cohorts
+    config.COHORTS, config.COHORT_MIN_SLOTS = cohorts, 1
     try:
         many = self_play.run_self_play_games(model, ids, seeds=seeds, n_slots=6, start_fens=fens, on_game=lambda fin: seen.append((fin.game_id, fin.slot)))
     finally:
         config.COHORTS = 1
+        del config.COHORT_MIN_SLOTS
     assert sorted(many) == sorted(one) == ids and many[2] == one[2] == []
     assert sorted(g for g, _ in seen) == ids and {s for _, s in seen} <= set(range(6)) and len({s for _, s in seen}) > 6 // cohorts  # global slot numbers
     for g in ids:

@@ -191,7 +191,7 @@ def test_mfma_conv3x3_matches_float64_convolution(backend, shape):
         conv3x3_mfma(lib, torch.zeros((1, 24, 8, 8)).cuda(), wp, bias, co)
 
 
-@pytest.mark.parametrize("conv", ["miopen", "mfma", "mfma_small", "tower", "tower_wg", "tower_split"])
+@pytest.mark.parametrize("conv", ["miopen", "mfma", "mfma_small", "tower_b1", "tower", "tower_wg", "tower_split"])
 @pytest.mark.parametrize("size", [(3, 1, 64), (8, 2, 128), (15, 5, 256), (2, 2, 256), (0, 3, 128), (4, 0, 64)])
 def test_fused_epilogue_net_matches_plain_net(backend, size, conv):
     """csrc/bo_nn_fused.h, csrc/bo_conv.h, csrc/bo_tower.h, csrc/bo_tower_s.h: conv (MIOpen, the fp32-MFMA direct kernel, the
@@ -232,6 +232,62 @@ def test_fused_epilogue_net_matches_plain_net(backend, size, conv):
         if name:  # and against the reference's own outputs (fixture G1)
             assert np.abs(l1[:3].cpu().numpy() - z[f"logits_{name}"]).max() < 1e-4
             assert np.abs(v1[:3].cpu().numpy() - z[f"value_{name}"]).max() < 1e-4
+    finally:
+        config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = saved
+
+
+@pytest.mark.parametrize("size", [(15, 5, 256), (3, 0, 256), (8, 2, 128), (3, 1, 64)])
+def test_one_launch_tower_for_single_positions_matches_the_per_layer_route(backend, size):
+    """csrc/bo_tower_b1.h (conv='tower_b1', uci.py's batch-1 evaluations): the whole tower as ONE launch, the layers handed over
+    inside it (write-through tiles, arrival counter, agent-scope acquire).  Against conv='mfma_small' (one launch per layer, the same
+    arithmetic in the same order): tower output BIT-identical for nets without SE blocks, <= 2e-6 with them (the channel means are
+    summed tile by tile); logits / value within 1e-5 of the PyTorch net; for every batch the grid holds, 300 evaluations in a row over
+    rotating inputs (a stale hand-off would show as a mismatch), eagerly and replayed from a captured graph; no hand-off timed out."""
+    import torch
+    from betaone_amd import dropin
+    dropin.install()
+    import config, network
+    from betaone_amd.fused_net import FusedPolicyValueNet
+    from fake_model import hash_init_
+
+    saved = (config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS)
+    config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = size
+    try:
+        net = hash_init_(network.PolicyValueNet().eval()).to("cuda:0")
+        one = FusedPolicyValueNet(net, conv="tower_b1").to("cuda:0")
+        per = FusedPolicyValueNet(net, conv="mfma_small").to("cuda:0")
+        z = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "g1_net.npz"))
+        base = torch.from_numpy(z["inputs"]).to("cuda:0")
+        g = torch.Generator(device="cuda:0").manual_seed(7)
+        tol = 0.0 if size[1] == 0 else 2e-6
+        for B in sorted({1, 2, one._b1_max}):
+            xs = [(base[torch.randint(0, 3, (B,), device="cuda:0", generator=g)] * torch.rand((B, 1, 1, 1), device="cuda:0", generator=g)).contiguous()
+                  for _ in range(6)]
+            with torch.no_grad():
+                for it in range(300):
+                    x = xs[it % 6]
+                    got = one._tower_b1(x)
+                    if it % 25 == 0:
+                        want = per._tower_small(x)
+                        assert (got - want).abs().max().item() <= tol, (size, B, it)
+                l0, v0 = net(xs[0])
+                l1, v1 = one(xs[0])
+                assert (l0 - l1).abs().max().item() < 1e-5 and (v0 - v1).abs().max().item() < 1e-5
+                # replayed from a captured graph (memset node + kernel node), input rewritten between replays
+                xg = xs[1].clone()
+                cg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(cg):
+                    yg = one._tower_b1(xg)
+                for it in range(40):
+                    xg.copy_(xs[it % 6])
+                    cg.replay()
+                    if it % 8 == 0:
+                        assert (yg - per._tower_small(xs[it % 6])).abs().max().item() <= tol, (size, B, "graph", it)
+            one.check_b1()
+        if size == (15, 5, 256):  # the reference's own outputs for its default net (fixture G1), through this route
+            with torch.no_grad():
+                l, v = one(base)
+            assert np.abs(l.cpu().numpy() - z["logits_15+5x256"]).max() < 1e-4 and np.abs(v.cpu().numpy() - z["value_15+5x256"]).max() < 1e-4
     finally:
         config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = saved
 
@@ -552,11 +608,11 @@ def test_evaluate_stage_is_routed_by_shape_to_the_hand_written_kernels(backend):
                 with torch.no_grad():
                     (l0, v0), (l1, v1) = net(x), routed(x)
                 assert (l0 - l1).abs().max().item() < 1e-4 and (v0 - v1).abs().max().item() < 1e-4, batch
-            assert best_inference_copy(net, 3, "cuda:0").layout == "nchw+mfma_small"
+            assert best_inference_copy(net, 3, "cuda:0").layout == "nchw+tower_b1" and best_inference_copy(net, 12, "cuda:0").layout == "nchw+mfma_small"
             assert best_inference_copy(net, 4096, "cuda:0", torch.float16).layout == "nchw+tower_f16"
             config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 3, 1, 256
             big = network.PolicyValueNet().to("cuda:0").eval()
-            assert best_inference_copy(big, 1, "cuda:0").layout == "nchw+mfma_small"
+            assert best_inference_copy(big, 1, "cuda:0").layout == "nchw+tower_b1" and best_inference_copy(big, 8, "cuda:0").layout == "nchw+mfma_small"
             assert best_inference_copy(big, 64, "cuda:0").layout == "nchw+tower_split"
             assert best_inference_copy(big, 64, "cuda:0", f32_pipe=True).layout == "nchw+mfma"
             assert best_inference_copy(big, 512, "cuda:0", torch.float16).layout == "nchw+tower_f16"
