@@ -1445,10 +1445,12 @@ extern "C" int bo_nn_tower_word(bo_tower *t, void **dev_word_out) {
 struct bo_b1_s {
 #if !defined(BO_WAVE_EMU)
     int device = 0, C = 0, n_layers = 0, max_batch = 0;
+    bool split = false;             // every layer came with (hi, lo) fp16 weights: the tiles multiply on the fp16 matrix pipe
     bo_b1_layer *layers = nullptr;  // device table
     float *bufs = nullptr, *pool = nullptr;
     unsigned *sync = nullptr;       // [max_batch counters | status word | padding], a block of its own (zeroed before every launch)
     size_t sync_bytes = 0;
+    unsigned long long *prof = nullptr;  // bo_nn_b1_profile: per-wave phase clocks of the next launches (NULL: off)
 #endif
 };
 
@@ -1462,6 +1464,7 @@ extern "C" int bo_nn_b1_create(const bo_b1_layer_desc *layers, int n_layers, int
     const int tiles = (channels / 16) * 4;
     if (max_batch < 1 || max_batch * tiles > 256) return fail(BO_E_CONFIG, "bo_nn_b1: (filters / 16) x 4 x batch workgroups must be resident at once (<= 256)");
     std::vector<bo_b1_layer> tab((size_t)n_layers);
+    int n_split = 0;
     for (int l = 0; l < n_layers; l++) {
         const bo_b1_layer_desc &d = layers[l];
         if (!d.weights_dev || !d.bias_dev) return fail(BO_E_ARG, "bo_nn_b1_create: null weights");
@@ -1472,11 +1475,15 @@ extern "C" int bo_nn_b1_create(const bo_b1_layer_desc *layers, int n_layers, int
         if (d.mode == 2 && (!d.se_w1_dev || !d.se_w2_dev || d.se_hidden < 1 || d.se_hidden > 16)) return fail(BO_E_CONFIG, "bo_nn_b1: SE hidden width 1..16");
         tab[l].w = (const bo_f32x4 *)d.weights_dev; tab[l].bias = d.bias_dev; tab[l].se_w1 = d.se_w1_dev; tab[l].se_w2 = d.se_w2_dev;
         tab[l].cin = d.c_in; tab[l].cin_x = d.c_in_x; tab[l].mode = d.mode; tab[l].se_h = d.se_hidden;
+        tab[l].w_split = (const bo_f32x4 *)d.weights_split_dev; tab[l].inv_scale = d.inv_scale; tab[l].pad = 0;
+        if (d.weights_split_dev && !(d.inv_scale > 0.0f)) return fail(BO_E_ARG, "bo_nn_b1_create: split weights need inv_scale > 0");
+        n_split += d.weights_split_dev ? 1 : 0;
     }
+    if (n_split != 0 && n_split != n_layers) return fail(BO_E_ARG, "bo_nn_b1_create: split weights for every layer or for none");
     RT((int)hipSetDevice(device));
     bo_b1 *t = new bo_b1();
-    t->device = device; t->C = channels; t->n_layers = n_layers; t->max_batch = max_batch;
-    t->sync_bytes = (((size_t)max_batch + 1) * 4 + 63) / 64 * 64;
+    t->device = device; t->C = channels; t->n_layers = n_layers; t->max_batch = max_batch; t->split = n_split == n_layers;
+    t->sync_bytes = (((size_t)2 * max_batch + 2) * 4 + 63) / 64 * 64;
     int rc = (int)hipMalloc((void **)&t->layers, tab.size() * sizeof(bo_b1_layer));
     if (!rc) rc = (int)hipMemcpy(t->layers, tab.data(), tab.size() * sizeof(bo_b1_layer), hipMemcpyHostToDevice);
     if (!rc) rc = (int)hipMalloc((void **)&t->bufs, (size_t)3 * max_batch * channels * 64 * 4);
@@ -1503,16 +1510,24 @@ extern "C" int bo_nn_b1_forward(bo_b1 *t, const float *x_dev, float *y_dev, int 
     if (!t || !x_dev || !y_dev) return fail(BO_E_ARG, "null argument");
     if (batch < 1 || batch > t->max_batch) return fail(BO_E_ARG, "bo_nn_b1_forward: batch beyond the handle's max_batch");
     hipStream_t st = (hipStream_t)stream;
-    // counters and the status word start from zero in EVERY launch (a memset node when captured; a block of its own, a multiple of 16 bytes)
-    RT((int)hipMemsetAsync(t->sync, 0, t->sync_bytes, st));
+    // No memset in front of the launch: the arrival counters run on from launch to launch (bo_b1_args::sync).
     bo_b1_args a;
     a.x = x_dev; a.y = y_dev; a.bufs = t->bufs; a.pool = t->pool; a.sync = t->sync; a.layers = t->layers; a.n_layers = t->n_layers; a.B = batch;
-    // the status word sits behind max_batch counters whatever the batch: the kernel indexes it by B, so hand it the handle's layout
-    a.sync = t->sync + (t->max_batch - batch);
+    a.prof = t->prof; a.MB = t->max_batch;
     const dim3 grid((unsigned)((t->C / 16) * 4), (unsigned)batch);
-    if (t->C == 256) hipLaunchKernelGGL(bo_k_tower_b1<256>, grid, dim3(256), 0, st, a);
-    else if (t->C == 128) hipLaunchKernelGGL(bo_k_tower_b1<128>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(bo_k_tower_b1<64>, grid, dim3(256), 0, st, a);
+    static const int mode = [] { const char *v = getenv("BETAONE_B1_MODE"); return (v && v[0] >= '0' && v[0] <= '2') ? v[0] - '0' : (int)BO_B1_SC1; }();
+#define BO_B1_LAUNCH_P(CC, PP)                                                                                       \
+    do {                                                                                                             \
+        if (mode == BO_B1_ACQ) hipLaunchKernelGGL((bo_k_tower_b1<CC, BO_B1_ACQ, PP>), grid, dim3(256), 0, st, a);    \
+        else if (mode == BO_B1_NT) hipLaunchKernelGGL((bo_k_tower_b1<CC, BO_B1_NT, PP>), grid, dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((bo_k_tower_b1<CC, BO_B1_SC1, PP>), grid, dim3(256), 0, st, a);                      \
+    } while (0)
+#define BO_B1_LAUNCH(CC) do { if (t->split) BO_B1_LAUNCH_P(CC, BO_B1_SPLIT); else BO_B1_LAUNCH_P(CC, BO_B1_F32); } while (0)
+    if (t->C == 256) BO_B1_LAUNCH(256);
+    else if (t->C == 128) BO_B1_LAUNCH(128);
+    else BO_B1_LAUNCH(64);
+#undef BO_B1_LAUNCH_P
+#undef BO_B1_LAUNCH
     RT((int)hipGetLastError());
     return BO_OK;
 #endif
@@ -1526,8 +1541,38 @@ extern "C" int bo_nn_b1_status(bo_b1 *t, int32_t *code_out, void *stream) {
     return fail(BO_E_CONFIG, "bo_nn_b1 is a gfx950-only kernel");
 #else
     if (!t || !code_out) return fail(BO_E_ARG, "bad arguments");
-    RT(rt_d2h(code_out, t->sync + t->max_batch, 4, stream));
+    int32_t two[2] = {0, 0};
+    RT(rt_d2h(two, t->sync + 2 * t->max_batch, 8, stream));
     RT(rt_sync(stream));
+    *code_out = two[0] ? two[0] : (two[1] ? -1 : 0);
+    if (two[0] || two[1]) {  // a fault leaves the counters anywhere: start over from zero (the stream is idle here)
+        RT((int)hipMemsetAsync(t->sync, 0, t->sync_bytes, (hipStream_t)stream));
+        RT(rt_sync(stream));
+    }
+    return BO_OK;
+#endif
+}
+
+// LAB: shader-clock sums per wave of the phases of a layer {wait for the hand-off, slab loads + staging, matrix pipe, reduction,
+// epilogue + signal, layers} over the launches since enable = 1; enable = 0 copies them out ([batch * tiles * 4 waves][8], `cap`
+// entries of 8) and switches the stamps off.  Synchronises the device.
+extern "C" int bo_nn_b1_profile(bo_b1 *t, int enable, uint64_t *out, int cap) {
+#if defined(BO_WAVE_EMU)
+    (void)t; (void)enable; (void)out; (void)cap;
+    return fail(BO_E_CONFIG, "bo_nn_b1 is a gfx950-only kernel");
+#else
+    if (!t) return fail(BO_E_ARG, "null handle");
+    const size_t n = (size_t)t->max_batch * (size_t)(t->C / 16) * 4 * 4 * 8;
+    RT((int)hipDeviceSynchronize());
+    if (enable) {
+        if (!t->prof) RT((int)hipMalloc((void **)&t->prof, n * 8));
+        RT((int)hipMemset(t->prof, 0, n * 8));
+        return BO_OK;
+    }
+    if (!t->prof) return fail(BO_E_STATE, "bo_nn_b1_profile: not enabled");
+    if (out) RT((int)hipMemcpy(out, t->prof, std::min(n, (size_t)cap * 8) * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(t->prof);
+    t->prof = nullptr;
     return BO_OK;
 #endif
 }
@@ -1535,6 +1580,7 @@ extern "C" int bo_nn_b1_status(bo_b1 *t, int32_t *code_out, void *stream) {
 extern "C" void bo_nn_b1_destroy(bo_b1 *t) {
 #if !defined(BO_WAVE_EMU)
     if (!t) return;
+    (void)hipFree(t->prof);
     (void)hipFree(t->layers); (void)hipFree(t->bufs); (void)hipFree(t->pool); (void)hipFree(t->sync);
 #endif
     delete t;

@@ -50,7 +50,8 @@ class BoPosition(C.Structure):
 
 class BoB1LayerDesc(C.Structure):
     _fields_ = [("weights_dev", C.c_void_p), ("bias_dev", C.c_void_p), ("se_w1_dev", C.c_void_p), ("se_w2_dev", C.c_void_p),
-                ("c_in", C.c_int32), ("c_in_x", C.c_int32), ("mode", C.c_int32), ("se_hidden", C.c_int32)]
+                ("c_in", C.c_int32), ("c_in_x", C.c_int32), ("mode", C.c_int32), ("se_hidden", C.c_int32),
+                ("weights_split_dev", C.c_void_p), ("inv_scale", C.c_float), ("reserved", C.c_int32)]
 
 
 class BoNode(C.Structure):
@@ -98,6 +99,7 @@ _SYMBOLS = {
     "bo_nn_b1_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "bo_nn_b1_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "bo_nn_b1_status": (C.c_int, [C.c_void_p, _I32P, C.c_void_p]),
+    "bo_nn_b1_profile": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.c_int]),
     "bo_nn_b1_destroy": (None, [C.c_void_p]),
     "bo_engine_watch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bo_engine_watch_seen": (C.c_int, [C.c_void_p, _I32P, C.c_int32]),

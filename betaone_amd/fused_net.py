@@ -112,6 +112,16 @@ def pack_conv_weight_small(w: torch.Tensor) -> torch.Tensor:
     return u.permute(0, 5, 2, 4, 1, 3).contiguous()  # [ot][tap][g][k][o][e]
 
 
+def pack_conv_weight_small_split(w: torch.Tensor, scale: float) -> torch.Tensor:
+    """[c_out, c_in, 3, 3] float32 -> fp16 [c_out/16][tap 9][c_in/16][64][2 = hi, lo][4] of scale*w (bo_nn_b1_create, weights_split_dev):
+    element (ot, tap, g, lane, hl, j) = split(scale * W[16*ot + (lane & 15)][16*g + 4*(lane >> 4) + j][tap]) -- per lane the B fragment
+    of one v_mfma_f32_16x16x16_f16 K-step as (hi x4 | lo x4) = 16 bytes, at the index the float32 fragments of pack_conv_weight_small have."""
+    co, ci = w.shape[0], w.shape[1]
+    hi, lo = split_f16(w.double() * scale)
+    u = torch.stack([hi, lo], 0).reshape(2, co // 16, 16, ci // 16, 4, 4, 9)  # [hl][ot][n][g][kq][j][tap]
+    return u.permute(1, 6, 3, 4, 2, 0, 5).contiguous()  # [ot][tap][g][kq][n][hl][j]
+
+
 def conv3x3_small(lib, x, wpacked, bias, c_in, c_out, mode=0, residual=None):
     """y = epilogue(conv3x3(x)) through bo_nn_conv3x3_small; x NCHW float32 [B, c_in_x <= c_in, 8, 8], contiguous."""
     B = x.shape[0]
@@ -138,11 +148,14 @@ def conv3x3_mfma(lib, x, wpacked, bias, c_out, mode=0, residual=None, out=None):
 
 
 class FusedPolicyValueNet(nn.Module):
-    def __init__(self, net, conv="miopen"):
-        """net: a PolicyValueNet (any device); weights are copied, BN folded."""
+    def __init__(self, net, conv="miopen", f32_pipe=None):
+        """net: a PolicyValueNet (any device); weights are copied, BN folded.  f32_pipe (conv='tower_b1' only; None = the
+        BETAONE_F32_TOWER setting): True keeps the tiles on the fp32 matrix pipe (exact float32 products), False multiplies them on
+        the fp16 pipe with (hi, lo) operand pairs -- the precision of conv='tower_split'."""
         super().__init__()
         self.lib = E.load_hip_library()
         self.conv = conv
+        self._f32_pipe = f32_pipe
         # policy FC + softmax + value head as one kernel behind the Winograd tower (needs contiguous float32 Linear weights of the
         # reference's head shapes: 2 policy planes, 32 value planes, 256 hidden units)
         self.fused_heads = conv in ("tower_wg", "tower", "mfma", "mfma_small", "tower_b1", "tower_f16", "tower_split")
@@ -224,21 +237,35 @@ class FusedPolicyValueNet(nn.Module):
 
     def _build_b1(self, dev):
         """bo_nn_b1_create over the SAME device tensors the per-layer route uses (pack_conv_weight_small layout): the handle keeps
-        their addresses, the module keeps them alive."""
-        c = self.c
-        descs = []
+        their addresses, the module keeps them alive.  Unless the fp32 matrix pipe is asked for, every layer also gets (hi, lo) fp16
+        weights (pack_conv_weight_small_split, scaled per layer by a power of two like conv='tower_split')."""
+        from .nn_tune import f32_pipe_default
 
-        def desc(wp, bias, c_in, c_in_x, mode, se=None):
+        c = self.c
+        split = not (f32_pipe_default() if self._f32_pipe is None else self._f32_pipe)
+        self.b1_precision = "f16 pairs (3 MFMAs per product, f32 accumulate)" if split else "f32 MFMA"
+        descs, self._b1_split = [], []
+
+        def desc(w, wp, bias, c_in, c_in_x, mode, se=None):
+            ws, inv = None, 0.0
+            if split:
+                wf = w.detach().float().cpu()
+                sc = split_scale(wf)
+                ws = nn.Parameter(pack_conv_weight_small_split(wf, sc).to(dev), requires_grad=False)
+                self._b1_split.append(ws)
+                inv = 1.0 / sc
             d = E.BoB1LayerDesc(wp.data_ptr(), bias.data_ptr(), se[0].data_ptr() if se else None, se[1].data_ptr() if se else None,
-                                c_in, c_in_x, mode, se[0].shape[0] if se else 0)
+                                c_in, c_in_x, mode, se[0].shape[0] if se else 0, ws.data_ptr() if ws is not None else None, inv, 0)
             descs.append(d)
 
-        desc(self.p_in, self.b_in, 128, 120, 0)
+        w0 = torch.zeros((c, 128, 3, 3))
+        w0[:, :120] = self.w_in.detach().float().cpu()
+        desc(w0, self.p_in, self.b_in, 128, 120, 0)
         for (w1, b1, w2, b2, se), (p1, p2) in zip(self.blocks, self.packed):
             if se is not None and se[0].shape[0] > 16:
                 raise E.EngineError("conv='tower_b1' supports SE hidden widths up to 16")
-            desc(p1, b1, c, c, 0)
-            desc(p2, b2, c, c, 2 if se is not None else 1, se)
+            desc(w1, p1, b1, c, c, 0)
+            desc(w2, p2, b2, c, c, 2 if se is not None else 1, se)
         arr = (E.BoB1LayerDesc * len(descs))(*descs)
         self._b1_max = 256 // ((c // 16) * 4)
         handle = C.c_void_p()
@@ -270,6 +297,9 @@ class FusedPolicyValueNet(nn.Module):
         code = C.c_int32(0)
         if self.lib.bo_nn_b1_status(t, C.byref(code), torch.cuda.current_stream(self._b1_dev).cuda_stream):
             raise E.EngineError(self.lib.bo_last_error().decode())
+        if code.value < 0:
+            raise E.EngineError("tower_b1: an activation left the fp16 range (|v| > 65504) and was saturated -- the evaluation is wrong on the fp16 "
+                                "matrix pipe; run this net with BETAONE_F32_TOWER=fp32 (FusedPolicyValueNet(..., f32_pipe=True))")
         if code.value:
             raise E.EngineError(f"tower_b1: a hand-off inside the launch timed out (phase {code.value - 1}); the evaluation is invalid")
 

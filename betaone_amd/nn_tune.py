@@ -69,7 +69,7 @@ def best_inference_copy(model, batch: int, device, dtype: torch.dtype = torch.fl
     route = kernel_route(filters, batch, dtype, f32_pipe)
     if route is not None:
         try:
-            net = FusedPolicyValueNet(model.to(device), conv=route).to(device)
+            net = FusedPolicyValueNet(model.to(device), conv=route, f32_pipe=f32_pipe).to(device)
             net.route = route
             if verbose:
                 print(f"[nn_route] batch={batch} filters={filters} {dtype}: hand-written evaluate stage conv='{route}'")

@@ -385,14 +385,24 @@ typedef struct bo_b1_layer_desc {
     const float *bias_dev;
     const float *se_w1_dev, *se_w2_dev;
     int32_t c_in, c_in_x, mode, se_hidden;
+    const void *weights_split_dev;   /* NULL, or (hi, lo) fp16 pairs of inv_scale^-1 * W: the tiles then multiply on the fp16 matrix pipe
+                                        (three MFMAs per product, float32 accumulation: the precision of BO_TOWER_SPLIT_F16); for every
+                                        layer or for none.  Layout [C/16][tap 9][c_in/16][64 lanes][hi x4 | lo x4]. */
+    float inv_scale;                 /* 1 / (the power of two the split weights were scaled by) */
+    int32_t reserved;
 } bo_b1_layer_desc;
 typedef struct bo_b1_s bo_b1;
 int bo_nn_b1_create(const bo_b1_layer_desc *layers, int n_layers, int channels, int max_batch, int device, bo_b1 **out);
 /* x [batch,120,8,8] -> y [batch,channels,8,8] float32 on `stream`; capturable; one launch of a handle in flight at a time. */
 int bo_nn_b1_forward(bo_b1 *tower, const float *x_dev, float *y_dev, int batch, void *stream);
-/* *code_out = 0, or 1 + the phase of a hand-off wait that gave up in the last launch (bounded spins: the kernel always ends; its
- * output is invalid then).  Synchronises `stream`. */
+/* *code_out = 0; 1 + the phase of a hand-off wait that gave up in the last launch (bounded spins: the kernel always ends; its output
+ * is invalid then); or -1: an activation left the fp16 range with split weights (saturated: the output is wrong, use a handle without
+ * split weights).  Synchronises `stream`. */
 int bo_nn_b1_status(bo_b1 *tower, int32_t *code_out, void *stream);
+/* LAB: per-wave shader-clock sums of a layer's phases {wait, stage, matrix pipe, reduction, epilogue + signal, layers} over the
+ * launches between enable = 1 and enable = 0 (which copies [batch * tiles * 4][8] uint64 out, `cap` rows at most).  Not for graphs
+ * captured before the switch (the kernel argument is frozen in them). */
+int bo_nn_b1_profile(bo_b1 *tower, int enable, uint64_t *out, int cap);
 void bo_nn_b1_destroy(bo_b1 *tower);
 
 #ifdef __cplusplus

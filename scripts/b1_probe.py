@@ -15,7 +15,9 @@ config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = a[0], a
 B = a[3]
 torch.manual_seed(0)
 plain = network.PolicyValueNet().cuda().eval()
-nets = {k: FusedPolicyValueNet(plain, conv=k).cuda() for k in ("tower_b1", "mfma_small")}
+nets = {"tower_b1": FusedPolicyValueNet(plain, conv="tower_b1", f32_pipe=os.environ.get("B1_F32", "0") == "1").cuda(),
+        "mfma_small": FusedPolicyValueNet(plain, conv="mfma_small").cuda()}
+print("tower_b1 precision:", nets["tower_b1"].b1_precision)
 x = torch.rand(B, 120, 8, 8, device="cuda")
 with torch.no_grad():
     ref = nets["mfma_small"]._tower_small(x)
@@ -45,4 +47,22 @@ with torch.no_grad():
             e1.record(); e1.synchronize()
             print(f"{k:11s} {what:8s} graph replay: {e0.elapsed_time(e1) * 1e3 / n:8.1f} us per evaluation")
     nets["tower_b1"].check_b1()
+    # per-wave phase clocks of a layer (eager launches: the graphs above hold the unprofiled argument)
+    import ctypes as C
+    import numpy as np
+    net = nets["tower_b1"]
+    net.lib.bo_nn_b1_profile(net._b1, 1, None, 0)
+    reps = 50
+    for _ in range(reps):
+        net._tower_b1(x)
+    torch.cuda.synchronize()
+    tiles = (a[2] // 16) * 4
+    out = np.zeros((B * tiles * 4, 8), dtype=np.uint64)
+    net.lib.bo_nn_b1_profile(net._b1, 0, out.ctypes.data_as(C.POINTER(C.c_uint64)), out.shape[0])
+    p = out.reshape(B * tiles, 4, 8).astype(np.float64)
+    layers = p[:, :, 5].max()
+    names = ["wait", "stage", "mfma", "reduce", "epilogue+signal"]
+    for w in range(4):
+        row = "  ".join(f"{names[k]} {p[:, w, k].mean() / layers:8.0f}" for k in range(5))
+        print(f"wave {w}: clocks per layer (mean over {B * tiles} workgroups, {reps} launches): {row}   sum {p[:, w, :5].sum(axis=1).mean() / layers:8.0f}")
 print("done")
