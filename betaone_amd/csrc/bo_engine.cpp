@@ -7,6 +7,7 @@
 #include "bo_tree.h"
 #include "bo_fastw.h"
 #include "bo_select_wide.h"
+#include "bo_replay.h"
 #include "bo_nn_fused.h"
 #include "bo_conv.h"
 #include "bo_tower.h"
@@ -23,6 +24,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <deque>
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) {
@@ -933,6 +935,140 @@ extern "C" int bo_records_encode(int n_positions, const bo_position *positions, 
     int rc2 = rt_sync(stream);
     rt_free(dp);
     if (rc || rc2) return fail(BO_E_HIP, std::string("bo_records_encode: ") + rt_errstr(rc ? rc : rc2));
+    return BO_OK;
+}
+
+// ---- GPU-resident replay buffer (bo_replay.h) ------------------------------------------------------
+// Storage is a ring of position slots; a game of n records takes n + 1 consecutive slots (its positions, the final one included: the
+// END-of-game tracker counts it), so a sampled ply finds its history blocks next to it.  Games are evicted oldest first when the ring
+// comes round.  Host side: the table of resident games; device side: SoA arrays indexed by slot.
+struct bo_replay_s {
+    int device = 0, W = 2;
+    int64_t cap = 0, head = 0, n_records = 0;
+    DPos *pos = nullptr;
+    int *rep = nullptr, *pi_n = nullptr, *pi_idx = nullptr, *s_slot = nullptr, *s_k = nullptr;
+    float *pi_val = nullptr, *z = nullptr;
+    int s_cap = 0;
+    struct Game { int64_t start; int32_t n_rec; int32_t game_id; };
+    std::deque<Game> games;
+    std::vector<int64_t> prefix;   // prefix[i] = records of games[0..i) (rebuilt after an add)
+    std::vector<int> h_slot, h_k;
+};
+
+extern "C" int bo_replay_create(int64_t capacity_positions, int pi_width, int device, bo_replay **out) {
+    if (!out || capacity_positions < 2 || capacity_positions > (int64_t)0x7fffffff || pi_width < 1 || pi_width > BO_RES_CAP) return fail(BO_E_ARG, "bo_replay_create: bad arguments");
+    RT(rt_set_device(device));
+    bo_replay *r = new bo_replay();
+    r->device = device; r->W = pi_width; r->cap = capacity_positions;
+    const size_t n = (size_t)capacity_positions;
+    int rc = rt_malloc((void **)&r->pos, n * sizeof(DPos));
+    if (!rc) rc = rt_malloc((void **)&r->rep, n * 4);
+    if (!rc) rc = rt_malloc((void **)&r->pi_n, n * 4);
+    if (!rc) rc = rt_malloc((void **)&r->pi_idx, n * (size_t)pi_width * 4);
+    if (!rc) rc = rt_malloc((void **)&r->pi_val, n * (size_t)pi_width * 4);
+    if (!rc) rc = rt_malloc((void **)&r->z, n * 4);
+    if (rc) {
+        rt_free(r->pos); rt_free(r->rep); rt_free(r->pi_n); rt_free(r->pi_idx); rt_free(r->pi_val); rt_free(r->z);
+        delete r;
+        return fail(BO_E_HIP, std::string("bo_replay_create: ") + rt_errstr(rc));
+    }
+    *out = r;
+    return BO_OK;
+}
+
+extern "C" void bo_replay_destroy(bo_replay *r) {
+    if (!r) return;
+    rt_free(r->pos); rt_free(r->rep); rt_free(r->pi_n); rt_free(r->pi_idx); rt_free(r->pi_val); rt_free(r->z); rt_free(r->s_slot); rt_free(r->s_k);
+    delete r;
+}
+
+// One finished game: positions[0 .. n_records] (the record wire format's list: position i is the one before move i, the last is the
+// final position), pi of record i = entries pi_ptr[i] .. pi_ptr[i + 1] of (pi_idx, pi_val), z[i] as the reference stores it
+// (self_play.py:202: the outcome from the point of view of the side to move, sign of zero included).  Evicts the oldest games that
+// are in the way; *evicted_records (may be NULL) = how many records that cost.  Synchronises `stream` (host staging is freed).
+extern "C" int bo_replay_add_game(bo_replay *r, int32_t game_id, const bo_position *positions, int32_t n_records, const int32_t *pi_ptr,
+                                  const int32_t *pi_idx, const float *pi_val, const float *z, int64_t *evicted_records, void *stream) {
+    if (!r || !positions || n_records < 0 || (n_records && (!pi_ptr || !pi_idx || !pi_val || !z))) return fail(BO_E_ARG, "bo_replay_add_game: bad arguments");
+    if (evicted_records) *evicted_records = 0;
+    if (n_records == 0) return BO_OK;  // (a start position that was already over: no examples, self_play.py:101)
+    const int64_t need = (int64_t)n_records + 1;
+    if (need > r->cap) return fail(BO_E_ARG, "bo_replay_add_game: the game is longer than the buffer");
+    for (int i = 0; i < n_records; i++)
+        if (pi_ptr[i + 1] - pi_ptr[i] > r->W || pi_ptr[i + 1] < pi_ptr[i]) return fail(BO_E_ARG, "bo_replay_add_game: a pi has more entries than the buffer's pi_width");
+    int64_t lost = 0;
+    auto evict_front = [&]() { lost += r->games.front().n_rec; r->n_records -= r->games.front().n_rec; r->games.pop_front(); };
+    if (r->head + need > r->cap) {  // does not fit behind the newest game: the games still living in that tail go, the ring comes round
+        while (!r->games.empty() && r->games.front().start >= r->head) evict_front();
+        r->head = 0;
+    }
+    while (!r->games.empty() && r->games.front().start >= r->head && r->games.front().start < r->head + need) evict_front();
+    const size_t n = (size_t)need;
+    std::vector<DPos> hp(n);
+    for (size_t i = 0; i < n; i++) hp[i] = from_abi(positions[i]);
+    std::vector<int> hn(n, 0), hi(n * (size_t)r->W, 0);
+    std::vector<float> hv(n * (size_t)r->W, 0.0f), hz(n, 0.0f);
+    for (int i = 0; i < n_records; i++) {
+        hn[i] = pi_ptr[i + 1] - pi_ptr[i];
+        for (int e = 0; e < hn[i]; e++) { hi[(size_t)i * r->W + e] = pi_idx[pi_ptr[i] + e]; hv[(size_t)i * r->W + e] = pi_val[pi_ptr[i] + e]; }
+        hz[i] = z[i];
+    }
+    const size_t o = (size_t)r->head;
+    int rc = rt_h2d(r->pos + o, hp.data(), n * sizeof(DPos), stream);
+    if (!rc) rc = rt_h2d(r->pi_n + o, hn.data(), n * 4, stream);
+    if (!rc) rc = rt_h2d(r->pi_idx + o * r->W, hi.data(), n * (size_t)r->W * 4, stream);
+    if (!rc) rc = rt_h2d(r->pi_val + o * r->W, hv.data(), n * (size_t)r->W * 4, stream);
+    if (!rc) rc = rt_h2d(r->z + o, hz.data(), n * 4, stream);
+    if (!rc) rc = RT_LAUNCH(bo_k_replay_counts, (int)need, stream, (const DPos *)(r->pos + o), (int)need, r->rep + o);
+    const int rc2 = rt_sync(stream);
+    if (rc || rc2) return fail(BO_E_HIP, std::string("bo_replay_add_game: ") + rt_errstr(rc ? rc : rc2));
+    r->games.push_back({r->head, n_records, game_id});
+    r->head += need;
+    r->n_records += n_records;
+    r->prefix.clear();
+    if (evicted_records) *evicted_records = lost;
+    return BO_OK;
+}
+
+extern "C" int bo_replay_size(bo_replay *r, int64_t *n_records, int64_t *n_games) {
+    if (!r) return fail(BO_E_ARG, "null handle");
+    if (n_records) *n_records = r->n_records;
+    if (n_games) *n_games = (int64_t)r->games.size();
+    return BO_OK;
+}
+
+// A batch: record_index[i] in [0, records) counts the resident records oldest game first (ChessDataset's index space over
+// load_recent_data's concatenation, train.py:179-219); states [n,120,8,8], pi [n,4672], z [n] are written on `stream` (no wait).
+extern "C" int bo_replay_sample(bo_replay *r, int32_t n, const int64_t *record_index, float *states_dev, float *pi_dev, float *z_dev, void *stream) {
+    if (!r || n < 1 || !record_index || !states_dev || !pi_dev || !z_dev) return fail(BO_E_ARG, "bo_replay_sample: bad arguments");
+    if (r->prefix.empty()) {
+        r->prefix.reserve(r->games.size() + 1);
+        int64_t acc = 0;
+        for (const auto &g : r->games) { r->prefix.push_back(acc); acc += g.n_rec; }
+        r->prefix.push_back(acc);
+    }
+    r->h_slot.resize((size_t)n); r->h_k.resize((size_t)n);
+    for (int i = 0; i < n; i++) {
+        const int64_t q = record_index[i];
+        if (q < 0 || q >= r->n_records) return fail(BO_E_ARG, "bo_replay_sample: record index out of range");
+        const size_t g = (size_t)(std::upper_bound(r->prefix.begin(), r->prefix.end(), q) - r->prefix.begin()) - 1;
+        const int k = (int)(q - r->prefix[g]);
+        r->h_slot[(size_t)i] = (int)(r->games[g].start + k);
+        r->h_k[(size_t)i] = k;
+    }
+    if (n > r->s_cap) {
+        RT(rt_sync(stream));  // (the previous batch's index arrays may still be read)
+        rt_free(r->s_slot); rt_free(r->s_k);
+        r->s_slot = r->s_k = nullptr; r->s_cap = 0;
+        RT(rt_malloc((void **)&r->s_slot, (size_t)n * 4));
+        RT(rt_malloc((void **)&r->s_k, (size_t)n * 4));
+        r->s_cap = n;
+    }
+    RT(rt_h2d(r->s_slot, r->h_slot.data(), (size_t)n * 4, stream));
+    RT(rt_h2d(r->s_k, r->h_k.data(), (size_t)n * 4, stream));
+    RT(RT_LAUNCH(bo_k_replay_encode, n, stream, (const DPos *)r->pos, (const int *)r->rep, (const int *)r->pi_n, (const int *)r->pi_idx,
+                 (const float *)r->pi_val, (const float *)r->z, r->W, (const int *)r->s_slot, (const int *)r->s_k, states_dev, pi_dev, z_dev));
+    // the pageable host index arrays are re-used by the next call: wait for their upload (the encode kernel itself is not waited for)
+    RT(rt_sync(stream));
     return BO_OK;
 }
 

@@ -96,6 +96,11 @@ _SYMBOLS = {
     "bo_event_pair_overhead": (C.c_int, [_F64P, C.c_int32, C.c_void_p]),
     "bo_nn_tower_status": (C.c_int, [C.c_void_p, _I32P, C.c_void_p]),
     "bo_nn_tower_word": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bo_replay_create": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "bo_replay_add_game": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(BoPosition), C.c_int32, _I32P, _I32P, _F32P, _F32P, C.POINTER(C.c_int64), C.c_void_p]),
+    "bo_replay_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "bo_replay_sample": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bo_replay_destroy": (None, [C.c_void_p]),
     "bo_nn_b1_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "bo_nn_b1_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "bo_nn_b1_status": (C.c_int, [C.c_void_p, _I32P, C.c_void_p]),

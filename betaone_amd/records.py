@@ -227,6 +227,127 @@ class CompactDataset(torch.utils.data.Dataset):
         return state, torch.from_numpy(policy).float(), torch.tensor([value], dtype=torch.float32)  # train.py:181-184
 
 
+class GpuReplayBuffer:
+    """Finished games resident in HBM as compact records, training batches expanded on the device (csrc/bo_replay.h, SURVEY.md
+    section 8f row f3): what train.load_recent_data + ChessDataset + DataLoader do on the host with 49.4 KB per ply
+    (/root/reference/train.py:179-219) done where the batches are consumed, with ~110 B per ply.
+
+        buf = GpuReplayBuffer(capacity_plies=2_000_000)
+        buf.add(games)                                  # rollout.FinishedGame objects, or the dicts unpack_games / load_games return
+        for states, policies, values in buf.loader(batch_size=256, steps=1000, seed=0):   # train_network's loop, train.py:252-262
+            ...                                         # float32 CUDA tensors [B,120,8,8], [B,4672], [B,1] -- ChessDataset's triple, batched
+
+    A batch item is bit-identical to what the reference's pickle of the same game yields through ChessDataset.__getitem__ (planes with
+    the END-of-game repetition counts, dense pi, z with its sign).  The oldest games leave when the buffer is full (the reference keeps
+    the most recent iterations, train.py:190-193).  pi_width: most entries a pi may have (2 with the reference's search)."""
+
+    def __init__(self, capacity_plies: int, device="cuda:0", pi_width: int = 2):
+        self.lib = E.load_hip_library()
+        self.device = E.runtime_device(device)
+        self.pi_width = int(pi_width)
+        h = C.c_void_p()
+        # (a game of n records takes n + 1 position slots: room for capacity_plies records of games of ~64 plies and longer)
+        slots = int(capacity_plies) + max(2, int(capacity_plies) // 64)
+        idx = self.device.index if self.device.index is not None else 0
+        self._check(self.lib.bo_replay_create(slots, self.pi_width, idx, C.byref(h)))
+        self.h = h
+        self.n_evicted = 0
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise E.EngineError(f"replay buffer: {self.lib.bo_last_error().decode()}")
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bo_replay_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        n, g = C.c_int64(), C.c_int64()
+        self._check(self.lib.bo_replay_size(self.h, C.byref(n), C.byref(g)))
+        return int(n.value)
+
+    @property
+    def n_games(self) -> int:
+        n, g = C.c_int64(), C.c_int64()
+        self._check(self.lib.bo_replay_size(self.h, C.byref(n), C.byref(g)))
+        return int(g.value)
+
+    def add(self, games: Sequence) -> int:
+        """Add finished games (FinishedGame objects, packed bytes, or unpack_games dicts); returns the records evicted to make room."""
+        lost = 0
+        for g in games:
+            if isinstance(g, (bytes, bytearray)):
+                lost += self.add(unpack_games(bytes(g)))
+                continue
+            if not isinstance(g, dict):
+                g = unpack_games(pack_game(g))[0]
+            n = int(g["n_plies"])
+            if n == 0:
+                continue
+            ptr = np.zeros(n + 1, dtype=np.int32)
+            np.cumsum([len(ix) for ix, _ in g["pis"]], out=ptr[1:])
+            idx = np.concatenate([np.asarray(ix, dtype=np.int32) for ix, _ in g["pis"]]) if ptr[-1] else np.zeros(1, np.int32)
+            val = np.concatenate([np.asarray(v, dtype=np.float32) for _, v in g["pis"]]) if ptr[-1] else np.zeros(1, np.float32)
+            out = np.float32(g["outcome"])
+            z = np.array([out if g["positions"][i].turn == 1 else -out for i in range(n)], dtype=np.float32)  # self_play.py:202
+            ev = C.c_int64(0)
+            self._check(self.lib.bo_replay_add_game(self.h, int(g["game_id"]), g["positions"], n, ptr.ctypes.data_as(E._I32P),
+                                                    np.ascontiguousarray(idx).ctypes.data_as(E._I32P), np.ascontiguousarray(val).ctypes.data_as(E._F32P),
+                                                    z.ctypes.data_as(E._F32P), C.byref(ev), self._stream()))
+            lost += int(ev.value)
+        self.n_evicted += lost
+        return lost
+
+    def batch(self, record_index) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """(states [n,120,8,8], policies [n,4672], values [n,1]) of the records with these indices (0 = oldest resident record)."""
+        q = np.ascontiguousarray(record_index, dtype=np.int64).reshape(-1)
+        n = int(q.size)
+        kw = dict(dtype=torch.float32, device=self.device)
+        states, pis, zs = torch.empty((n, E.INPUT_CHANNELS, 8, 8), **kw), torch.empty((n, E.NUM_ACTIONS), **kw), torch.empty((n, 1), **kw)
+        self._check(self.lib.bo_replay_sample(self.h, n, q.ctypes.data_as(C.POINTER(C.c_int64)), states.data_ptr(), pis.data_ptr(), zs.data_ptr(),
+                                              self._stream()))
+        return states, pis, zs
+
+    def sample(self, batch_size: int, rng: Optional[np.random.Generator] = None):
+        rng = rng if rng is not None else np.random.default_rng()
+        return self.batch(rng.integers(0, len(self), size=int(batch_size)))
+
+    def loader(self, batch_size: int, steps: Optional[int] = None, seed: Optional[int] = None, shuffle: bool = True):
+        """An iterable with DataLoader's contract for train_network (train.py:252: `for states, t_policies, t_values in dataloader`):
+        one epoch over the resident records in a random order (shuffle=True, the reference's DataLoader(shuffle=True)), or `steps` batches
+        drawn with replacement.  Batches are made on the buffer's device; the loop's `.to(config.DEVICE)` finds them there."""
+        return _ReplayLoader(self, int(batch_size), steps, seed, shuffle)
+
+
+class _ReplayLoader:
+    def __init__(self, buf: GpuReplayBuffer, batch_size: int, steps, seed, shuffle):
+        self.buf, self.batch_size, self.steps, self.seed, self.shuffle = buf, batch_size, steps, seed, shuffle
+
+    def __len__(self) -> int:
+        return self.steps if self.steps is not None else (len(self.buf) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        rng = np.random.default_rng(self.seed)
+        n = len(self.buf)
+        if self.steps is not None:
+            for _ in range(self.steps):
+                yield self.buf.batch(rng.integers(0, n, size=self.batch_size))
+            return
+        order = rng.permutation(n) if self.shuffle else np.arange(n)
+        for i in range(0, n, self.batch_size):
+            yield self.buf.batch(order[i:i + self.batch_size])
+
+
 def all_gather_bytes(payload: bytes, device: Optional[torch.device] = None, group=None) -> List[bytes]:
     """One exchange step: every rank contributes `payload`, every rank receives all payloads.
     Two collectives: sizes (int64 all_gather), then the padded payload (uint8 all_gather) -- RCCL over

@@ -373,6 +373,23 @@ int bo_engine_watch(bo_engine *engine, int32_t *dev_word);
 int bo_engine_watch_seen(bo_engine *engine, int32_t *seen_out, int32_t clear);
 
 
+/* ---- (ABI 4) GPU-resident replay buffer: csrc/bo_replay.h ----------------------------------------------------------------------
+ * Replaces, on the training side of the path's hand-over, train.load_recent_data + ChessDataset (/root/reference/train.py:179-219): the
+ * finished games stay in HBM as compact records (position 80 B, end-of-game repetition count, sparse pi, z: ~110 B per ply) and a
+ * batch of the triples ChessDataset.__getitem__ yields -- state float32 [120,8,8], dense pi [4672], z -- is expanded on the device for
+ * the loop that consumes it (train_network, train.py:252-262).  capacity in POSITION slots (a game of n records takes n + 1); the
+ * oldest games are evicted when the ring comes round (the reference keeps the most recent iterations, train.py:190-193). */
+typedef struct bo_replay_s bo_replay;
+int bo_replay_create(int64_t capacity_positions, int pi_width, int device, bo_replay **out);
+/* positions[0 .. n_records] (position i before move i; the last one final), pi of record i = entries pi_ptr[i] .. pi_ptr[i+1] (at most
+ * pi_width), z[i] as self_play.py:202 stores it.  *evicted_records (may be NULL): records of the games that had to go. */
+int bo_replay_add_game(bo_replay *rb, int32_t game_id, const bo_position *positions, int32_t n_records, const int32_t *pi_ptr,
+                       const int32_t *pi_idx, const float *pi_val, const float *z, int64_t *evicted_records, void *stream);
+int bo_replay_size(bo_replay *rb, int64_t *n_records, int64_t *n_games);
+/* record_index[i] in [0, records): resident records, oldest game first.  states [n,120,8,8], pi [n,4672], z [n] (device, float32). */
+int bo_replay_sample(bo_replay *rb, int32_t n, const int64_t *record_index, float *states_dev, float *pi_dev, float *z_dev, void *stream);
+void bo_replay_destroy(bo_replay *rb);
+
 /* ---- (ABI 4) the residual tower of ONE board (a few boards) as ONE launch spread over the chip: csrc/bo_tower_b1.h ----------------
  * Replaces, for uci.py's single-position searches (/root/reference/uci.py:60-93 -> mcts.py:183-185: PolicyValueNet.forward at
  * batch 1, /root/reference/network.py:167-185), the per-layer launches of bo_nn_conv3x3_small / bo_nn_se_residual_small.

@@ -334,6 +334,58 @@ def test_compact_file_survives_a_writer_killed_inside_a_write_and_both_mode_resu
     assert replayed["moves"].tolist() == R.unpack_games(blob)[3]["moves"].tolist()  # per-game seeds: the replay is the same game
 
 
+def test_gpu_replay_buffer_yields_chessdataset_triples_and_evicts_oldest_games(tmp_path):
+    """Row f3, the ingest side: records.GpuReplayBuffer keeps finished games as compact records on the device and expands training
+    batches there (csrc/bo_replay.h).  Record i of the buffer (oldest resident game first) must be, bit for bit, item i of
+    ChessDataset over the reference's pickles of the same games (train.py:179-184: planes with END-of-game repetition counts, dense
+    pi, z with its sign) -- here against CompactDataset, which the test above pins to those pickles.  A full buffer evicts whole
+    games, oldest first; the loader has DataLoader's contract for train_network's loop (train.py:252)."""
+    from betaone_amd import records as R
+    from betaone_amd import selfplay_main as M
+
+    config.NUM_SIMULATIONS, config.MCTS_BATCH_SIZE, config.MAX_GAME_MOVES = 30, 16, 9
+    config.DATA_DIR = str(tmp_path / "data")
+    model = FakeNet(scale=2.0, salt=4)
+    fens = None
+    done = M.run_iteration(model, 1, n_games=7, n_slots=3, log=lambda s: None, records="compact")
+    path = R.compact_path(config.DATA_DIR, 1, 0)
+    games = R.load_games(path)
+    ds = R.CompactDataset([path], device="cpu", cache_games=8)
+    assert len(ds) == sum(done.values()) == 7 * 9
+    buf = R.GpuReplayBuffer(capacity_plies=200, device="cpu")
+    assert buf.add(games) == 0 and len(buf) == len(ds) and buf.n_games == 7
+    st, pi, z = buf.batch(np.arange(len(ds)))
+    assert st.dtype == pi.dtype == z.dtype == torch.float32 and tuple(st.shape) == (63, 120, 8, 8) and tuple(pi.shape) == (63, 4672) and tuple(z.shape) == (63, 1)
+    for i in range(len(ds)):
+        s0, p0, z0 = ds[i]
+        assert torch.equal(st[i], s0) and torch.equal(pi[i], p0) and torch.equal(z[i], z0), i
+        assert np.signbit(z[i].numpy()[0]) == np.signbit(z0.numpy()[0])
+    one = buf.batch([40, 3, 40])                       # any order, repeats allowed
+    assert torch.equal(one[0][0], ds[40][0]) and torch.equal(one[0][1], ds[3][0]) and torch.equal(one[1][2], ds[40][1])
+    with pytest.raises(Exception):
+        buf.batch([len(ds)])
+    # DataLoader contract: an epoch visits every record once, in a seeded random order; `steps` batches are drawn with replacement
+    seen = []
+    loader = buf.loader(batch_size=16, seed=3)
+    assert len(loader) == 4
+    for states, policies, values in loader:
+        assert states.shape[1:] == (120, 8, 8) and policies.shape[1] == 4672 and values.shape[1] == 1 and states.shape[0] == policies.shape[0] == values.shape[0] <= 16
+        seen.append(states.shape[0])
+    assert sum(seen) == 63 and seen[:-1] == [16, 16, 16]
+    assert [b[0].shape[0] for b in buf.loader(batch_size=8, steps=5, seed=1)] == [8] * 5
+    # a small buffer: 25 plies + slack -> position slots for two 9-ply games (10 slots each) and a bit: whole games leave, oldest first
+    small = R.GpuReplayBuffer(capacity_plies=25, device="cpu")
+    lost = [small.add([g]) for g in games]
+    assert lost == [0, 0, 9, 9, 9, 9, 9] and len(small) == 18 and small.n_games == 2 and small.n_evicted == 45
+    st2, pi2, z2 = small.batch(np.arange(18))
+    off = 5 * 9                                        # the two newest games = the last 18 items of the dataset
+    for i in range(18):
+        assert torch.equal(st2[i], ds[off + i][0]) and torch.equal(pi2[i], ds[off + i][1]) and torch.equal(z2[i], ds[off + i][2]), i
+    with pytest.raises(Exception, match="longer than the buffer"):
+        R.GpuReplayBuffer(capacity_plies=4, device="cpu").add(games[:1])
+    buf.close(); small.close()
+
+
 def test_weights_are_swapped_inside_a_living_process(tmp_path):
     """Row f4: main.py:147-148 hands new weights to its workers through best_model.pth.  ModelFileWatcher notices the changed file,
     run_self_play_games swaps the evaluate stage between two plies (Rollout.swap_model): plies before the swap are those of the

@@ -93,6 +93,57 @@ def test_compact_dataset_on_the_gpu_yields_what_the_reference_pickles_yield(env,
     assert [g["game_id"] for g in R.load_games(path)] == [g[0] for g in idx[:-1]] + [idx[0][0]]
 
 
+def test_gpu_replay_buffer_feeds_a_training_step_with_the_reference_pickles_content(env, tmp_path):
+    """Row f3, ingest: records.GpuReplayBuffer on cuda:0 (csrc/bo_replay.h: compact records resident in HBM, batches expanded by one
+    wave per sampled ply).  Every record of the buffer equals, bit for bit, the tuple the reference's pickle of the same game holds
+    (ChessDataset.__getitem__, train.py:179-184); the loader drives the body of train_network's loop (train.py:252-262: forward, the
+    two losses of calculate_loss, backward, optimizer step) without a host copy of a plane; a full buffer evicts the oldest games."""
+    import torch
+    import torch.nn.functional as F
+    from betaone_amd import records as R
+    from betaone_amd import selfplay_main as M
+
+    config = env
+    model = _net(config, (3, 1, 64), 0)
+    config.NUM_SIMULATIONS, config.MCTS_BATCH_SIZE, config.MAX_GAME_MOVES = 100, 96, 14
+    config.DATA_DIR = str(tmp_path / "data")
+    done = M.run_iteration(model, 4, n_games=20, n_slots=8, log=lambda s: None, records="both")
+    games = R.load_games(R.compact_path(config.DATA_DIR, 4, 0))
+    buf = R.GpuReplayBuffer(capacity_plies=4096, device="cuda:0")
+    assert buf.add(games) == 0 and len(buf) == sum(done.values()) and buf.n_games == 20
+    st, pi, z = buf.batch(np.arange(len(buf)))
+    assert st.is_cuda and pi.is_cuda and z.is_cuda
+    st, pi, z = st.cpu(), pi.cpu(), z.cpu()
+    k = 0
+    for g in games:  # the buffer's index space: resident records, oldest game first = the file's order
+        dense = pickle.load(open(tmp_path / "data" / "iter_4" / f"game_{g['game_id']}.pkl", "rb"))
+        for state, policy, value in dense:
+            assert torch.equal(st[k], state) and torch.equal(pi[k], torch.from_numpy(policy).float())
+            assert z[k, 0].item() == value and np.signbit(z[k, 0].item()) == np.signbit(np.float32(value))
+            k += 1
+    assert k == len(buf)
+    # train_network's loop body over the loader (a fresh net in train mode, plain SGD; the reference wraps this in autocast + GradScaler)
+    net = _net(config, (3, 1, 64), 5).train()
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+    losses = []
+    for states, t_policies, t_values in buf.loader(batch_size=64, steps=6, seed=0):
+        states, t_policies, t_values = states.to("cuda"), t_policies.to("cuda"), t_values.to("cuda")   # (no-ops: the batches are made there)
+        opt.zero_grad()
+        policies, values = net(states)
+        loss = F.mse_loss(values, t_values) + F.cross_entropy(policies, t_policies)      # calculate_loss, train.py:222-245
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert len(losses) == 6 and all(np.isfinite(l) for l in losses)
+    small = R.GpuReplayBuffer(capacity_plies=60, device="cuda:0")
+    for g in games:
+        small.add([g])
+    assert 0 < len(small) <= 60 + 14 and small.n_evicted == len(buf) - len(small)
+    tail = small.batch(np.arange(len(small)))[0].cpu()
+    assert torch.equal(tail, st[len(buf) - len(small):])        # what is left are the newest games, in order
+    buf.close(); small.close()
+
+
 def _play(ro, n_plies, fins, upto=None):
     for _ in range(n_plies):
         ro.play_ply(on_finished=fins.append)
