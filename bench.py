@@ -33,6 +33,7 @@ Also measured live, per the contract:
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import math
 import os
@@ -46,6 +47,7 @@ import betaone_amd  # noqa: F401  (first: sets GPU_MAX_HW_QUEUES before the HIP 
 import numpy as np
 import torch
 
+C_INT32 = ctypes.c_int32
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 NETS = {"4x64": (3, 1, 64), "10x128": (8, 2, 128), "20x256": (15, 5, 256)}
 
@@ -204,22 +206,49 @@ TOWER_PMC_SOURCE = {"tower_split": "profiles/r03_tower_split_pmc.md (separate ro
                     "tower_wg": "profiles/r02_tower_wg_pmc.md (separate rocprofv3 --pmc pass of this kernel, 256 boards x 128 filters)"}
 
 
-def nn_roofline(net, batch, device, ro=None, drv=None, plies=3):
-    """MFMA roofline of the evaluate stage's tower kernel (csrc/bo_tower_wg.h / bo_tower.h), timed with events on the
-    stream it is launched on.  `achieved` counts the fp32 MFMA flops the kernel executes (Winograd F(2x2,3x3): 16
-    multiplies per 2x2 output tile and input channel, input conv padded to 128 channels); `algorithmic` is the direct
-    3x3 convolution's flop count for the same layers (what MIOpen / the reference's net would be charged).
-    Launch duration: `plies` more plies of THIS run's workload (same engine, same games) are played with eager launches and
-    an event pair around every tower launch (FusedPolicyValueNet.tower_events) -- the kernel between the tree steps it runs
-    between in the timed region, which is what rocprofv3's per-kernel average of the same command shows
-    (profiles/r02_bench_kernel_stats.md).  `back_to_back_us` is the same kernel replayed as 20 consecutive graph nodes:
-    nothing but fp32 MFMA work for 30 ms, ~4 % slower per launch."""
+def tower_timings(parts, seq0, khz):
+    """Durations (us) and [start, end) intervals (us, common clock) of the tower launches each Rollout made since `seq0` -- noted by the
+    kernel itself (bo_nn_tower_forward_timed), so launches inside the captured graphs of the timed region are measured, not re-runs."""
+    dur, iv = [], []
+    for p, s0 in zip(parts, seq0):
+        t = p.tower_timing.cpu().numpy().astype(np.uint64)
+        s1, cap = int(t[0]), 4096
+        lo = max(s0, s1 - cap)
+        for k in range(lo, s1):
+            a, b = int(t[2 + k % cap]), int(t[2 + cap + k % cap])
+            if b > a:
+                dur.append((b - a) / khz * 1e3)
+                iv.append((a / khz * 1e3, b / khz * 1e3))
+    return dur, iv
+
+
+def _union(iv):
+    tot, cs, ce = 0.0, None, None
+    for a, b in sorted(iv):
+        if ce is None or a > ce:
+            if ce is not None:
+                tot += ce - cs
+            cs, ce = a, b
+        else:
+            ce = max(ce, b)
+    return tot + (ce - cs if ce is not None else 0.0)
+
+
+def nn_roofline(net, batch, device, timed=None, wall_us=None):
+    """MFMA roofline of the evaluate stage's tower kernel.  `achieved` / `frac` = ALGORITHMIC flops per launch (SURVEY.md section 8d:
+    2 x MACs of the tower's direct 3x3 convolutions) / the kernel's average launch duration IN THE TIMED REGION, which the kernel notes
+    itself (first workgroup's start, last workgroup's end, constant-rate device clock: `timed` = (durations us, intervals) from
+    tower_timings) -- event pairs cannot sit between the nodes of the captured graphs the timed region replays; rocprofv3's per-kernel
+    average of the same command is the check (profiles/).  With cohorts two launches of half the boards overlap: `concurrency` = sum of
+    durations / time with at least one launch running, and `achieved_all_launches` prices what the chip's matrix pipes did in that time.
+    `back_to_back_us`: the same kernel alone on the chip, replayed as 20 consecutive graph nodes."""
     conv = getattr(net, "conv", None)
     if conv not in ("tower", "tower_wg", "tower_split"):
         return None
     heads = conv in ("tower_wg", "tower_split")
     C, n_conv = net.c, 1 + 2 * len(net.blocks)
     x = torch.rand((batch, 120, 8, 8), device=device)
+    net.__dict__.pop("tower_timing_buf", None)
     with torch.no_grad():
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
@@ -241,19 +270,13 @@ def nn_roofline(net, batch, device, ro=None, drv=None, plies=3):
         e1.synchronize()
         del keep
     b2b = e0.elapsed_time(e1) * 1e3 / (per_graph * replays)
-    us, n_timed, how = b2b, per_graph * replays, "20 consecutive graph nodes x 4 replays"
-    if ro is not None and drv is not None and heads:
-        graph = ro.use_graph
-        ro.use_graph = False
-        net.tower_events = []
-        for _ in range(plies):
-            drv.step()
-        torch.cuda.synchronize(device)
-        ev, net.tower_events = net.tower_events, None
-        ro.use_graph = graph
-        if ev:
-            us = sum(a.elapsed_time(b) for a, b in ev) * 1e3 / len(ev)
-            n_timed, how = len(ev), f"event pair around every launch of {plies} more plies of this workload (eager launches)"
+    us, n_timed, how, conc = b2b, per_graph * replays, "20 consecutive graph nodes x 4 replays (no in-kernel timings for this kernel)", None
+    if timed and timed[0]:
+        dur, iv = timed
+        us, n_timed = float(np.mean(dur)), len(dur)
+        conc = float(sum(dur) / max(_union(iv), 1e-9))
+        how = ("every launch of the timed region, noted by the kernel itself (first workgroup's start -> last workgroup's end, wall_clock64; "
+               "bo_nn_tower_forward_timed)")
     per_mac = 16 * 16 if conv == "tower_wg" else 3 * 9 * 64 if conv == "tower_split" else 9 * 64  # multiplies per (c_in, c_out) pair and board
     executed = 2.0 * per_mac * C * (128 + (n_conv - 1) * C) * batch
     # SURVEY.md section 8d's per-unit figure: 2 x MACs of the direct 3x3 convolutions of the tower, per board (input conv: 120 planes)
@@ -276,6 +299,10 @@ def nn_roofline(net, batch, device, ro=None, drv=None, plies=3):
             "pipe_utilisation": round(executed / us / 1e6 / peak, 4),
             "executed_tflops": round(executed / us / 1e6, 1),
             "avg_launch_us": round(us, 1), "launches_timed": n_timed, "timing": how, "back_to_back_us": round(b2b, 1),
+            "launch_us_p10_p50_p90": ([round(float(v), 1) for v in np.percentile(timed[0], [10, 50, 90])] if timed and timed[0] else None),
+            "concurrency": (round(conc, 3) if conc else None),
+            "share_of_wall_time": (round(_union(timed[1]) / wall_us, 4) if (conc and wall_us) else None),  # time with >= 1 tower launch running / the timed region
+            "achieved_all_launches": (round(ach * conc, 1) if conc else None), "frac_all_launches": (round(ach * conc / peak, 4) if conc else None),
             "boards_per_launch": batch, "conv_layers": n_conv, "note": note}
 
 
@@ -542,7 +569,8 @@ def main():
     ro_kw = dict(num_simulations=args.sims, mcts_batch_size=args.batch, device=str(device), use_graph=not args.no_graph,
                  rng_mode="native", max_game_moves=args.max_game_moves, fast=args.fast, leaves_per_step=args.leaves,
                  fast_arena_granules=(args.arena_granules_per_expansion * (args.sims + args.leaves + 2) if args.fast else 0),
-                 policy_kind="probs" if args.softmax == "torch" else "logits")
+                 policy_kind="probs" if args.softmax == "torch" else "logits",
+                 time_tower=(not args.no_roofline and not args.fast and args.net_dtype == "fp32"))
     ro = CohortRollout(net, G, cohorts=args.cohorts, **ro_kw) if args.cohorts > 1 else Rollout(net, G, **ro_kw)
     if args.fast and G * args.leaves > 65536:
         ro.MAX_GRAPH_ITERATIONS = 4 if G * args.leaves <= 131072 else 2  # (every iteration of a captured graph keeps its own logits / probabilities: 6.5 GB at 131072 rows)
@@ -564,6 +592,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(device)
     t_pre = time.perf_counter() - t_pre
+    parts = getattr(ro, "parts", [ro])
+    timing_on = parts[0].tower_timing is not None
+    seq0 = [int(p.tower_timing[0].item()) for p in parts] if timing_on else None
     fin_pre = drv.n_finished
     s0, p0, f0, h0, n0, pf0 = ro.n_sims, ro.n_plies, ro.n_forward, ro.host_seconds, drv.n_finished, drv.plies_finished
     import gc
@@ -580,6 +611,11 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     gc.enable()
+    timed = None
+    if timing_on:  # the tower launches of the timed region, timed by the kernel itself
+        khz = C_INT32(0)
+        E.load_hip_library().bo_device_wall_clock_khz(device.index or 0, ctypes.byref(khz))
+        timed = tower_timings(parts, seq0, float(khz.value or 100000))
     # The exchange pipeline is drained after the K timed steps: every step did its own exchange tick (records of earlier plies
     # arrived during the timed region exactly as these will in the steps after it); the drain is an artefact of stopping.
     t_flush = time.perf_counter()
@@ -652,7 +688,7 @@ def main():
         if fast_roof is not None and args.select_sweep:
             fast_roof["variants"] = sweep
     if rank == 0 and not args.no_roofline and not args.fast and args.net_dtype == "fp32":
-        rn = nn_roofline(net, G // args.cohorts, device, ro if dist is None else None, drv)  # (more plies of this workload, after everything reported)
+        rn = nn_roofline(net, G // args.cohorts, device, timed, dt * 1e6)
 
     out = None
     if rank == 0:

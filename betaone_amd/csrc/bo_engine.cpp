@@ -1483,10 +1483,36 @@ extern "C" int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layer
 #endif
 }
 
+// Rate (kHz) of the constant-rate clock the in-kernel timings are taken with (wall_clock64: hipDeviceAttributeWallClockRate).
+extern "C" int bo_device_wall_clock_khz(int device, int32_t *khz_out) {
+#if defined(BO_WAVE_EMU)
+    (void)device; (void)khz_out;
+    return fail(BO_E_CONFIG, "gfx950 only");
+#else
+    if (!khz_out) return fail(BO_E_ARG, "null argument");
+    int v = 0;
+    RT((int)hipDeviceGetAttribute(&v, hipDeviceAttributeWallClockRate, device));
+    *khz_out = v;
+    return BO_OK;
+#endif
+}
+
+static int tower_forward_impl(bo_tower *t, const float *x_dev, float *y_dev, void *head_a_dev, void *head_b_dev, int batch, void *timing_dev, void *stream);
 extern "C" int bo_nn_tower_forward(bo_tower *t, const float *x_dev, float *y_dev, void *head_a_dev, void *head_b_dev, int batch,
                                    void *stream) {
+    return tower_forward_impl(t, x_dev, y_dev, head_a_dev, head_b_dev, batch, nullptr, stream);
+}
+// The same launch with its duration noted by the kernel itself in `timing_dev` (BO_TOWER_SPLIT_F16 only): uint64 [seq | arrivals |
+// start[4096] | end[4096]], zeroed by the caller; launch k made with this buffer leaves its first workgroup's start and its last
+// workgroup's end in slot k % 4096 (units: the device's constant-rate clock, hipDeviceAttributeWallClockRate kHz).  One launch per
+// buffer at a time (launches of one stream).  For measurements inside captured graphs, where no event pair fits between two nodes.
+extern "C" int bo_nn_tower_forward_timed(bo_tower *t, const float *x_dev, float *y_dev, void *head_a_dev, void *head_b_dev, int batch,
+                                         void *timing_dev, void *stream) {
+    return tower_forward_impl(t, x_dev, y_dev, head_a_dev, head_b_dev, batch, timing_dev, stream);
+}
+static int tower_forward_impl(bo_tower *t, const float *x_dev, float *y_dev, void *head_a_dev, void *head_b_dev, int batch, void *timing_dev, void *stream) {
 #if defined(BO_WAVE_EMU)
-    (void)t; (void)x_dev; (void)y_dev; (void)head_a_dev; (void)head_b_dev; (void)batch; (void)stream;
+    (void)t; (void)x_dev; (void)y_dev; (void)head_a_dev; (void)head_b_dev; (void)batch; (void)stream; (void)timing_dev;
     return fail(BO_E_CONFIG, "bo_nn_tower is a gfx950-only kernel");
 #else
     if (!t || !x_dev || batch < 1) return fail(BO_E_ARG, "bad arguments");
@@ -1517,8 +1543,14 @@ extern "C" int bo_nn_tower_forward(bo_tower *t, const float *x_dev, float *y_dev
         bo_tower_head_s hs;
         hs.channels = t->head_channels; hs.split = t->head_split; hs.w_off8 = t->head_w_off; hs.b_off = t->head_b_off;
         hs.out_a = (float *)head_a_dev; hs.out_b = (float *)head_b_dev; hs.overflow = t->overflow;
+        hs.timing = (unsigned long long *)timing_dev;
         const bo_h8 *w8 = reinterpret_cast<const bo_h8 *>(t->wts);
-        if (t->channels == 256) hipLaunchKernelGGL((bo_k_tower_s<256, 2>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
+        // 256 filters: two tiles per wave double every register set.  Weight fragments 8 K-steps ahead: 41 spilled registers (160 B of
+        // scratch); 4 ahead: none, and as fast (1 667-1 672 us against 1 678-1 679 per 256 boards, same box: profiles/r04_tower256_ring.md).
+        // BETAONE_TOWER256_AR=8 keeps the old instance selectable for A/B runs.
+        static const int ar256 = [] { const char *v = getenv("BETAONE_TOWER256_AR"); return (v && v[0] == '8') ? 8 : 4; }();
+        if (t->channels == 256 && ar256 == 8) hipLaunchKernelGGL((bo_k_tower_s<256, 2, 0, 1, 8>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
+        else if (t->channels == 256) hipLaunchKernelGGL((bo_k_tower_s<256, 2, 0, 1, 4>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
         else  // (B operands read two K-steps ahead, weight fragments requested twelve ahead: profiles/r03_split_tower.md)
             hipLaunchKernelGGL((bo_k_tower_s<128, 1, 0, 2, 12>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
         RT((int)hipGetLastError());

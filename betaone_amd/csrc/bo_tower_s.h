@@ -16,9 +16,11 @@
 //     half is then a normal fp16 number for every weight above 2^-18 of the largest); the epilogue multiplies the
 //     accumulator by the inverse (exact) in the fma that adds the bias;
 //   * M = 32*MT output channels per wave (4 waves, one per SIMD), N = 64 positions (two 32-wide tiles), K = 9 taps x C in
-//     steps of 16 channels; A fragments [step][oc/32][hi|lo][lane][8 fp16] = one buffer_load_dwordx4 each, reloaded 8 steps
-//     ahead into the register set its own MFMAs just released.
-// Numerics (tests/test_fused_net_gpu.py): within 1e-5 of the float32 layer-by-layer net; G1 fixtures within 1e-4.
+//     steps of 16 channels; A fragments [step][oc/32][hi|lo][lane][8 fp16] = one buffer_load_dwordx4 each, reloaded AR steps
+//     ahead into the register set its own MFMAs just released (AR = 12 for the 128-filter instance; 4 for 256 filters, whose
+//     two tiles per wave double every register set: with 8 the instance spilled 41 registers).
+// Numerics (tests/test_engine_gpu.py: test_fused_epilogue_net_matches_plain_net): within 1e-5 of the float32 layer-by-layer net;
+// G1 fixtures (3 sizes, the reference-default 15+5 x 256 among them) within 1e-4.
 #pragma once
 #if !defined(BO_WAVE_EMU)
 #include <hip/hip_runtime.h>
@@ -30,7 +32,10 @@ struct bo_tower_head_s {
     int channels = 0, split = 0, w_off8 = 0, b_off = 0;  // head weights: [mt][step C/16][hi|lo][lane][8 fp16] at bo_h8 offset w_off8 in wts;
     float *out_a = nullptr, *out_b = nullptr;            // params[b_off + channels] = their inverse scale
     int *overflow = nullptr;                              // set to 1 when an activation had to be saturated to the fp16 range (the result is then wrong)
+    unsigned long long *timing = nullptr;                 // bo_nn_tower_forward_timed: [seq | arrivals | start[BO_TOWER_TIMING_CAP] | end[..]] of the launches
+                                                          // made with this buffer, in the device's constant-rate clock (wall_clock64)
 };
+#define BO_TOWER_TIMING_CAP 4096
 
 // hi / lo halves of 4 float32 values (saturating: |v| beyond the fp16 range would turn into inf - inf)
 __device__ inline void bo_split4(const float (&v)[4], bo_h4 &hi, bo_h4 &lo) {
@@ -56,7 +61,7 @@ __device__ inline void bo_split4_pos(const float (&v)[4], bo_h4 &hi, bo_h4 &lo, 
 // LAB (scripts/split_lab.hip only): 0 = the kernel; 1 = no weight loads; 2 = no B operand reads; 3 = B operand reads into a dead
 // register set (issued, never waited for by an MFMA); 4 = no epilogue; 5 = 1 + 2 + 4
 // BD = how many K-steps ahead of its MFMAs a B operand is read from LDS (1: two register sets; 2, 3: four);
-// AR = weight-fragment sets = how many K-steps ahead a weight fragment is requested (8, or 12 with the loop unrolled 24-fold)
+// AR = weight-fragment sets = how many K-steps ahead a weight fragment is requested (4 or 8, or 12 with the loop unrolled 24-fold)
 template <int C, int MT, int LAB = 0, int BD = 1, int AR = 8>
 __global__ void __launch_bounds__(256)
 bo_k_tower_s(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const float *__restrict__ params,
@@ -69,11 +74,19 @@ bo_k_tower_s(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kg = lane >> 5, n = lane & 31;
     const int cell0 = ((n >> 3) + 1) * 10 + (n & 7) + 1;  // padded cell of position n; position n + 32 is cell0 + 40
 
+    // launch timing (bench.py's live roofline leg; works inside captured graphs, where no event pair can sit between two nodes): the
+    // first workgroup notes when it starts, the workgroup that finishes last notes when, in slot seq % CAP of the caller's buffer;
+    // seq only moves when a launch has ended, so every workgroup of a launch reads the same value (one launch per buffer at a time).
+    unsigned long long tseq = 0;
+    if (head.timing) {
+        tseq = __hip_atomic_load(head.timing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (blockIdx.x == 0 && tid == 0) head.timing[2 + tseq % BO_TOWER_TIMING_CAP] = wall_clock64();
+    }
     for (int i = tid; i < 2 * IMGH / 8; i += NT) reinterpret_cast<bo_h8 *>(X)[i] = bo_h8{0, 0, 0, 0, 0, 0, 0, 0};
 
     bo_f32x16 acc[MT][2];      // [tile][position half]: rows = channels 32*(MT*wave + tile) + (r&3) + 8*(r>>2) + 4*kg, col = position n + 32*half
-    constexpr int UNR = AR == 8 ? 8 : 24;
-    static_assert((AR == 8 || AR == 12) && BD >= 1 && BD <= 3, "ring sizes the unrolled loop can index statically");
+    constexpr int UNR = (AR == 8 || AR == 4) ? 8 : 24;
+    static_assert((AR == 4 || AR == 6 || AR == 8 || AR == 12) && BD >= 1 && BD <= 3, "ring sizes the unrolled loop can index statically");
     bo_h8 a[AR][MT][2];        // A fragments (hi, lo) of AR consecutive K-steps
     constexpr int BM = BD == 1 ? 1 : 3;
     bo_h8 bq[BM + 1][2][2];    // B operands of consecutive K-steps: [set][position half][hi | lo]
@@ -300,6 +313,17 @@ bo_k_tower_s(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
                         else head.out_b[((size_t)b * (head.channels - head.split) + (oc - head.split)) * 64 + sq] = v;
                     }
                 }
+            }
+        }
+    }
+    if (head.timing) {
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long arrived = __hip_atomic_fetch_add(head.timing + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (arrived + 1 == gridDim.x) {  // the launch's last workgroup
+                head.timing[2 + BO_TOWER_TIMING_CAP + tseq % BO_TOWER_TIMING_CAP] = wall_clock64();
+                __hip_atomic_store(head.timing + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(head.timing, tseq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }

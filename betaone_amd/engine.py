@@ -126,6 +126,8 @@ _SYMBOLS = {
     "bo_nn_tower_create": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p,
                                      C.c_int, C.POINTER(C.c_void_p)]),
     "bo_nn_tower_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "bo_device_wall_clock_khz": (C.c_int, [C.c_int, _I32P]),
+    "bo_nn_tower_forward_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "bo_nn_value_tail": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "bo_nn_tower_destroy": (None, [C.c_void_p]),
     "bo_select_wide": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int,

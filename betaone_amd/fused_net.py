@@ -560,7 +560,11 @@ class FusedPolicyValueNet(nn.Module):
             if timed is not None:
                 timed.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
                 timed[-1][0].record()
-            rc = self.lib.bo_nn_tower_forward(self._tower, x.data_ptr(), None, pa.data_ptr(), pb.data_ptr(), B, stream)
+            tbuf = self.__dict__.get("tower_timing_buf")  # (Rollout(time_tower=True): the kernel notes its own duration, also inside graphs)
+            if tbuf is not None and self.conv == "tower_split":
+                rc = self.lib.bo_nn_tower_forward_timed(self._tower, x.data_ptr(), None, pa.data_ptr(), pb.data_ptr(), B, tbuf.data_ptr(), stream)
+            else:
+                rc = self.lib.bo_nn_tower_forward(self._tower, x.data_ptr(), None, pa.data_ptr(), pb.data_ptr(), B, stream)
             if timed is not None:
                 timed[-1][1].record()
             out = (pa, pb)

@@ -115,11 +115,14 @@ class Rollout:
                  dirichlet_epsilon: float = 0.25, max_plies: Optional[int] = None, max_game_moves: int = 16384,
                  temperature=(30, 1.0, 0.1), device: str = "cuda:0", use_graph: bool = True, autocast: bool = False,
                  rng_mode: str = "python", policy_kind: str = "logits", fast: bool = False, leaves_per_step: int = 16,
-                 fast_arena_granules: int = 0, stream: Optional["torch.cuda.Stream"] = None):
+                 fast_arena_granules: int = 0, stream: Optional["torch.cuda.Stream"] = None, time_tower: bool = False):
         self.device = E.runtime_device(device)
         # `stream`: every launch of this Rollout goes to that HIP stream (CohortRollout: one stream per cohort of games, so that
         # one cohort's tower runs while another's tree step / head kernels / host turn are in progress); None = torch's current one
-        self._main = stream  # 'cuda' -> cuda:<current device>: engine, NN rows and model on ONE GPU
+        self._main = stream
+        # time_tower (measurement, bench.py): every launch of the split-precision tower made by THIS Rollout notes its own duration in
+        # this buffer (bo_nn_tower_forward_timed: works inside captured graphs) -- [seq | arrivals | start[4096] | end[4096]]
+        self.tower_timing = torch.zeros(2 + 2 * 4096, dtype=torch.int64, device=self.device) if time_tower else None  # 'cuda' -> cuda:<current device>: engine, NN rows and model on ONE GPU
         self.G = int(n_games)
         self.S, self.B = int(num_simulations), int(mcts_batch_size)
         self.alpha = float(dirichlet_alpha)
@@ -203,6 +206,8 @@ class Rollout:
         return torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
 
     def _forward(self):
+        if self.tower_timing is not None:  # (one host thread drives every cohort: the buffer named here is the one this forward's launch gets)
+            getattr(self.model, "net", self.model).tower_timing_buf = self.tower_timing
         want_probs = self.policy_kind == E.POLICY_PROBS
         fused = getattr(self.model, "forward_probs", None) if (want_probs and not self.autocast) else None
         with torch.no_grad():

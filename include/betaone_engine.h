@@ -357,6 +357,13 @@ int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layers, const fl
                        const float *params, int64_t n_params, int channels, int algo, const bo_tower_head_desc *head, int device,
                        bo_tower **out);
 int bo_nn_tower_forward(bo_tower *tower, const float *x_dev, float *y_dev, void *head_a_dev, void *head_b_dev, int batch, void *stream);
+/* (ABI 4) bo_nn_tower_forward with the launch's duration noted by the kernel itself (BO_TOWER_SPLIT_F16): timing_dev = uint64
+ * [seq | arrivals | start[4096] | end[4096]], zeroed by the caller; launch k with this buffer leaves (first workgroup's start, last
+ * workgroup's end) in slot k % 4096, in ticks of the device's constant-rate clock.  One launch per buffer at a time.  Measurement aid
+ * (bench.py's live roofline leg: event pairs cannot sit between the nodes of a captured graph). */
+int bo_device_wall_clock_khz(int device, int32_t *khz_out);   /* rate of that clock (hipDeviceAttributeWallClockRate) */
+int bo_nn_tower_forward_timed(bo_tower *tower, const float *x_dev, float *y_dev, void *head_a_dev, void *head_b_dev, int batch,
+                              void *timing_dev, void *stream);
 int bo_nn_value_tail(const float *h_dev, const float *w_dev, const float *bias_dev, float *out_dev, int batch, int hidden, void *stream);
 void bo_nn_tower_destroy(bo_tower *tower);
 /* BO_TOWER_SPLIT_F16 carries every activation as a pair of fp16 numbers: a value beyond +-65504 is saturated and the forward's result
