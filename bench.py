@@ -105,6 +105,8 @@ def parse():
         ap.error("--cohorts must divide --games (and is 1 with --fast)")
     if args.fast and args.steps == 20 and args.warmup == 3:
         args.steps, args.warmup = 1, 0  # (a ply of 32768 games x 800 simulations is 26 M evaluations: ~12 s)
+    if args.fast and args.opening_steps == 20:
+        args.opening_steps = 0          # (the opening-only extra would be twenty such plies)
     return args
 
 
