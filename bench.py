@@ -383,7 +383,8 @@ def fast_select_sweep(ro, drv, steps=12):
     """Every variant of the select + backup kernel over `steps` more launches each on this run's trees (they keep growing meanwhile;
     when the searches run out of simulations a ply is played in between)."""
     out = []
-    for ut, fl in ((2, 18), (2, 16), (2, 19), (2, 0), (4, 8)):  # (flags 16..19: eight lanes per game; 0..7: half a wave per game; 8 / 9: one lane per game)
+    variants = ((2, 32), (2, 36), (2, 16)) if ro.G > 40000 else ((2, 32), (2, 36), (2, 34), (2, 18), (2, 16), (2, 19), (2, 0), (4, 8))
+    for ut, fl in variants:  # (flags 32 / 34: four lanes per game; 16..19: eight; 0..7: half a wave; 8 / 9: one lane)
         if True:
             ro.eng.fast_options(games_per_halfwave=ut, select_flags=fl)
             r = fast_select_roofline(ro, drv, steps, f" u{ut} flags{fl}")

@@ -479,6 +479,15 @@ static int launch_fw_select(bo_engine *e, const float *value_dev, int kind, void
         if (f.sel_flags & FW_SEL_NT) return RT_LAUNCH(bo_k_fw_select_lane_nt, blocks, stream, e->d, e->f, value_dev, kind);
         return RT_LAUNCH(bo_k_fw_select_lane, blocks, stream, e->d, e->f, value_dev, kind);
     }
+    if (L <= 8 && (f.sel_flags & FW_SEL_QUAD)) {  // four lanes per game, sixteen games per wave
+        const int blocks = (G + 15) / 16;
+#define SELQ(K) return RT_LAUNCH(K, blocks, stream, e->d, e->f, value_dev, kind)
+        if (L > 4) SELQ(bo_k_fw_select_q4l8_0);
+        if (f.sel_flags & FW_SEL_DENSE) SELQ(bo_k_fw_select_q4l4_4);
+        if (f.sel_flags & FW_SEL_ROOT_IN_REGS) SELQ(bo_k_fw_select_q4l4_2);
+        SELQ(bo_k_fw_select_q4l4_0);
+#undef SELQ
+    }
     if (L <= 8 && (f.sel_flags & FW_SEL_OCT)) {  // eight lanes per game, eight games per wave
         const int blocks = (G + 7) / 8;
         const int fl = f.sel_flags & 3;
@@ -1156,7 +1165,7 @@ extern "C" int bo_fast_options(bo_engine *e, int32_t tree_reuse, int32_t games_p
         return fail(BO_E_ARG, "bo_fast_options: games_per_halfwave must be 1, 2 or 4");
     if (tree_reuse >= 0) e->fast_reuse = tree_reuse ? 1 : 0;
     if (games_per_halfwave >= 0) e->f.sel_ut = games_per_halfwave == 1 ? 2 : games_per_halfwave;  // (one game per half-wave is the form for more than 16 leaves per step)
-    if (select_flags >= 0) e->f.sel_flags = select_flags & (FW_SEL_NT | FW_SEL_ROOT_IN_REGS | FW_SEL_DENSE | FW_SEL_LANE | FW_SEL_OCT);
+    if (select_flags >= 0) e->f.sel_flags = select_flags & (FW_SEL_NT | FW_SEL_ROOT_IN_REGS | FW_SEL_DENSE | FW_SEL_LANE | FW_SEL_OCT | FW_SEL_QUAD);
     return BO_OK;
 }
 

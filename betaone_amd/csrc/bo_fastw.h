@@ -61,7 +61,7 @@
 #define FW_DRAW (-3)
 #define FW_SIM_MATE (-2)      // sim_row codes of simulations that ended in a known terminal (no NN row)
 #define FW_SIM_DRAW (-3)
-enum { FW_SEL_NT = 1, FW_SEL_ROOT_IN_REGS = 2, FW_SEL_DENSE = 4, FW_SEL_LANE = 8, FW_SEL_OCT = 16 };  // FastW::sel_flags
+enum { FW_SEL_NT = 1, FW_SEL_ROOT_IN_REGS = 2, FW_SEL_DENSE = 4, FW_SEL_LANE = 8, FW_SEL_OCT = 16, FW_SEL_QUAD = 32 };  // FastW::sel_flags
 
 struct alignas(16) WRec {
     int n;        // visits; -1 = padding of a run's last granule, never selected
@@ -268,6 +268,7 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
     constexpr int NGRP = 64 / W, NSL = NGRP * UT;  // groups of lanes per wave; games per wave
     constexpr int CSL = FWC_HEAD + FWR_FIELDS * LCAP, NCR = (CSL + W - 1) / W, NVR = (LCAP + W - 1) / W;
     static_assert(LCAP <= W * 2, "row list scan covers two words per lane");
+    static_assert(RPL <= 16, "in-flight counts are packed for sixteen passes");
     constexpr int BO_FW_BK_CH = UT >= 4 ? 2 : 4;  // simulations of a game whose backups are fetched together and chained in registers
     BO_SHARED int s_ctl[NSL][NCR * W];                         // the games' control blocks
     BO_SHARED float s_val[NSL][NVR * W];                       // values of the step's rows
@@ -355,11 +356,12 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
         int term_sims[UT], deep[UT];
         BO_UNROLL
         for (int u = 0; u < UT; u++) term_sims[u] = deep[u] = 0;
+        constexpr int DS = W >= 8 ? 1 : 2;  // path depths a lane owns in the register-chained backup: c (+ W with four lanes per game)
         for (int s0 = 0; s0 < maxstep; s0 += BO_FW_BK_CH) {
-            int rec[UT][BO_FW_BK_CH];
-            bool val[UT][BO_FW_BK_CH];
-            float sgn[UT][BO_FW_BK_CH];
-            fw_nw x[UT][BO_FW_BK_CH];
+            int rec[UT][BO_FW_BK_CH][DS];
+            bool val[UT][BO_FW_BK_CH][DS];
+            float sgn[UT][BO_FW_BK_CH][DS];
+            fw_nw x[UT][BO_FW_BK_CH][DS];
             BO_UNROLL
             for (int u = 0; u < UT; u++) {
                 const int *sp = f.sim_path + (size_t)FW_G(u) * L * BO_FW_PATH_CAP;
@@ -378,48 +380,57 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
                         v = q == FW_SIM_MATE ? 1.0f : 0.0f;
                         term_sims[u] += ok ? 1 : 0;
                     }
-                    if (plen > W) deep[u] = 1;
-                    val[u][j] = c >= 1 && c < plen;  // the root (depth 0) only counts visits
-                    sgn[u][j] = ((plen - 1 - c) & 1) ? -v : v;
-                    rec[u][j] = val[u][j] ? (s0 == 0 ? pid[u][j] : sp[(size_t)s * BO_FW_PATH_CAP + c]) : 0;
-                }
-            }
-            BO_UNROLL
-            for (int u = 0; u < UT; u++) {
-                BO_UNROLL
-                for (int j = 0; j < BO_FW_BK_CH; j++) {
-                    x[u][j].n = 0; x[u][j].w = 0.0f;
-                    if (val[u][j]) x[u][j] = fw_ld_nw(FW_A(u) + rec[u][j]);
-                }
-            }
-            BO_UNROLL
-            for (int u = 0; u < UT; u++) {
-                BO_UNROLL
-                for (int j = 0; j < BO_FW_BK_CH; j++) {
-                    if (!val[u][j]) continue;
+                    if (plen > W * DS) deep[u] = 1;
                     BO_UNROLL
-                    for (int i = 0; i < j; i++)
-                        if (val[u][i] && rec[u][i] == rec[u][j]) x[u][j] = x[u][i];  // (the latest earlier simulation through the same record wins)
-                    x[u][j].n = x[u][j].n + 1;
-                    x[u][j].w = x[u][j].w + sgn[u][j];
+                    for (int ds = 0; ds < DS; ds++) {
+                        const int cd = c + W * ds;
+                        val[u][j][ds] = cd >= 1 && cd < plen;  // the root (depth 0) only counts visits
+                        sgn[u][j][ds] = ((plen - 1 - cd) & 1) ? -v : v;
+                        rec[u][j][ds] = val[u][j][ds] ? ((s0 == 0 && ds == 0) ? pid[u][j] : sp[(size_t)s * BO_FW_PATH_CAP + cd]) : 0;
+                    }
                 }
+            }
+            BO_UNROLL
+            for (int u = 0; u < UT; u++) {
                 BO_UNROLL
                 for (int j = 0; j < BO_FW_BK_CH; j++)
-                    if (val[u][j]) fw_st_nw(FW_A(u) + rec[u][j], x[u][j].n, x[u][j].w);
+                    BO_UNROLL
+                    for (int ds = 0; ds < DS; ds++) {
+                        x[u][j][ds].n = 0; x[u][j][ds].w = 0.0f;
+                        if (val[u][j][ds]) x[u][j][ds] = fw_ld_nw(FW_A(u) + rec[u][j][ds]);
+                    }
+            }
+            BO_UNROLL
+            for (int u = 0; u < UT; u++) {
+                BO_UNROLL
+                for (int ds = 0; ds < DS; ds++) {  // (a record sits at one depth only: the slots are independent chains)
+                    BO_UNROLL
+                    for (int j = 0; j < BO_FW_BK_CH; j++) {
+                        if (!val[u][j][ds]) continue;
+                        BO_UNROLL
+                        for (int i = 0; i < j; i++)
+                            if (val[u][i][ds] && rec[u][i][ds] == rec[u][j][ds]) x[u][j][ds] = x[u][i][ds];  // (the latest earlier simulation through the same record wins)
+                        x[u][j][ds].n = x[u][j][ds].n + 1;
+                        x[u][j][ds].w = x[u][j][ds].w + sgn[u][j][ds];
+                    }
+                    BO_UNROLL
+                    for (int j = 0; j < BO_FW_BK_CH; j++)
+                        if (val[u][j][ds]) fw_st_nw(FW_A(u) + rec[u][j][ds], x[u][j][ds].n, x[u][j][ds].w);
+                }
             }
         }
         BO_UNROLL
         for (int u = 0; u < UT; u++) {
             root_n[u] = rootrec[u].n; root_link[u] = rootrec[u].link;
             if (!bk[u]) continue;
-            if (deep[u]) {  // path depths W..63 (rare): one simulation at a time
+            if (deep[u]) {  // path depths W * DS .. 63 (rare): one simulation at a time
                 const int *sp = f.sim_path + (size_t)FW_G(u) * L * BO_FW_PATH_CAP;
                 for (int s = 0; s < n_step[u]; s++) {
                     const int q = FW_C(u, FWC_F(L, FWS_ROW, s)), plen = FW_C(u, FWC_F(L, FWS_PLEN, s));
                     float v;
                     if (q >= 0) { const int t = FW_C(u, FWC_F(L, FWR_TERM, q)); v = t > 0 ? (t == 1 ? 1.0f : 0.0f) : -s_val[FW_SLOT(u)][q]; }
                     else v = q == FW_SIM_MATE ? 1.0f : 0.0f;
-                    for (int k = c + W; k < plen; k += W) {
+                    for (int k = c + W * DS; k < plen; k += W) {
                         WRec *R = FW_A(u) + sp[(size_t)s * BO_FW_PATH_CAP + k];
                         const fw_nw y = fw_ld_nw(R);
                         fw_st_nw(R, y.n + 1, y.w + (((plen - 1 - k) & 1) ? -v : v));
@@ -532,18 +543,20 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
             bool ok[RPL];
             float rq[RPL], ru[RPL];
             bool beyond = lv && pn[u] >= BO_FW_SQRT_TAB;
-            unsigned cpk = 0u;  // descents in flight through this lane's records: 4 bits per pass (an index b belongs to lane b % W, pass b / W)
+            unsigned cpk = 0u, cpk1 = 0u;  // descents in flight through this lane's records: 4 bits per pass (an index b belongs to lane b % W,
+                                           // pass b / W); passes 8..15 (a lane of the four-lane form holds ten records) in the second word
             BO_UNROLL
             for (int sp = 0; sp < LCAP - 1; sp++) {
                 const unsigned bb = (iw[sp >> 2] >> (8 * (sp & 3))) & 255u;
                 const unsigned mine = (unsigned)((M[u] >> sp) & 1) & ((bb % W) == (unsigned)c ? 1u : 0u);
                 cpk += (bb / W < 8u ? mine : 0u) << (4 * (bb / W & 7u));
+                if (RPL > 8) cpk1 += ((bb / W >= 8u && bb / W < 16u) ? mine : 0u) << (4 * (bb / W & 7u));
             }
             int nkl = 0;
             BO_UNROLL
             for (int k = 0; k < RPL; k++) {
                 if (LCAP <= 16) {
-                    cnt[k] = k < 8 ? (int)((cpk >> (4 * k)) & 15u) : 0;
+                    cnt[k] = k < 8 ? (int)((cpk >> (4 * k)) & 15u) : k < 16 ? (int)((cpk1 >> (4 * (k - 8))) & 15u) : 0;
                 } else {  // (more than 15 descents can share a record: count them one by one)
                     cnt[k] = 0;
                     BO_UNROLL
@@ -610,14 +623,16 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
             int nk = nkl;  // children scanned at this level: the lanes' counts added up alongside
 #define BO_FW_RED(kind_)                                                                                                 \
             { const float o = __builtin_bit_cast(float, BO_ROW_XCHG(__builtin_bit_cast(int, mx), kind_)); mx = o > mx ? o : mx; nk += BO_ROW_XCHG(nk, kind_); }
-            BO_FW_RED(0) BO_FW_RED(1) BO_FW_RED(2)
+            BO_FW_RED(0) BO_FW_RED(1)
+            if (W >= 8) BO_FW_RED(2)
             if (W >= 16) BO_FW_RED(3)
             if (W >= 32) { const float o = bo_shfl_xor_f(mx, 16); mx = o > mx ? o : mx; nk += bo_shfl_xor(nk, 16); }
 #undef BO_FW_RED
             // the lowest child index among the lanes that hold the maximum: a minimum over the group
             int win = (lv && best == mx && mx > -__builtin_inff()) ? bi : 0x7fffffff;
 #define BO_FW_MIN(kind_) { const int o = BO_ROW_XCHG(win, kind_); win = o < win ? o : win; }
-            BO_FW_MIN(0) BO_FW_MIN(1) BO_FW_MIN(2)
+            BO_FW_MIN(0) BO_FW_MIN(1)
+            if (W >= 8) BO_FW_MIN(2)
             if (W >= 16) BO_FW_MIN(3)
             if (W >= 32) { const int o = bo_shfl_xor(win, 16); win = o < win ? o : win; }
 #undef BO_FW_MIN
@@ -1091,6 +1106,14 @@ BO_FW_SELECT_KERNEL(1, 64, 0, ) BO_FW_SELECT_KERNEL(1, 64, 3, )
     }
 BO_FW_SELECT_OCT(4, 0) BO_FW_SELECT_OCT(4, 1) BO_FW_SELECT_OCT(4, 2) BO_FW_SELECT_OCT(4, 3)
 BO_FW_SELECT_OCT(8, 0) BO_FW_SELECT_OCT(8, 2)
+// four lanes per game: sixteen games per wave-instruction, ten records per lane -- the per-level work that does not grow with the
+// records a lane holds (reductions, in-flight masks, row / path bookkeeping, the next request) is shared by twice the games
+#define BO_FW_SELECT_QUAD(LCAP, FL, OCC)                                                                               \
+    OCC BO_KERNEL void bo_k_fw_select_q4l##LCAP##_##FL(Eng e, FastW f, const float *value, int kind) {                  \
+        fw_select_body<4, 10, 1, LCAP, ((FL) & FW_SEL_NT) != 0, ((FL) & FW_SEL_ROOT_IN_REGS) != 0>(e, f, value, kind);  \
+    }
+BO_FW_SELECT_QUAD(4, 0, ) BO_FW_SELECT_QUAD(4, 2, ) BO_FW_SELECT_QUAD(8, 0, )
+BO_FW_SELECT_QUAD(4, 4, BO_FW_OCC(4))   // FW_SEL_DENSE: registers capped for four waves per SIMD = 65 536 games resident at once
 
 // ---- leaf: materialise the position of row r, its legal moves, is_game_over(claim_draw=True), its planes ------------------
 BO_KERNEL void bo_k_fw_leaf(Eng e, FastW f, float *nn_in) {

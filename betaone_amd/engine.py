@@ -422,7 +422,7 @@ class Engine:
                                              -1 if games_per_halfwave is None else int(games_per_halfwave),
                                              -1 if select_flags is None else int(select_flags)))
 
-    SEL_NT, SEL_ROOT_IN_REGS, SEL_DENSE, SEL_LANE, SEL_OCT = 1, 2, 4, 8, 16
+    SEL_NT, SEL_ROOT_IN_REGS, SEL_DENSE, SEL_LANE, SEL_OCT, SEL_QUAD = 1, 2, 4, 8, 16, 32
     def debug_fast(self, slot: int, stream: int = 0):
         """(control block of game `slot` as a dict of its fields, paths [L, 64] of the step's simulations) -- bo_debug_fast."""
         L = self.L

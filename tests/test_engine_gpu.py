@@ -498,7 +498,7 @@ def test_fast_select_kernel_variants_on_gpu_match_restatement(backend, L, ut):
     capped registers}) with a different position in every game slot: whole trees against tests/fast_reference.py, bit for bit."""
     import test_fast_mode_emu as T
 
-    for flags in list(range(10)) + [16, 17, 18, 19]:  # (8, 9: one lane per game; 16..19: eight lanes per game)
+    for flags in list(range(10)) + [16, 17, 18, 19, 32, 34]:  # (8, 9: one lane per game; 16..19: eight lanes per game; 32, 34: four)
         T.check_multi("hip", L, 80, dict(games_per_halfwave=ut, select_flags=flags))
 
 
@@ -506,7 +506,7 @@ def test_fast_select_kernel_variants_on_gpu_match_restatement(backend, L, ut):
 def test_fast_select_kernel_more_leaves_per_step_on_gpu(backend, L, sims):
     import test_fast_mode_emu as T
 
-    for flags in (0, 3) + ((16, 18) if L <= 8 else ()):
+    for flags in (0, 3) + ((16, 18, 32) if L <= 8 else ()):
         T.check_multi("hip", L, sims, dict(select_flags=flags))
 
 

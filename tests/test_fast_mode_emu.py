@@ -254,6 +254,11 @@ def check_multi(backend, L, sims, opts):
     (3, 60, dict(select_flags=17)),
     (7, 84, dict(select_flags=16)),
     (8, 96, dict(select_flags=18)),
+    (4, 90, dict(select_flags=32)),      # four lanes per game: ten records per lane, two path depths per lane in the backup
+    (4, 130, dict(select_flags=34)),
+    (3, 60, dict(select_flags=32)),
+    (7, 84, dict(select_flags=32)),
+    (8, 96, dict(select_flags=32)),
     (4, 70, dict()),                      # the defaults
     (4, 60, dict(games_per_halfwave=4, select_flags=2)),
     (4, 60, dict(games_per_halfwave=4, select_flags=0)),
