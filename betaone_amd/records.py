@@ -110,6 +110,9 @@ def compact_path(data_dir: str, iteration: int, rank: int = 0) -> str:
     return os.path.join(data_dir, f"iter_{iteration}", f"games_rank{rank}{COMPACT_SUFFIX}")
 
 
+_KNOWN_COMPLETE: Dict[str, int] = {}  # path -> its size after this process's last complete append
+
+
 def complete_prefix_bytes(path: str) -> int:
     """Length of the leading run of complete games in the compact file `path` (0 for a missing / empty file): where the next
     game has to be appended.  A writer killed inside a write leaves a partial record behind the last complete game."""
@@ -133,13 +136,17 @@ def save_games(path: str, finished: Sequence, append: bool = True) -> int:
     if not blob:
         return 0
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-    keep = complete_prefix_bytes(path) if append else 0
+    key = os.path.abspath(path)
+    size = os.path.getsize(path) if os.path.exists(path) else 0
+    # (a file this process left complete is not scanned again: the scan is for what a PREVIOUS, killed writer may have left behind)
+    keep = 0 if not append else (size if _KNOWN_COMPLETE.get(key) == size else complete_prefix_bytes(path))
     with open(path, "r+b" if (append and os.path.exists(path)) else "wb") as fh:
         fh.truncate(keep)
         fh.seek(keep)
         fh.write(blob)
         fh.flush()
         os.fsync(fh.fileno())
+    _KNOWN_COMPLETE[key] = keep + len(blob)
     return len(blob)
 
 

@@ -726,6 +726,9 @@ class CohortRollout:
         self.device = E.runtime_device(kw.get("device", "cuda:0"))
         self.G, self.K, self.Gc = int(n_games), K, int(n_games) // K
         models = list(model) if isinstance(model, (list, tuple)) else [model] * K
+        if K > 1 and len({id(m) for m in models}) < K and any(getattr(getattr(m, "net", m), "conv", None) == "tower_b1" for m in models):
+            raise ValueError("CohortRollout: a conv='tower_b1' evaluate stage keeps its hand-off buffers in ONE handle (one launch in flight at "
+                             "a time): pass one inference copy per cohort")
         # (cohort 0 keeps torch's current stream semantics only when it is alone; with K > 1 every cohort gets a stream of its own)
         self.parts: List[Rollout] = []
         for k in range(K):
