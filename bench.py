@@ -67,7 +67,10 @@ def parse():
                          "(csrc/bo_tower_s.h); 'fp32' = the fp32-MFMA Winograd tower of rounds 1-2 (csrc/bo_tower_wg.h)")
     ap.add_argument("--cohorts", type=int, default=None,
                     help="the resident games as K phase-shifted cohorts, each with its own engine, HIP stream and captured graphs "
-                         "(betaone_amd.rollout.CohortRollout); results per game are identical for every K; default: 2 from 128 games up, else 1")
+                         "(betaone_amd.rollout.CohortRollout); results per game are identical for every K; default: 4 from 256 games up, 2 from 128, else 1")
+    ap.add_argument("--cu-masks", default=None, choices=["auto", "off", "contiguous", "interleaved"],
+                    help="cohort streams confined to disjoint 1/K shares of the compute units (hipExtStreamCreateWithCUMask; default: "
+                         "BETAONE_COHORT_CU_MASK or off; with 4 cohorts 'contiguous' is what keeps their towers off each other's CUs)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -99,8 +102,8 @@ def parse():
     for k, v in (d_fast if args.fast else d_ref).items():
         if getattr(args, k) is None:
             setattr(args, k, v)
-    if args.cohorts is None:  # two phase-shifted cohorts where each still fills its half of the chip's CUs (measured: +4..7 % per ply)
-        args.cohorts = 2 if (args.games % 2 == 0 and args.games // 2 >= 64) else 1
+    if args.cohorts is None:  # phase-shifted cohorts of >= 64 games (measured at 256 games: two +4..7 % per ply, four on disjoint CU sets +2.7 % more)
+        args.cohorts = next((k for k in (4, 2) if args.games % k == 0 and args.games // k >= 64), 1)
     if args.cohorts < 1 or args.games % args.cohorts or (args.fast and args.cohorts > 1):
         ap.error("--cohorts must divide --games (and is 1 with --fast)")
     if args.fast and args.steps == 20 and args.warmup == 3:
@@ -574,7 +577,7 @@ def main():
                  fast_arena_granules=(args.arena_granules_per_expansion * (args.sims + args.leaves + 2) if args.fast else 0),
                  policy_kind="probs" if args.softmax == "torch" else "logits",
                  time_tower=(not args.no_roofline and not args.fast and args.net_dtype == "fp32"))
-    ro = CohortRollout(net, G, cohorts=args.cohorts, **ro_kw) if args.cohorts > 1 else Rollout(net, G, **ro_kw)
+    ro = CohortRollout(net, G, cohorts=args.cohorts, cu_masks=args.cu_masks, **ro_kw) if args.cohorts > 1 else Rollout(net, G, **ro_kw)
     if args.fast and G * args.leaves > 65536:
         ro.MAX_GRAPH_ITERATIONS = 4 if G * args.leaves <= 131072 else 2  # (every iteration of a captured graph keeps its own logits / probabilities: 6.5 GB at 131072 rows)
     if args.fast and (args.select_games_per_halfwave is not None or args.select_flags is not None):
@@ -710,7 +713,7 @@ def main():
                                    + (f"steady state (games at every stage after {args.preroll} untimed pre-roll plies with staggered starts; finished games are "
                                       f"exported and their slots refilled inside the timed region); " if args.preroll > 0 else "opening phase (all games start together); ")
                                    + cfg_name,
-                       "games_per_gpu": G, "cohorts": args.cohorts, "sims_per_move": args.sims, "net": args.net, "net_dtype": args.net_dtype,
+                       "games_per_gpu": G, "cohorts": args.cohorts, "cohort_cu_masks": getattr(ro, "cu_masks", "off") if args.cohorts > 1 else None, "sims_per_move": args.sims, "net": args.net, "net_dtype": args.net_dtype,
                        "hipgraph": not args.no_graph, "net_layout": net_layout, "policy_softmax": softmax_site(net, args, G * (args.leaves if args.fast else 1)), "evaluate_stage": getattr(getattr(net, "net", net), "route", net_layout), "hw_queues": betaone_amd.hw_queues(), "preroll_plies": args.preroll,
                        "search_mode": ("fast: virtual loss, %d leaves/step, full-width expansion (NOT the reference's semantics)" % args.leaves)
                                       if args.fast else "reference semantics (bit-exact)",

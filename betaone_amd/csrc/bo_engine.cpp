@@ -1763,6 +1763,56 @@ extern "C" void bo_nn_b1_destroy(bo_b1 *t) {
     delete t;
 }
 
+// LAB: a one-thread kernel that notes the device's constant-rate clock: ring[0] = entries written (atomic), entry k = ring[1 + 2k] =
+// tag, ring[2 + 2k] = wall_clock64() -- enqueued between the launches of a stream (also inside captured graphs) it gives the timeline of
+// that stream's phases as the device ran them (rocprofv3 changes how streams overlap; event pairs cannot sit between graph nodes).
+#if !defined(BO_WAVE_EMU)
+__global__ void bo_k_stamp(unsigned long long *ring, unsigned long long tag, unsigned long long cap) {
+    const unsigned long long k = __hip_atomic_fetch_add(ring, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k < cap) { ring[1 + 2 * k] = tag; ring[2 + 2 * k] = wall_clock64(); }
+}
+#endif
+extern "C" int bo_debug_stamp(void *ring_dev, uint64_t tag, uint64_t capacity, void *stream) {
+#if defined(BO_WAVE_EMU)
+    (void)ring_dev; (void)tag; (void)capacity; (void)stream;
+    return fail(BO_E_CONFIG, "gfx950 only");
+#else
+    if (!ring_dev) return fail(BO_E_ARG, "null ring");
+    hipLaunchKernelGGL(bo_k_stamp, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long *)ring_dev, (unsigned long long)tag, (unsigned long long)capacity);
+    RT((int)hipGetLastError());
+    return BO_OK;
+#endif
+}
+
+// A stream whose kernels run on the compute units named by the mask only (bit i = CU i).  K cohorts with disjoint sets: their towers
+// (one workgroup per board, grid far below the chip) no longer share CUs while others idle -- profiles/r04_cohort_cu_masks.md.
+extern "C" int bo_stream_create_cu_mask(int device, const uint32_t *mask_words, int n_words, void **stream_out) {
+#if defined(BO_WAVE_EMU)
+    (void)device; (void)mask_words; (void)n_words; (void)stream_out;
+    return fail(BO_E_CONFIG, "gfx950 only");
+#else
+    if (!mask_words || n_words < 1 || !stream_out) return fail(BO_E_ARG, "bad arguments");
+    bool any = false;
+    for (int i = 0; i < n_words; i++) any = any || mask_words[i] != 0;
+    if (!any) return fail(BO_E_ARG, "an empty CU mask would never run a kernel");
+    RT((int)hipSetDevice(device));
+    hipStream_t st = nullptr;
+    RT((int)hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, mask_words));
+    *stream_out = (void *)st;
+    return BO_OK;
+#endif
+}
+extern "C" int bo_stream_destroy(void *stream) {
+#if defined(BO_WAVE_EMU)
+    (void)stream;
+    return fail(BO_E_CONFIG, "gfx950 only");
+#else
+    if (!stream) return BO_OK;
+    RT((int)hipStreamDestroy((hipStream_t)stream));
+    return BO_OK;
+#endif
+}
+
 // ---- policy FC + softmax + value head behind the tower: two launches (bo_heads.h) ------------------------------------
 extern "C" int bo_nn_heads(const void *p_dev, const void *v_dev, const float *wp_dev, const float *bp_dev, const float *w1_dev,
                            const float *b1_dev, const float *w2_dev, const float *b2_dev, float *policy_out_dev, float *value_out_dev,

@@ -40,11 +40,13 @@ _TABLES = {
     #   POLICY_SOFTMAX  "torch" = torch.softmax(logits, dim=1) exactly where the reference calls it (mcts.py:185,287), inside
     #                 the captured graph; the engine gathers probabilities (the seam the parity tests record).
     #                 "engine" = the step kernel's own softmax over the logits row (hardware exp; within 1e-5 relative)
-    #   COHORTS       run_self_play_games: the resident games as this many phase-shifted cohorts, each on its own HIP stream
+    #   COHORTS       run_self_play_games: the resident games as UP TO this many phase-shifted cohorts, each on its own HIP stream
     #                 (rollout.CohortRollout: one cohort's tower overlaps another's tree step, heads and ply boundary); 1 = one Rollout.
-    #                 Results do not depend on it (games are independent).  Used when it divides the slot count and leaves every
-    #                 cohort at least 64 slots (below that a cohort's kernels no longer fill their share of the CUs).
-    "engine": dict(AUTOCAST=False, SEARCH_MODE="reference", FAST_LEAVES=16, ENGINE_MAX_PLIES=None, POLICY_SOFTMAX="torch", COHORTS=2),
+    #                 Results do not depend on it (games are independent).  The largest of COHORTS, COHORTS/2, ... that divides the slot
+    #                 count and leaves every cohort at least 64 slots is used (below that a cohort's kernels no longer fill their share of
+    #                 the CUs).  From three cohorts up every cohort's stream is confined to its own share of the compute units
+    #                 (BETAONE_COHORT_CU_MASK=off/contiguous/interleaved overrides).
+    "engine": dict(AUTOCAST=False, SEARCH_MODE="reference", FAST_LEAVES=16, ENGINE_MAX_PLIES=None, POLICY_SOFTMAX="torch", COHORTS=4),
 }
 for _group in _TABLES.values():
     globals().update(_group)

@@ -43,7 +43,11 @@ def _inference_copy(model, n_slots: int):
 def _cohorts(n_slots: int, rng_mode: str) -> int:
     k = int(getattr(config, "COHORTS", 1))
     floor = int(getattr(config, "COHORT_MIN_SLOTS", 64))  # (tests lower it to drive small cohorts)
-    return k if (k > 1 and rng_mode == "native" and config.SEARCH_MODE != "fast" and n_slots % k == 0 and n_slots // k >= floor) else 1
+    if rng_mode != "native" or config.SEARCH_MODE == "fast":
+        return 1
+    while k > 1 and (n_slots % k or n_slots // k < floor):  # COHORTS, COHORTS/2, ...: the largest that fits
+        k //= 2
+    return max(k, 1)
 
 
 def _rollout(model, n_slots: int, rng_mode: str = "python"):

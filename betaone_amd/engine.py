@@ -126,7 +126,10 @@ _SYMBOLS = {
     "bo_nn_tower_create": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p,
                                      C.c_int, C.POINTER(C.c_void_p)]),
     "bo_nn_tower_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "bo_debug_stamp": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
     "bo_device_wall_clock_khz": (C.c_int, [C.c_int, _I32P]),
+    "bo_stream_create_cu_mask": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_void_p)]),
+    "bo_stream_destroy": (C.c_int, [C.c_void_p]),
     "bo_nn_tower_forward_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "bo_nn_value_tail": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "bo_nn_tower_destroy": (None, [C.c_void_p]),
@@ -176,6 +179,41 @@ def runtime_device(requested) -> torch.device:
     if dev.type != "cuda":
         raise EngineError(f"betaone_amd runs on an MI355X (device 'cuda' / 'cuda:N', got {requested!r}); there is no CPU path")
     return torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+
+
+def cu_partition_masks(n_cu: int, parts: int, layout: str = "contiguous") -> list:
+    """`parts` disjoint CU sets covering CUs [0, n_cu - n_cu % parts) as uint32 mask words (bit i = CU i): part p owns CUs
+    [p * n_cu / parts, (p + 1) * n_cu / parts) ("contiguous") or the CUs i with i % parts == p ("interleaved")."""
+    if parts < 1 or n_cu < parts:
+        raise ValueError(f"cannot split {n_cu} CUs into {parts} parts")
+    per, words = n_cu // parts, (n_cu + 31) // 32
+    out = []
+    for p in range(parts):
+        m = np.zeros(words, dtype=np.uint32)
+        idx = np.arange(p * per, (p + 1) * per) if layout == "contiguous" else np.arange(per) * parts + p
+        np.bitwise_or.at(m, idx // 32, (np.uint32(1) << (idx % 32).astype(np.uint32)))
+        out.append(m)
+    return out
+
+
+class MaskedStream:
+    """A HIP stream confined to a CU set (bo_stream_create_cu_mask) with its torch view (`.stream`, a torch.cuda.ExternalStream)."""
+
+    def __init__(self, device: torch.device, mask_words: np.ndarray):
+        self.lib = load_hip_library()
+        self.mask = np.ascontiguousarray(mask_words, dtype=np.uint32)
+        h = C.c_void_p()
+        rc = self.lib.bo_stream_create_cu_mask(int(device.index or 0), self.mask.ctypes.data_as(C.POINTER(C.c_uint32)), len(self.mask), C.byref(h))
+        if rc != 0:
+            raise EngineError(f"bo_stream_create_cu_mask: {self.lib.bo_last_error().decode()}")
+        self.handle = h.value
+        self.stream = torch.cuda.ExternalStream(self.handle, device=device)
+
+    def close(self):
+        if self.handle:
+            self.stream.synchronize()
+            self.lib.bo_stream_destroy(C.c_void_p(self.handle))
+            self.handle = None
 
 
 def move_to_uci(m: int) -> str:

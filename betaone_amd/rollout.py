@@ -17,6 +17,7 @@ There is no CPU path here: the engine is csrc/libbetaone_hip.so or an exception.
 from __future__ import annotations
 
 import math
+import os
 import time
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Sequence
@@ -110,6 +111,14 @@ def _on_main(fn):
 
 
 class Rollout:
+    STAMP_RING = None        # LAB (BO_STAMPS=1, scripts/cohort_timeline.py): a device ring every Rollout's phases are stamped into
+    STAMP_CAP = 1 << 18
+    _n_instances = 0
+
+    def _stamp(self, phase: int):
+        if Rollout.STAMP_RING is not None:
+            self.eng.lib.bo_debug_stamp(Rollout.STAMP_RING.data_ptr(), self._stamp_id * 16 + phase, Rollout.STAMP_CAP, self._stream())
+
     def __init__(self, model: torch.nn.Module, n_games: int, *, num_simulations: int = 250, mcts_batch_size: int = 96,
                  cpuct: float = 1.0, widen_coeff: float = 1.5, dirichlet_alpha: float = 0.1,
                  dirichlet_epsilon: float = 0.25, max_plies: Optional[int] = None, max_game_moves: int = 16384,
@@ -120,6 +129,8 @@ class Rollout:
         # `stream`: every launch of this Rollout goes to that HIP stream (CohortRollout: one stream per cohort of games, so that
         # one cohort's tower runs while another's tree step / head kernels / host turn are in progress); None = torch's current one
         self._main = stream
+        self._stamp_id = Rollout._n_instances
+        Rollout._n_instances += 1
         # time_tower (measurement, bench.py): every launch of the split-precision tower made by THIS Rollout notes its own duration in
         # this buffer (bo_nn_tower_forward_timed: works inside captured graphs) -- [seq | arrivals | start[4096] | end[4096]]
         self.tower_timing = torch.zeros(2 + 2 * 4096, dtype=torch.int64, device=self.device) if time_tower else None  # 'cuda' -> cuda:<current device>: engine, NN rows and model on ONE GPU
@@ -225,9 +236,12 @@ class Rollout:
         return logits.contiguous(), value.float().contiguous()
 
     def _eval_and_step_eager(self):
+        self._stamp(1)
         logits, value = self._forward()
+        self._stamp(2)
         self._logits, self._value = logits, value  # keep alive until the step kernel has run
         self.eng.step(logits.data_ptr(), value.data_ptr(), self.policy_kind, self.nn_in.data_ptr(), self._stream())
+        self._stamp(3)
 
     def _capture(self):
         """Capture `net forward -> tree step` once; afterwards a step is one hipGraphLaunch."""
@@ -276,8 +290,11 @@ class Rollout:
             cg, keep = torch.cuda.CUDAGraph(), []
             with torch.cuda.graph(cg):
                 for _ in range(n):
+                    self._stamp(1)
                     logits, value = self._forward()
+                    self._stamp(2)
                     self.eng.step(logits.data_ptr(), value.data_ptr(), self.policy_kind, self.nn_in.data_ptr(), self._stream())
+                    self._stamp(3)
                     keep.append((logits, value))
             g = self._graphs_n[n] = (cg, keep)
         self.n_forward += n
@@ -716,7 +733,7 @@ class CohortRollout:
     games, n_sims, ...); play_ply returns the moves played by the plies it ENDED (0 on the first call, which only begins).
     `drain()` ends the outstanding plies without beginning new ones."""
 
-    def __init__(self, model, n_games: int, cohorts: int = 2, **kw):
+    def __init__(self, model, n_games: int, cohorts: int = 2, cu_masks: Optional[str] = None, **kw):
         K = int(cohorts)
         if K < 1 or n_games % K:
             raise ValueError(f"CohortRollout: {n_games} games do not split into {K} equal cohorts")
@@ -730,9 +747,24 @@ class CohortRollout:
             raise ValueError("CohortRollout: a conv='tower_b1' evaluate stage keeps its hand-off buffers in ONE handle (one launch in flight at "
                              "a time): pass one inference copy per cohort")
         # (cohort 0 keeps torch's current stream semantics only when it is alone; with K > 1 every cohort gets a stream of its own)
+        # cu_masks: every cohort's stream confined to its own 1/K of the compute units ("contiguous" / "interleaved", engine.
+        # cu_partition_masks); None / "off": plain streams, the dispatcher places the cohorts' workgroups as it likes.
+        # "auto" (default, or BETAONE_COHORT_CU_MASK): contiguous from three cohorts up -- unconfined, four 64-board towers land on each
+        # other's CUs (4.2-4.7 ms per ply against 2.9 confined; two cohorts place well either way) -- profiles/r04_cohort_cu_masks.md.
+        self.cu_masks = cu_masks if cu_masks is not None else os.environ.get("BETAONE_COHORT_CU_MASK", "auto")
+        if self.cu_masks == "auto":
+            self.cu_masks = "contiguous" if K > 2 else "off"
+        if self.cu_masks not in ("off", "contiguous", "interleaved"):
+            raise ValueError(f"CohortRollout: cu_masks={self.cu_masks!r} (off / contiguous / interleaved / auto)")
+        self._masked: List[E.MaskedStream] = []
+        if K > 1 and self.device.type == "cuda" and self.cu_masks != "off":
+            n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
+            self._masked = [E.MaskedStream(self.device, m) for m in E.cu_partition_masks(n_cu, K, self.cu_masks)]
         self.parts: List[Rollout] = []
         for k in range(K):
-            st = torch.cuda.Stream(self.device) if (K > 1 and self.device.type == "cuda") else None
+            st = None
+            if K > 1 and self.device.type == "cuda":
+                st = self._masked[k].stream if self._masked else torch.cuda.Stream(self.device)
             self.parts.append(Rollout(models[k], self.Gc, stream=st, **kw))
         if K > 1 and self.device.type == "cuda":
             torch.cuda.synchronize(self.device)  # (buffers zeroed on the constructing stream are used on the cohorts' streams from here on)
@@ -825,5 +857,8 @@ class CohortRollout:
                 p.close()
             except Exception as ex:  # (close every engine; report the first fault)
                 err = err or ex
+        for m in self._masked:  # (graphs captured on these streams went with the parts above)
+            m.close()
+        self._masked = []
         if err is not None:
             raise err

@@ -361,9 +361,18 @@ int bo_nn_tower_forward(bo_tower *tower, const float *x_dev, float *y_dev, void 
  * [seq | arrivals | start[4096] | end[4096]], zeroed by the caller; launch k with this buffer leaves (first workgroup's start, last
  * workgroup's end) in slot k % 4096, in ticks of the device's constant-rate clock.  One launch per buffer at a time.  Measurement aid
  * (bench.py's live roofline leg: event pairs cannot sit between the nodes of a captured graph). */
-int bo_device_wall_clock_khz(int device, int32_t *khz_out);   /* rate of that clock (hipDeviceAttributeWallClockRate) */
 int bo_nn_tower_forward_timed(bo_tower *tower, const float *x_dev, float *y_dev, void *head_a_dev, void *head_b_dev, int batch,
                               void *timing_dev, void *stream);
+int bo_device_wall_clock_khz(int device, int32_t *khz_out);   /* rate of that clock (hipDeviceAttributeWallClockRate) */
+/* LAB: enqueue a one-thread kernel that appends (tag, wall_clock64()) to `ring_dev` (uint64: [count | tag0, t0 | tag1, t1 | ...], zeroed by
+ * the caller, `capacity` entries): the timeline of a stream's phases as the device ran them, also between the nodes of a captured graph. */
+int bo_debug_stamp(void *ring_dev, uint64_t tag, uint64_t capacity, void *stream);
+/* (ABI 4) A HIP stream confined to a set of compute units (hipExtStreamCreateWithCUMask): bit i of mask_words = CU i of `device`.
+ * CohortRollout gives every cohort such a stream with a disjoint set, so that the cohorts' one-board-per-workgroup towers do not land on
+ * the same CUs while others idle (the reference's counterpart is one OS process per game batch, main.py:160-175).  The handle is a
+ * hipStream_t for every `stream` argument of this header and for torch.cuda.ExternalStream. */
+int bo_stream_create_cu_mask(int device, const uint32_t *mask_words, int n_words, void **stream_out);
+int bo_stream_destroy(void *stream);
 int bo_nn_value_tail(const float *h_dev, const float *w_dev, const float *bias_dev, float *out_dev, int batch, int hidden, void *stream);
 void bo_nn_tower_destroy(bo_tower *tower);
 /* BO_TOWER_SPLIT_F16 carries every activation as a pair of fp16 numbers: a value beyond +-65504 is saturated and the forward's result

@@ -150,3 +150,23 @@ def test_split_precision_weight_packing_reconstructs_float32_and_follows_the_doc
     back = hi.double() + lo.double()
     assert bool(((back - x).abs() <= x.abs() * 2.0 ** -21 + 2.0 ** -24).all())
     assert split_scale(torch.zeros(4, 4)) == 1.0
+
+
+def test_cu_partition_masks_are_disjoint_equal_shares_of_the_compute_units():
+    """engine.cu_partition_masks (the CU sets of CohortRollout's masked streams, bo_stream_create_cu_mask): K disjoint sets of
+    n_cu // K CUs each, bit i = CU i; "contiguous" = consecutive CU numbers, "interleaved" = every K-th."""
+    import numpy as np
+    from betaone_amd.engine import cu_partition_masks
+
+    for n_cu, K in ((256, 2), (256, 4), (256, 8), (304, 4), (256, 3)):
+        for layout in ("contiguous", "interleaved"):
+            ms = cu_partition_masks(n_cu, K, layout)
+            bits = [np.unpackbits(m.view(np.uint8), bitorder="little")[:n_cu].astype(bool) for m in ms]
+            assert len(ms) == K and all(m.dtype == np.uint32 and len(m) == (n_cu + 31) // 32 for m in ms)
+            assert all(int(b.sum()) == n_cu // K for b in bits)
+            assert int(np.sum(bits, axis=0).max()) == 1  # disjoint
+            first = np.nonzero(bits[1])[0][:2]
+            assert tuple(first) == ((n_cu // K, n_cu // K + 1) if layout == "contiguous" else (1, 1 + K))
+    import pytest
+    with pytest.raises(ValueError):
+        cu_partition_masks(4, 8)

@@ -112,7 +112,7 @@ LATE_GAME_FENS = [
 ]
 
 
-def _bench_like_run(net, G, sims, max_game_moves, preroll, steps, watch, record, cohorts=1):
+def _bench_like_run(net, G, sims, max_game_moves, preroll, steps, watch, record, cohorts=1, cu_masks=None):
     """bench.py's own step loop (bench.Driver: staggered pre-roll, finished games exported and their slots refilled on the side
     stream inside the run, n-iteration graphs, native RNG), with every 8th refilled game starting from a late-game position.
     record=True: the same run with the evaluate stage launched one iteration at a time and the seam of the `watch` slots read
@@ -122,7 +122,7 @@ def _bench_like_run(net, G, sims, max_game_moves, preroll, steps, watch, record,
 
     kw = dict(num_simulations=sims, mcts_batch_size=96, device="cuda:0", use_graph=True, rng_mode="native", policy_kind="probs",
               max_game_moves=max_game_moves)
-    ro = CohortRollout(net, G, cohorts=cohorts, **kw) if cohorts > 1 else Rollout(net, G, **kw)
+    ro = CohortRollout(net, G, cohorts=cohorts, cu_masks=cu_masks, **kw) if cohorts > 1 else Rollout(net, G, **kw)
     rec = SeamRecorder(ro, watch) if record else None
     fens = {}
 
@@ -251,8 +251,8 @@ def test_bench_steady_state_path_with_refills_and_late_game_positions_matches_or
     assert n_checked >= 8 and late, (n_checked, late)
 
 
-@pytest.mark.parametrize("cohorts", [2, 4])
-def test_cohorts_on_their_own_streams_finish_the_games_of_the_single_rollout(env, cohorts):
+@pytest.mark.parametrize("cohorts,cu_masks", [(2, None), (4, None), (4, "contiguous")])
+def test_cohorts_on_their_own_streams_finish_the_games_of_the_single_rollout(env, cohorts, cu_masks):
     """rollout.CohortRollout (bench.py --cohorts K): the 256 slots as K cohorts, each with its own engine, HIP stream and captured
     graphs, the plies software-pipelined (ply_end of one ply followed at once by ply_begin of the next, cohort after cohort).
     Games are independent (main.py:160-175), so the bench-like steady-state run -- refills on the side streams, late-game start
@@ -268,7 +268,8 @@ def test_cohorts_on_their_own_streams_finish_the_games_of_the_single_rollout(env
     torch.manual_seed(0)
     net = FusedPolicyValueNet(network.PolicyValueNet().to("cuda:0").eval(), conv="tower_split").to("cuda:0")
     one, fens1, _, _, _ = _bench_like_run(net, G, SIMS, LIMIT, PREROLL, STEPS, (), record=False)
-    many, fensk, _, slots, n_graphs = _bench_like_run(net, G, SIMS, LIMIT, PREROLL, STEPS + 1, (), record=False, cohorts=cohorts)
+    # cu_masks: every cohort's stream confined to its own quarter of the CUs (bo_stream_create_cu_mask) -- placement only, same games
+    many, fensk, _, slots, n_graphs = _bench_like_run(net, G, SIMS, LIMIT, PREROLL, STEPS + 1, (), record=False, cohorts=cohorts, cu_masks=cu_masks)
     assert n_graphs >= cohorts and set(slots.values()) == set(range(G))   # every cohort replayed graphs; finished games carry global slots
     # a game's id, seed and start position are handed out when a slot falls free: the ORDER in which slots are refilled differs
     # between the two schedules only among games that end in the same ply, so ids can be attached to different start positions

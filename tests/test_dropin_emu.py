@@ -467,6 +467,20 @@ def test_cohorts_of_games_play_exactly_the_games_one_rollout_plays(cohorts):
             assert torch.equal(s1, s2) and np.array_equal(p1, p2) and z1 == z2 and np.signbit(z1) == np.signbit(z2)
 
 
+def test_cohort_count_is_the_largest_share_of_config_cohorts_that_keeps_64_slots_per_cohort():
+    """dropin.self_play._cohorts: config.COHORTS is an upper limit, halved until it divides the slot count and leaves every cohort
+    COHORT_MIN_SLOTS (64) slots; one Rollout for the Python-RNG mode and for the fast search."""
+    saved = config.COHORTS
+    try:
+        config.COHORTS = 4
+        assert [self_play._cohorts(n, "native") for n in (256, 2048, 192, 128, 130, 64, 6)] == [4, 4, 2, 2, 2, 1, 1]
+        assert self_play._cohorts(256, "python") == 1
+        config.COHORTS = 1
+        assert self_play._cohorts(256, "native") == 1
+    finally:
+        config.COHORTS = saved
+
+
 def test_one_overlong_game_does_not_end_the_others():
     """config.ENGINE_MAX_PLIES smaller than the games: a slot whose position stack is full stops THAT game like the
     reference's move limit (self_play.py:186: records of the moves played are kept) and every other game -- running or

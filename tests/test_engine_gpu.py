@@ -685,3 +685,30 @@ def test_fused_heads_kernel_matches_torch(backend):
         assert rc == 0, lib.bo_last_error()
         torch.cuda.synchronize()
         assert (out.double() - ref).abs().max().item() < 2e-6 and (val.double() - value_ref).abs().max().item() < 5e-6, B
+
+
+def test_masked_stream_runs_kernels_and_refuses_an_empty_mask(backend):
+    """bo_stream_create_cu_mask / engine.MaskedStream: a HIP stream confined to a quarter of the compute units is an ordinary
+    stream for this library's launches and for torch (ExternalStream); an all-zero mask is refused instead of hanging every launch."""
+    import ctypes
+    import torch
+    from betaone_amd import engine as E
+
+    dev = torch.device("cuda:0")
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    masks = E.cu_partition_masks(n_cu, 4)
+    ms = E.MaskedStream(dev, masks[2])
+    ring = torch.zeros(1 + 2 * 8, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(ms.stream):
+        y = torch.arange(1 << 20, device=dev, dtype=torch.float32).mul_(2.0).sum()
+        for k in range(3):
+            assert ms.lib.bo_debug_stamp(ring.data_ptr(), 16 + k, 8, ctypes.c_void_p(ms.handle)) == 0
+    ms.stream.synchronize()
+    assert float(y) == float((1 << 20) * ((1 << 20) - 1))
+    r = ring.cpu().numpy()
+    assert r[0] == 3 and list(r[1:7:2]) == [16, 17, 18] and r[2] <= r[4] <= r[6]  # three stamps, in stream order, clock non-decreasing
+    ms.close()
+    zero = (ctypes.c_uint32 * len(masks[0]))()
+    h = ctypes.c_void_p()
+    assert ms.lib.bo_stream_create_cu_mask(0, zero, len(masks[0]), ctypes.byref(h)) != 0 and not h.value
