@@ -550,6 +550,8 @@ def main():
     dist = None
     if args.share_gpu:
         local = 0
+        if args.cu_masks is None and "BETAONE_COHORT_CU_MASK" not in os.environ:
+            args.cu_masks = "off"  # (ranks sharing one GPU would all confine their cohort k to the same CUs)
     if world > 1 or args.force_dist:
         import torch.distributed as dist
 
@@ -720,7 +722,7 @@ def main():
                        "parallelism": f"games sharded over {world} GPU(s) by id; record all-gather every {args.exchange_every} plies, pipelined" if world > 1
                                       else "1 GPU"},
             "plies_per_sec": round(plies / dt, 2), "nn_forwards_per_sec": round(fwd / dt / world, 2),
-            "unique_nn_evals_per_sec": round(fwd * G * (args.leaves if args.fast else 1) / dt, 1),
+            "unique_nn_evals_per_sec": round(fwd * (G // args.cohorts) * (args.leaves if args.fast else 1) / dt, 1),  # (a forward evaluates ONE cohort's boards)
             "games_finished_in_timed_region": int(fin_timed),
             "games_per_hour_measured": (round(fin_timed * 3600.0 / dt, 1) if fin_timed else None),
             "mean_plies_of_finished_games": (round(fin_plies_timed / fin_timed, 1) if fin_timed else None),

@@ -181,6 +181,7 @@ class Rollout:
         self._t_ret = None
         self._begun = None          # (n_legal, terminal, go) of searches already begun by the previous selfplay_turn
         self._turn_due = None       # go[G] of a ply whose searches ply_begin enqueued and ply_end has not turned yet
+        self._ply_event = None      # recorded behind everything ply_begin enqueued (ply_ready)
         self._begun_want = None
         self._active = np.zeros(G, dtype=bool)
         self._plies = np.zeros(G, dtype=np.int64)
@@ -523,16 +524,28 @@ class Rollout:
             while_searching()
         if self.ply_profile is not None: self._pp("while_searching")
         self._turn_due = go
+        self._mark_enqueued()
         return True
 
+    def _mark_enqueued(self) -> None:
+        if self.device.type == "cuda":
+            if self._ply_event is None:
+                self._ply_event = torch.cuda.Event()
+            self._ply_event.record(torch.cuda.current_stream(self.device))
+
+    def ply_ready(self) -> bool:
+        """A ply is due and the device has finished everything ply_begin enqueued for it (never blocks): ply_end will not wait."""
+        return self._turn_due is not None and (self._ply_event is None or self._ply_event.query())
+
     @_on_main
-    def ply_end(self) -> int:
+    def ply_end(self, block: bool = True) -> Optional[int]:
         """Second half of a ply: wait for the searches ply_begin enqueued (the ply's ONE host round trip), sample and play the
-        moves, begin the next searches on the device and enqueue their root evaluation.  Returns the number of moves played."""
+        moves, begin the next searches on the device and enqueue their root evaluation.  Returns the number of moves played.
+        block=False (CohortRollout's scheduler): if a search turns out to need one more evaluation than was enqueued, enqueue it
+        and return None instead of waiting for it -- the ply stays due, ply_ready() tells when to call again."""
         eng, G = self.eng, self.G
         stream = self._stream()
         go, self._turn_due = self._turn_due, None
-        self.n_sims += int(np.count_nonzero(go)) * self.S
         t0 = time.perf_counter()
         if self.ply_profile is not None: self._pp_t = t0
         move_number = self._start_full + (self._plies + self._start_black) // 2   # board.fullmove_number, self_play.py:104
@@ -546,6 +559,11 @@ class Rollout:
             if out is not None:
                 break
             self._eval_and_step()  # a search needed one more evaluation than expected
+            if not block:
+                self._turn_due = go
+                self._mark_enqueued()
+                return None
+        self.n_sims += int(np.count_nonzero(go)) * self.S
         self._check_watch()  # (the evaluate stage's fault word arrived with the result block)
         if self.ply_profile is not None: self._pp("turn")
         t0 = time.perf_counter()
@@ -730,7 +748,7 @@ class CohortRollout:
     engine code, same per-game RNG streams; only WHEN a game's kernels run differs.
 
     Slot s belongs to cohort s // (G / K).  The interface is Rollout's (start_games / play_ply / retire / swap_model / close,
-    games, n_sims, ...); play_ply returns the moves played by the plies it ENDED (0 on the first call, which only begins).
+    games, n_sims, ...); play_ply ends one cohort-ply per cohort with work (in the order the device finishes them) and returns the moves played.
     `drain()` ends the outstanding plies without beginning new ones."""
 
     def __init__(self, model, n_games: int, cohorts: int = 2, cu_masks: Optional[str] = None, **kw):
@@ -769,6 +787,8 @@ class CohortRollout:
         if K > 1 and self.device.type == "cuda":
             torch.cuda.synchronize(self.device)  # (buffers zeroed on the constructing stream are used on the cohorts' streams from here on)
         self.eng = _CohortEngines(self.parts)
+        self._turns = [0] * K  # cohort-plies ended per cohort
+        self._rr = 0
         p0 = self.parts[0]
         self.S, self.B, self.L, self.fast = p0.S, p0.B, p0.L, p0.fast
         self.expected_evals, self.rng_mode, self.max_game_moves = p0.expected_evals, p0.rng_mode, p0.max_game_moves
@@ -816,16 +836,54 @@ class CohortRollout:
 
         return (fin_cb if on_finished is not None else None), ((lambda s: refill(s + base)) if refill is not None else None)
 
+    # plies a cohort may be ahead of the least advanced one.  1 (default) = every call ends exactly one ply of every cohort with work;
+    # larger values let a fast cohort be turned twice in a call -- measured equal on the bench (3.21 / 3.22 ms per ply at 4 and 1,
+    # profiles/r04_cohort_cu_masks.md), so the simpler contract stays; BETAONE_COHORT_LEAD is the lab switch
+    MAX_LEAD = max(1, int(os.environ.get("BETAONE_COHORT_LEAD", "1")))
+
     def play_ply(self, on_finished=None, refill=None, while_searching=None) -> int:
+        """One cohort-ply per cohort with work, ended in the order in which the DEVICE finishes them: a cohort whose ply is done is
+        turned and begun again at once, whichever it is (in a fixed rotation the host sat waiting for cohort 0 while cohort 2 had
+        finished); a search that needs one more evaluation than was enqueued gets it without the host waiting for it (ply_end(block=
+        False)).  With MAX_LEAD > 1 a fast cohort may be turned twice in a call while a slow one is not turned at all.  The first
+        call begins every cohort's ply before it ends any."""
         moved = 0
+        cbs = [self._callbacks(k, on_finished, refill) for k in range(self.K)]
         for k, p in enumerate(self.parts):
-            if p._turn_due is not None:
-                moved += p.ply_end()
-            fin_cb, refill_cb = self._callbacks(k, on_finished, refill)
-            p.ply_begin(fin_cb, refill_cb)
+            if p._turn_due is None:
+                p.ply_begin(*cbs[k])
+        target = sum(1 for p in self.parts if p._turn_due is not None)
         if while_searching is not None:
             while_searching()
+        ended = 0
+        while ended < target:
+            due = [k for k, p in enumerate(self.parts) if p._turn_due is not None]
+            if not due:
+                break
+            floor = min(self._turns[k] for k in due)
+            k = self._pick_ready([k for k in due if self._turns[k] - floor < self.MAX_LEAD])
+            p = self.parts[k]
+            n = p.ply_end(block=False)
+            if n is None:  # (one more evaluation was enqueued for a straggling search: the cohort stays due)
+                continue
+            moved += n
+            ended += 1
+            self._turns[k] += 1
+            p.ply_begin(*cbs[k])
         return moved
+
+    def _pick_ready(self, cands) -> int:
+        """The first of `cands` (rotating start) whose enqueued work the device has finished; polls without blocking, then yields."""
+        spins = 0
+        while True:
+            for i in range(len(cands)):
+                k = cands[(self._rr + i) % len(cands)]
+                if self.parts[k].ply_ready():
+                    self._rr = (self._rr + i + 1) % max(1, len(cands))
+                    return k
+            spins += 1
+            if spins > 64:
+                time.sleep(0)  # (let the side threads -- record exchange, model watcher -- have the interpreter)
 
     def drain(self) -> int:
         """End every outstanding ply (no new searches are enqueued): the state then is what a sequence of whole plies leaves."""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """scripts/cohort_timeline.py -- LAB: where a cohort's iteration goes when K cohorts share the chip, by the device's own clock: a
 one-thread stamp kernel (bo_debug_stamp) sits in every cohort's captured graphs in front of the forward (1), behind it (2) and behind
-the tree step (3).  usage: cohort_timeline.py K [games] [steps]"""
+the tree step (3).  usage: cohort_timeline.py K [games] [steps] [preroll plies]"""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,7 +9,8 @@ import bench
 from betaone_amd import engine as E
 from betaone_amd.rollout import CohortRollout, Rollout
 
-K = int(sys.argv[1]); MASK = os.environ.get("BETAONE_COHORT_CU_MASK", "off"); G = int(sys.argv[2]) if len(sys.argv) > 2 else 256; steps = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+K = int(sys.argv[1]);  G = int(sys.argv[2]) if len(sys.argv) > 2 else 256; steps = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+PREROLL = int(sys.argv[4]) if len(sys.argv) > 4 else 100
 dev = torch.device("cuda:0")
 E.load_hip_library()
 _, net = bench.make_net("10x128", dev, "fp32", G // K)
@@ -17,7 +18,7 @@ Rollout.STAMP_RING = torch.zeros(1 + 2 * Rollout.STAMP_CAP, dtype=torch.int64, d
 kw = dict(num_simulations=800, mcts_batch_size=96, device=str(dev), use_graph=True, rng_mode="native", policy_kind="probs")
 ro = CohortRollout(net, G, cohorts=K, **kw) if K > 1 else Rollout(net, G, **kw)
 drv = bench.Driver(ro, 0, 1, None)
-drv.preroll(100, G)
+drv.preroll(PREROLL, G)
 for _ in range(5):
     drv.step()
 torch.cuda.synchronize()
@@ -34,7 +35,7 @@ n = int(min(ring[0], Rollout.STAMP_CAP))
 tags, ts = ring[1:1 + 2 * n:2].astype(np.int64), ring[2:2 + 2 * n:2].astype(np.float64)
 khz = ctypes.c_int32(0); E.load_hip_library().bo_device_wall_clock_khz(0, ctypes.byref(khz))
 ts = ts / (khz.value or 100000) * 1e3  # us
-print(f"K = {K} (cu masks {MASK}), {G} games, {steps} steps: {dt / steps * 1e3:.3f} ms per step, {n} stamps")
+print(f"K = {K} (cu masks {getattr(ro, "cu_masks", "-")}), preroll {PREROLL}, {G} games, {steps} steps: {dt / steps * 1e3:.3f} ms per step, {n} stamps")
 ids = sorted(set(int(t) // 16 for t in tags))
 fw, st, gap = [], [], []
 for cid in ids:
