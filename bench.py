@@ -244,8 +244,8 @@ def nn_roofline(net, batch, device, timed=None, wall_us=None):
     2 x MACs of the tower's direct 3x3 convolutions) / the kernel's average launch duration IN THE TIMED REGION, which the kernel notes
     itself (first workgroup's start, last workgroup's end, constant-rate device clock: `timed` = (durations us, intervals) from
     tower_timings) -- event pairs cannot sit between the nodes of the captured graphs the timed region replays; rocprofv3's per-kernel
-    average of the same command is the check (profiles/).  With cohorts two launches of half the boards overlap: `concurrency` = sum of
-    durations / time with at least one launch running, and `achieved_all_launches` prices what the chip's matrix pipes did in that time.
+    average of the same command is the check (profiles/).  With cohorts several launches of a share of the boards overlap: `concurrency` =
+    sum of durations / time with at least one launch running; `achieved` prices a launch against the chip's time per launch (see below).
     `back_to_back_us`: the same kernel alone on the chip, replayed as 20 consecutive graph nodes."""
     conv = getattr(net, "conv", None)
     if conv not in ("tower", "tower_wg", "tower_split"):
@@ -296,18 +296,28 @@ def nn_roofline(net, batch, device, timed=None, wall_us=None):
     else:
         peak, kernel = 157.3, ("bo_k_tower_wg" if conv == "tower_wg" else "bo_k_tower")  # fp32 MFMA dense: 256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz
         note = "fp32 v_mfma_f32_16x16x4_f32; one workgroup per board, activations LDS-resident for the whole tower"
-    ach = algorithmic / us / 1e6
+    # Cohorts launch this kernel for a share of the boards on a share of the CUs, several launches at a time: the time the CHIP spends per
+    # launch is (time with at least one launch running) / launches = average duration / concurrency, and `achieved` / `frac` price the
+    # algorithmic flops of a launch against THAT (with one launch at a time it is the launch's own duration).  `per_launch` keeps the
+    # single launch against the whole chip and against the CUs it can occupy (one workgroup per board: boards / CUs of the chip).
+    n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+    eff_us = us / conc if conc else us
+    ach, ach1 = algorithmic / eff_us / 1e6, algorithmic / us / 1e6
+    share = min(1.0, batch / float(n_cu))
     return {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": None, "traffic_source": TOWER_PMC_SOURCE.get(conv),
-            "basis": "algorithmic flops = 2 x MACs of the tower's direct 3x3 convolutions (2*9*64*C*(120 + (layers-1)*C) per board) x boards per launch",
+            "basis": "algorithmic flops = 2 x MACs of the tower's direct 3x3 convolutions (2*9*64*C*(120 + (layers-1)*C) per board) x boards per launch, "
+                     "/ the chip's time per launch = time with >= 1 launch of this kernel running / launches (= avg_launch_us / concurrency)",
             "alg_flops_per_launch": algorithmic, "executed_mfma_flops_per_launch": executed,
-            "pipe_utilisation": round(executed / us / 1e6 / peak, 4),
-            "executed_tflops": round(executed / us / 1e6, 1),
+            "pipe_utilisation": round(executed / eff_us / 1e6 / peak, 4),
+            "executed_tflops": round(executed / eff_us / 1e6, 1),
+            "chip_us_per_launch": round(eff_us, 1),
             "avg_launch_us": round(us, 1), "launches_timed": n_timed, "timing": how, "back_to_back_us": round(b2b, 1),
             "launch_us_p10_p50_p90": ([round(float(v), 1) for v in np.percentile(timed[0], [10, 50, 90])] if timed and timed[0] else None),
             "concurrency": (round(conc, 3) if conc else None),
             "share_of_wall_time": (round(_union(timed[1]) / wall_us, 4) if (conc and wall_us) else None),  # time with >= 1 tower launch running / the timed region
-            "achieved_all_launches": (round(ach * conc, 1) if conc else None), "frac_all_launches": (round(ach * conc / peak, 4) if conc else None),
+            "per_launch": {"achieved": round(ach1, 1), "frac_of_whole_chip": round(ach1 / peak, 4), "cu_share": round(share, 4),
+                           "frac_of_cu_share": round(ach1 / (peak * share), 4), "pipe_utilisation_of_cu_share": round(executed / us / 1e6 / (peak * share), 4)},
             "boards_per_launch": batch, "conv_layers": n_conv, "note": note}
 
 
@@ -649,7 +659,7 @@ def main():
         mine = tot.tolist()
     sims, plies, fwd, fin_timed, fin_plies_timed, fin_all, fin_plies_all = [float(x) for x in mine]
     step_ms = np.diff(np.array([t0] + step_end)) * 1e3  # host-side period of each step on this rank (a step returns when its moves are played)
-    ro.eng.check_status()
+    arena_full = ro.eng.check_status()  # (raises on a fault; fast mode: slots whose arena was full at some expansion -- those searches ran narrower)
     ro.check_net()
     if getattr(ro, "ply_profile", None):  # BO_PLY_PROFILE=1: host seconds per phase of the native ply path over the whole run
         import collections
@@ -723,6 +733,7 @@ def main():
                                       else "1 GPU"},
             "plies_per_sec": round(plies / dt, 2), "nn_forwards_per_sec": round(fwd / dt / world, 2),
             "unique_nn_evals_per_sec": round(fwd * (G // args.cohorts) * (args.leaves if args.fast else 1) / dt, 1),  # (a forward evaluates ONE cohort's boards)
+            "arena_full_slots": (int(arena_full) if args.fast else None),
             "games_finished_in_timed_region": int(fin_timed),
             "games_per_hour_measured": (round(fin_timed * 3600.0 / dt, 1) if fin_timed else None),
             "mean_plies_of_finished_games": (round(fin_plies_timed / fin_timed, 1) if fin_timed else None),

@@ -1839,6 +1839,36 @@ extern "C" int bo_nn_heads(const void *p_dev, const void *v_dev, const float *wp
 #endif
 }
 
+// fp16 head planes and fp16 Linear weights, any number of rows: policy FC + softmax in one kernel, the whole value head in another
+extern "C" int bo_nn_heads_f16(const void *p_dev, const void *v_dev, const void *wp_f16_dev, const float *bp_dev, const void *w1_f16_dev,
+                               const float *b1_dev, const float *w2_dev, const float *b2_dev, float *policy_out_dev, float *value_out_dev,
+                               float *scratch_dev, int batch, int flags, void *stream) {
+#if defined(BO_WAVE_EMU)
+    (void)p_dev; (void)v_dev; (void)wp_f16_dev; (void)bp_dev; (void)w1_f16_dev; (void)b1_dev; (void)w2_dev; (void)b2_dev; (void)policy_out_dev;
+    (void)value_out_dev; (void)scratch_dev; (void)batch; (void)flags; (void)stream;
+    return fail(BO_E_CONFIG, "bo_nn_heads_f16 is a gfx950-only kernel");
+#else
+    if (!p_dev || !v_dev || !wp_f16_dev || !bp_dev || !w1_f16_dev || !b1_dev || !w2_dev || !b2_dev || !policy_out_dev || !value_out_dev)
+        return fail(BO_E_ARG, "null argument");
+    if (batch < 1 || batch > (1 << 22)) return fail(BO_E_ARG, "bo_nn_heads_f16: 1 <= batch <= 4194304");
+    bo_heads_h_args a;
+    a.p = (const _Float16 *)p_dev; a.v = (const _Float16 *)v_dev; a.wp = (const _Float16 *)wp_f16_dev; a.w1 = (const _Float16 *)w1_f16_dev;
+    a.bp = bp_dev; a.b1 = b1_dev; a.w2 = w2_dev; a.b2 = b2_dev; a.policy_out = policy_out_dev; a.value_out = value_out_dev;
+    a.B = batch; a.softmax = flags & 1; a.stats = scratch_dev;
+    if (a.softmax && !scratch_dev) return fail(BO_E_ARG, "bo_nn_heads_f16: the softmax needs scratch_dev (20 * batch floats)");
+    const dim3 pgrid((unsigned)((batch + 255) / 256), BO_HEADS_PS);
+    if (a.softmax) {
+        hipLaunchKernelGGL(bo_k_heads_policy_h<0>, pgrid, dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(bo_k_heads_policy_h<1>, pgrid, dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL(bo_k_heads_policy_h<2>, pgrid, dim3(256), 0, (hipStream_t)stream, a);
+    }
+    hipLaunchKernelGGL(bo_k_heads_value_h, dim3((unsigned)((batch + 63) / 64)), dim3(256), 0, (hipStream_t)stream, a);
+    RT((int)hipGetLastError());
+    return BO_OK;
+#endif
+}
+
 extern "C" int bo_nn_value_tail(const float *h_dev, const float *w_dev, const float *bias_dev, float *out_dev, int batch, int hidden, void *stream) {
 #if defined(BO_WAVE_EMU)
     (void)h_dev; (void)w_dev; (void)bias_dev; (void)out_dev; (void)batch; (void)hidden; (void)stream;

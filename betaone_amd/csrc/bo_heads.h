@@ -218,4 +218,256 @@ bo_k_heads_rows(bo_heads_args a) {
         }
     }
 }
+
+// ---- fp16 head planes, any number of rows (fast mode: 4 096 .. 131 072 rows per evaluation) -------------------------------------------
+// Behind the fp16 tower (bo_tower_h.h) the head planes are fp16 and so are the Linear weights the reference's autocast evaluation
+// multiplies with (network.py:186-197 under torch.autocast; softmax of mcts.py:287 in float32).  As library calls that is a GEMM that
+// writes fp16 logits, a widening copy, a softmax that reads and writes the float32 rows again (9.8 GB of traffic at 131 072 rows),
+// the value GEMM, a clamp, a small GEMM and a tanh.  Here the probabilities are written ONCE and nothing is read back -- a logits tile
+// costs 16 MFMAs to recompute, a round trip through memory costs more:
+//   bo_k_heads_policy_h<0>  workgroup = 256 boards (64 per wave, their B fragments resident in registers) x one of 10 ranges of the 146
+//                           output tiles [32 outputs x 32 boards], v_mfma_f32_32x32x16_f16: running (max, sum of exp) per board over
+//                           the range -> stats[range][board].  The 32 weight rows of a tile are fetched once per workgroup with
+//                           coalesced loads into a double-buffered LDS tile; the four waves take their A fragments from there.
+//   bo_k_heads_policy_h<1>  same decomposition: a board's ten partial (max, sum) pairs are merged, every tile is computed again and
+//                           exp(x - max) / sum is stored.  Transposed product (M = outputs, N = boards): a lane's accumulator group is
+//                           four consecutive outputs of one board, 16-byte stores.   <2>: the logits, no statistics.
+//   bo_k_heads_value_h      64 boards per workgroup: value_fc1 over the whole K = 2048 (activation chunks staged through LDS, the wave's
+//                           64 weight rows streamed from L2), bias, ReLU, value_fc2 and tanh in the epilogue -- no partial sums in memory.
+// Both decompose over (board blocks x output ranges), so 4 096 rows already give 160 workgroups.
+// K is taken in the order (kg, step, i) -> k = KSPAN * kg + 8 * step + i for both operands (any permutation of K is a valid product):
+// a lane's fragments of consecutive steps are then consecutive 16-byte pieces of ONE row.
+typedef _Float16 bo_hh8 __attribute__((ext_vector_type(8)));
+
+#ifndef BO_HEADS_NT_STORES
+#define BO_HEADS_NT_STORES 1                              // probabilities are written once and read by a later kernel: stream them past L2
+#endif
+#define BO_HEADS_PS 10                                    // output ranges per board block
+#define BO_HEADS_PT 15                                    // tiles per range (the last range: 11)
+#define BO_HEADS_WPITCH (BO_HEADS_KP + 8)                 // halves per LDS weight row: + 16 bytes (conflict-free 16-byte fragment reads)
+
+struct bo_heads_h_args {
+    const _Float16 *p, *v;        // [B,128], [B,2048]
+    const _Float16 *wp, *w1;      // policy_fc.weight [4672,128], value_fc1.weight [256,2048], fp16
+    const float *bp, *b1, *w2, *b2;  // float32: policy_fc.bias, value_fc1.bias, value_fc2.weight [256], value_fc2.bias
+    float *policy_out, *value_out;   // [B,4672] probabilities (softmax != 0) or logits; [B]
+    float *stats;                    // [BO_HEADS_PS][B][2]: (max, sum of exp(x - max)) of a board over one output range
+    int B, softmax;
+};
+
+template <int PASS>
+__global__ void __launch_bounds__(256)
+bo_k_heads_policy_h(bo_heads_h_args a) {
+    __shared__ __attribute__((aligned(16))) _Float16 wt[2][32 * BO_HEADS_WPITCH];
+    __shared__ float2 merged[PASS == 1 ? 256 : 1];  // (max, 1 / sum) of the workgroup's boards
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kg = lane >> 5, n = lane & 31;
+    const int B = a.B, r0 = 256 * (int)blockIdx.x + 64 * wave, rg = (int)blockIdx.y;
+    constexpr int NT = BO_HEADS_NA / 32, KS = BO_HEADS_KP / 16;  // 146 output tiles, 8 K-steps
+    const int t0 = BO_HEADS_PT * rg, t1 = t0 + BO_HEADS_PT < NT ? t0 + BO_HEADS_PT : NT;
+    int row[2];
+    bo_hh8 fb[2][KS];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        row[h] = r0 + 32 * h + n < B ? r0 + 32 * h + n : B - 1;  // (rows past the end: loads clamped, stores skipped)
+        const bo_hh8 *prow = reinterpret_cast<const bo_hh8 *>(a.p + (size_t)row[h] * BO_HEADS_KP + 64 * kg);
+#pragma unroll
+        for (int s = 0; s < KS; s++) fb[h][s] = prow[s];
+    }
+    // staging: a tile's 32 weight rows x 256 bytes = 512 16-byte pieces, two per thread (16 threads per row: coalesced)
+    const int srow = tid >> 3, sc = 2 * (tid & 7);
+    const bo_hh8 *wsrc = reinterpret_cast<const bo_hh8 *>(a.wp + (size_t)srow * BO_HEADS_KP) + sc;
+    constexpr size_t TSTRIDE = (size_t)32 * BO_HEADS_KP / 8;  // bo_hh8 units per tile of 32 weight rows
+    bo_hh8 g0 = wsrc[t0 * TSTRIDE], g1 = wsrc[t0 * TSTRIDE + 1];
+    *reinterpret_cast<bo_hh8 *>(&wt[0][srow * BO_HEADS_WPITCH + 8 * sc]) = g0;
+    *reinterpret_cast<bo_hh8 *>(&wt[0][srow * BO_HEADS_WPITCH + 8 * sc + 8]) = g1;
+    const bo_f32x4 *bias4 = reinterpret_cast<const bo_f32x4 *>(a.bp);
+    const float ninf = -__builtin_inff();
+    float m[2] = {ninf, ninf}, ssum[2] = {0.0f, 0.0f};
+    if (PASS == 1) {  // merge the board's partial statistics (every range's workgroup does this for its own use)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            float pm[BO_HEADS_PS], ps[BO_HEADS_PS];
+#pragma unroll
+            for (int q = 0; q < BO_HEADS_PS; q++) {
+                const float2 st = *reinterpret_cast<const float2 *>(a.stats + 2 * ((size_t)q * B + row[h]));
+                pm[q] = st.x; ps[q] = st.y;
+            }
+            float mm = pm[0];
+#pragma unroll
+            for (int q = 1; q < BO_HEADS_PS; q++) mm = fmaxf(mm, pm[q]);
+            float tot = 0.0f;
+#pragma unroll
+            for (int q = 0; q < BO_HEADS_PS; q++) tot += ps[q] * __expf(pm[q] - mm);
+            if (kg == 0) merged[64 * wave + 32 * h + n] = float2{mm, 1.0f / tot};
+        }
+    }
+    // The write passes multiply the other way round (M = boards, N = outputs): accumulator r of a lane is output 32t + (lane & 31) of board
+    // 32h + (r & 3) + 8 (r >> 2) + 4 kg, so that one store instruction writes 128 consecutive bytes of two boards' rows -- whole lines
+    // (with M = outputs a lane's four stores of a tile fill one line 32 bytes at a time: 2.9 TB/s at 131 072 rows, profiles/r04_heads_f16.md).
+    float bm[2][16], binv[2][16];
+    if (PASS == 1) {
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float2 st = merged[64 * wave + 32 * h + (r & 3) + 8 * (r >> 2) + 4 * kg];
+                bm[h][r] = st.x; binv[h][r] = st.y;
+            }
+    }
+    const bool full = r0 + 64 <= B;
+    float *obase = a.policy_out + (size_t)(r0 + 4 * kg) * BO_HEADS_NA + n;
+    for (int t = t0; t < t1; t++) {
+        const int cur = (t - t0) & 1;
+        if (t + 1 < t1) { g0 = wsrc[(t + 1) * TSTRIDE]; g1 = wsrc[(t + 1) * TSTRIDE + 1]; }
+        __syncthreads();  // tile t is in wt[cur]; every wave is done with wt[cur ^ 1] (tile t - 1)
+        bo_hh8 fa[KS];
+#pragma unroll
+        for (int s = 0; s < KS; s++) fa[s] = *reinterpret_cast<const bo_hh8 *>(&wt[cur][n * BO_HEADS_WPITCH + 64 * kg + 8 * s]);
+        bo_f32x16 acc[2];
+        if (PASS == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const bo_f32x4 bq = bias4[(32 * t + 8 * q + 4 * kg) >> 2];
+#pragma unroll
+                for (int e = 0; e < 4; e++) { acc[0][4 * q + e] = bq[e]; acc[1][4 * q + e] = bq[e]; }
+            }
+#pragma unroll
+            for (int s = 0; s < KS; s++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) acc[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s], fb[h][s], acc[h], 0, 0, 0);
+        } else {
+            const float bn = a.bp[32 * t + n];
+#pragma unroll
+            for (int r = 0; r < 16; r++) { acc[0][r] = bn; acc[1][r] = bn; }
+#pragma unroll
+            for (int s = 0; s < KS; s++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) acc[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[h][s], fa[s], acc[h], 0, 0, 0);
+        }
+        if (t + 1 < t1) {
+            *reinterpret_cast<bo_hh8 *>(&wt[cur ^ 1][srow * BO_HEADS_WPITCH + 8 * sc]) = g0;
+            *reinterpret_cast<bo_hh8 *>(&wt[cur ^ 1][srow * BO_HEADS_WPITCH + 8 * sc + 8]) = g1;
+        }
+        if (PASS == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                float tm = acc[h][0];
+#pragma unroll
+                for (int r = 1; r < 16; r++) tm = fmaxf(tm, acc[h][r]);
+                const float mn = fmaxf(m[h], tm);
+                float add = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; r++) add += __expf(acc[h][r] - mn);
+                ssum[h] = ssum[h] * __expf(m[h] - mn) + add;
+                m[h] = mn;
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int brow = 32 * h + (r & 3) + 8 * (r >> 2);  // (+ 4 kg: in obase)
+                    const float o = PASS == 1 ? __expf(acc[h][r] - bm[h][r]) * binv[h][r] : acc[h][r];
+                    if (full || r0 + 4 * kg + brow < B) {
+                        float *dst = obase + (size_t)brow * BO_HEADS_NA + 32 * t;
+                        if (BO_HEADS_NT_STORES) __builtin_nontemporal_store(o, dst);
+                        else *dst = o;
+                    }
+                }
+        }
+    }
+    if (PASS == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {  // the board's other sixteen outputs of every tile sit in lane ^ 32
+            const float m2 = __shfl_xor(m[h], 32, 64), s2 = __shfl_xor(ssum[h], 32, 64);
+            const float mm = fmaxf(m[h], m2);
+            const float tot = ssum[h] * __expf(m[h] - mm) + s2 * __expf(m2 - mm);
+            if (kg == 0 && r0 + 32 * h + n < B) *reinterpret_cast<float2 *>(a.stats + 2 * ((size_t)rg * B + row[h])) = float2{mm, tot};
+        }
+    }
+}
+
+#define BO_HEADS_VKC 256                       // halves of K per LDS chunk
+#define BO_HEADS_VPITCH (BO_HEADS_VKC + 8)     // + 16 bytes: conflict-free 16-byte fragment reads
+
+__global__ void __launch_bounds__(256)
+bo_k_heads_value_h(bo_heads_h_args a) {
+    __shared__ __attribute__((aligned(16))) _Float16 tileV[64 * BO_HEADS_VPITCH];
+    __shared__ float red[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kg = lane >> 5, n = lane & 31;
+    const int B = a.B, r0 = 64 * (int)blockIdx.x;
+    constexpr int NC = BO_HEADS_KV / BO_HEADS_VKC, KS = BO_HEADS_VKC / 16;  // 8 chunks of 16 K-steps
+    // staging: 64 rows x 512 bytes per chunk = 2048 16-byte pieces, 8 per thread (32 threads per row: coalesced)
+    bo_hh8 g[8];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int idx = tid + 256 * q, rr = idx >> 5, c8 = idx & 31;
+            const int row = r0 + rr < B ? r0 + rr : B - 1;
+            g[q] = *reinterpret_cast<const bo_hh8 *>(a.v + (size_t)row * BO_HEADS_KV + BO_HEADS_VKC * c + 8 * c8);
+        }
+    };
+    bo_f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[mt][t][r] = 0.0f;
+    // this wave: hidden units 64 * wave + 32 * mt + (lane & 31); a lane's 16 steps of a chunk are 256 consecutive bytes of its row
+    const bo_hh8 *wrow[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) wrow[mt] = reinterpret_cast<const bo_hh8 *>(a.w1 + (size_t)(64 * wave + 32 * mt + n) * BO_HEADS_KV + 128 * kg);
+    fetch(0);
+    for (int c = 0; c < NC; c++) {
+        __syncthreads();  // (the previous chunk's fragment reads are done)
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int idx = tid + 256 * q, rr = idx >> 5, c8 = idx & 31;
+            *reinterpret_cast<bo_hh8 *>(&tileV[rr * BO_HEADS_VPITCH + 8 * c8]) = g[q];
+        }
+        __syncthreads();
+        if (c + 1 < NC) fetch(c + 1);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            bo_hh8 fa[2][8];
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int s = 0; s < 8; s++) fa[mt][s] = wrow[mt][(BO_HEADS_VKC * c) / 8 + 8 * half + s];
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                bo_hh8 fv[2];
+#pragma unroll
+                for (int t = 0; t < 2; t++) fv[t] = *reinterpret_cast<const bo_hh8 *>(&tileV[(32 * t + n) * BO_HEADS_VPITCH + 128 * kg + 8 * (8 * half + s)]);
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int t = 0; t < 2; t++) acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][s], fv[t], acc[mt][t], 0, 0, 0);
+            }
+        }
+    }
+    // value = tanh(value_fc2(relu(value_fc1 + b1)) + b2): this lane holds hidden 64*wave + 32*mt + 8*q + 4*kg + e of boards 32*t + n
+    float part[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int h0 = 64 * wave + 32 * mt + 8 * q + 4 * kg;
+            const bo_f32x4 b4 = *reinterpret_cast<const bo_f32x4 *>(a.b1 + h0), w4 = *reinterpret_cast<const bo_f32x4 *>(a.w2 + h0);
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const float h = acc[mt][t][4 * q + e] + b4[e];
+                    part[t] += (h > 0.0f ? h : 0.0f) * w4[e];
+                }
+        }
+#pragma unroll
+    for (int t = 0; t < 2; t++) part[t] += __shfl_xor(part[t], 32, 64);
+    if (kg == 0) { red[wave][n] = part[0]; red[wave][32 + n] = part[1]; }
+    __syncthreads();
+    if (tid < 64 && r0 + tid < B) a.value_out[r0 + tid] = tanhf(((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) + a.b2[0]);
+}
 #endif

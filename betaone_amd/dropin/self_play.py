@@ -130,9 +130,13 @@ def _settle_status(ro: Rollout, results, finished, next_game):
     abort of self_play.py:167 (-> None); a slot whose position stack is full (config.ENGINE_MAX_PLIES smaller than
     MAX_GAME_MOVES) is the move-limit stop of self_play.py:186 (records kept).  Anything else is an engine fault."""
     st = ro.eng.status_bits()
+    soft = E.ST_NODE_OVERFLOW if ro.fast else 0
     for g in np.nonzero(st)[0]:
         g, bits = int(g), int(st[g])
         if ro.games[g] is None:
+            continue
+        bits &= ~soft  # (fast mode: a full arena narrows that search, it does not end the game)
+        if not bits:
             continue
         if bits & ~(E.ST_PLY_OVERFLOW | E.ST_ILLEGAL_ACTION):
             raise E.EngineError(f"game {ro.games[g].game_id} (slot {g}): {ro.eng.describe_status(bits)}")

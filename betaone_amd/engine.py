@@ -27,6 +27,9 @@ POLICY_NONE, POLICY_LOGITS, POLICY_PROBS = 0, 1, 2
 STATUS_BITS = {1: "node overflow", 2: "depth overflow", 4: "NaN PUCT score", 8: "ply overflow",
                16: "illegal action", 32: "leaf cache overflow", 64: "tracker overflow"}
 ST_PLY_OVERFLOW, ST_ILLEGAL_ACTION = 8, 16   # per-GAME conditions (the reference aborts that game only); the rest are engine faults
+ST_NODE_OVERFLOW = 1  # reference mode: a fault (the node arrays are sized for the search).  Fast mode: the game's arena was full at an
+#                       expansion or a re-root -- the leaf stayed unexpanded (its value was still backed up) / the subtree that did not
+#                       fit was dropped; the search is valid, only narrower.  Sticky per slot until the slot is reset.
 
 
 LAZY_BEGIN = "lazy-begin"  # selfplay_turn(lazy_begin=True): the begun searches' root info comes from selfplay_begun()
@@ -119,6 +122,7 @@ _SYMBOLS = {
     "bo_nn_se_residual_small": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p]),
     "bo_nn_heads": (C.c_int, [C.c_void_p] * 11 + [C.c_int, C.c_int, C.c_void_p]),
+    "bo_nn_heads_f16": (C.c_int, [C.c_void_p] * 11 + [C.c_int, C.c_int, C.c_void_p]),
     "bo_nn_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p]),
     "bo_nn_conv3x3_small": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -511,12 +515,19 @@ class Engine:
     def describe_status(bits: int) -> str:
         return ", ".join(v for b, v in STATUS_BITS.items() if bits & b)
 
-    def check_status(self):
+    def soft_status_bits(self) -> int:
+        """Status bits that are conditions of ONE search rather than faults of the engine (fast mode: a full arena)."""
+        return ST_NODE_OVERFLOW if self.fast else 0
+
+    def check_status(self) -> int:
+        """Raises on an engine fault in any slot; returns the number of slots that carry only soft conditions (fast mode: slots
+        whose arena was full at some point -- see ST_NODE_OVERFLOW)."""
         st = self.status_bits()
-        bad = np.nonzero(st)[0]
+        bad = np.nonzero(st & ~self.soft_status_bits())[0]
         if len(bad):
             g = int(bad[0])
             raise EngineError(f"game slot {g}: {self.describe_status(int(st[g]))}")
+        return int(np.count_nonzero(st))
 
     def profile(self, enable: int = -1, read: bool = True, stream: int = 0):
         out = np.zeros((self.G, PROF_SLOTS), dtype=np.uint64) if read else None

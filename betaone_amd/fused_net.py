@@ -32,6 +32,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -597,6 +598,19 @@ class FusedPolicyValueNet(nn.Module):
             raise E.EngineError(self.lib.bo_last_error().decode())
         return out, value
 
+    def _heads_f16(self, p, v, probs):
+        B, dev = p.shape[0], p.device
+        out = torch.empty((B, 4672), dtype=torch.float32, device=dev)
+        value = torch.empty((B, 1), dtype=torch.float32, device=dev)
+        scr = torch.empty(20 * B, dtype=torch.float32, device=dev)  # (max, sum of exp) per board and output range (per call: see _heads)
+        rc = self.lib.bo_nn_heads_f16(p.data_ptr(), v.data_ptr(), self.policy_fc_h.weight.data_ptr(), self.policy_fc.bias.data_ptr(),
+                                      self.value_fc1_h.weight.data_ptr(), self.value_fc1.bias.data_ptr(), self.value_fc2.weight.data_ptr(),
+                                      self.value_fc2.bias.data_ptr(), out.data_ptr(), value.data_ptr(), scr.data_ptr(), B, 1 if probs else 0,
+                                      torch.cuda.current_stream(dev).cuda_stream)
+        if rc:
+            raise E.EngineError(self.lib.bo_last_error().decode())
+        return out, value
+
     def _value_tail(self, h):
         out = torch.empty((h.shape[0], 1), dtype=torch.float32, device=h.device)
         rc = self.lib.bo_nn_value_tail(h.data_ptr(), self.value_fc2.weight.data_ptr(), self.value_fc2.bias.data_ptr(), out.data_ptr(), h.shape[0],
@@ -659,11 +673,15 @@ class FusedPolicyValueNet(nn.Module):
     def forward(self, x, probs: bool = False):
         if self.conv == "tower_f16":
             p, v = self._tower_f16_forward(x)
-            if self.fused_heads and p.shape[1] == 128 and v.shape[1] == 2048 and p.shape[0] <= 1024:
-                # fp16 head planes widened on load; float32 head weights, accumulation, softmax and value (closer to the float32 net
-                # than the half-precision GEMMs this replaces).  Up to 1024 boards (configs[4]: 512): the head kernels multiply on
-                # the fp32 matrix pipe, beyond that the library's fp16 GEMM wins (fast mode at 4096+ rows: measured 5-8 % per step).
-                return self._heads(p, v, probs)
+            if self.fused_heads and p.shape[1] == 128 and v.shape[1] == 2048:
+                # Up to 1024 boards (configs[4]: 512): fp16 head planes widened on load; float32 head weights, accumulation, softmax and
+                # value on the fp32 matrix pipe (closer to the float32 net than the half-precision GEMMs; tile-parallel, so a few
+                # hundred rows still fill the chip).  Beyond (fast mode: 4 096 .. 131 072 rows): fp16 weights on the fp16 pipe, the
+                # policy FC and its softmax fused per 32-board wave, the value head in one kernel (bo_heads.h) -- no library launch.
+                if p.shape[0] <= 1024:
+                    return self._heads(p, v, probs)
+                if os.environ.get("BETAONE_HEADS_F16", "1") != "0":  # (0: the library path below, for A/B runs)
+                    return self._heads_f16(p, v, probs)
             logits = self.policy_fc_h(p)
             return (torch.softmax(logits.float(), dim=1) if probs else logits), torch.tanh(self.value_fc2_h(F.relu(self.value_fc1_h(v))))
         if self.conv in ("tower_wg", "tower_split"):  # tower + head convolutions in one kernel, then the heads

@@ -732,9 +732,8 @@ class _CohortEngines:
     def describe_status(bits: int) -> str:
         return E.Engine.describe_status(bits)
 
-    def check_status(self):
-        for p in self._parts:
-            p.eng.check_status()
+    def check_status(self) -> int:
+        return sum(p.eng.check_status() for p in self._parts)
 
 
 class CohortRollout:

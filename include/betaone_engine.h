@@ -299,6 +299,16 @@ int bo_nn_se_residual_small(const float *x_dev, const float *bias_dev, const flo
 int bo_nn_heads(const void *p_dev, const void *v_dev, const float *wp_dev, const float *bp_dev, const float *w1_dev,
                 const float *b1_dev, const float *w2_dev, const float *b2_dev, float *policy_out_dev, float *value_out_dev,
                 float *scratch_dev, int batch, int flags, void *stream);
+/* (ABI 4) The same behind the fp16 tower at any number of rows (fast mode: 4 096 .. 131 072 rows per evaluation; network.py:186-197 under
+ * torch.autocast, softmax of mcts.py:287 in float32): p [batch,128], v [batch,2048], policy_fc weight [4672,128] and value_fc1 weight
+ * [256,2048] float16 row-major; biases, value_fc2 weight [256] + bias float32; products on the fp16 matrix pipe with float32
+ * accumulation, logits never rounded to float16.  The probabilities are written once: a first launch leaves every board's (max, sum of
+ * exp) per output range in scratch_dev (20 * batch floats, no initial contents needed; may be NULL without softmax), a second
+ * computes every logits tile again and stores exp(x - max) / sum; a third launch is the whole value head.  flags bit 0 = softmax.
+ * 1 <= batch <= 4194304. */
+int bo_nn_heads_f16(const void *p_dev, const void *v_dev, const void *wp_f16_dev, const float *bp_dev, const void *w1_f16_dev,
+                    const float *b1_dev, const float *w2_dev, const float *b2_dev, float *policy_out_dev, float *value_out_dev,
+                    float *scratch_dev, int batch, int flags, void *stream);
 int bo_nn_conv3x3(const float *x_dev, const float *wpacked_dev, const float *bias_dev, const float *residual_dev,
                   float *y_dev, int batch, int c_in, int c_out, int mode, void *stream);
 

@@ -687,6 +687,59 @@ def test_fused_heads_kernel_matches_torch(backend):
         assert (out.double() - ref).abs().max().item() < 2e-6 and (val.double() - value_ref).abs().max().item() < 5e-6, B
 
 
+def test_f16_heads_at_any_row_count_match_torch(backend):
+    """csrc/bo_heads.h, bo_nn_heads_f16 (fast mode's evaluate stage above 1024 rows: fp16 head planes and fp16 Linear weights on the
+    fp16 matrix pipe, policy FC + softmax fused per 32-board wave, the value head in one kernel): against torch's float64 result from
+    the same fp16 operands, for row counts that are not multiples of its 32- and 64-board tiles, and at fast mode's full 131 072 rows
+    through size-independent properties (rows sum to 1, a strided sample of rows against float64)."""
+    import torch
+    from betaone_amd import engine as E
+
+    lib = E.load_hip_library()
+    g = torch.Generator().manual_seed(7)
+    wp = (torch.randn((4672, 128), generator=g) / 11.0).cuda().half(); bp = torch.randn(4672, generator=g).cuda()
+    w1 = (torch.randn((256, 2048), generator=g) / 45.0).cuda().half(); b1 = torch.randn(256, generator=g).cuda()
+    w2 = (torch.randn((1, 256), generator=g) / 16.0).cuda(); b2 = torch.randn(1, generator=g).cuda()
+
+    def run(p, v, softmax):
+        B = p.shape[0]
+        out = torch.full((B, 4672), float("nan"), device="cuda"); val = torch.full((B, 1), float("nan"), device="cuda")
+        scr = torch.full((20 * B,), float("nan"), device="cuda")
+        rc = lib.bo_nn_heads_f16(p.data_ptr(), v.data_ptr(), wp.data_ptr(), bp.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                                 b2.data_ptr(), out.data_ptr(), val.data_ptr(), scr.data_ptr(), B, softmax, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.bo_last_error()
+        torch.cuda.synchronize()
+        return out, val
+
+    def reference(p, v, softmax):
+        logits = p.double() @ wp.double().t() + bp.double()
+        value = torch.tanh(torch.relu(v.double() @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double())
+        return (torch.softmax(logits, dim=1) if softmax else logits), value
+
+    for B in (1, 31, 33, 64, 65, 1100, 4096):
+        p = (torch.rand((B, 128), generator=g) * 2.0).cuda().half(); v = torch.rand((B, 2048), generator=g).cuda().half()
+        if B > 1:
+            p[B // 2] *= 6.0  # one row with a sharp maximum (logits tens apart: the running maximum must rescale the sum)
+        for softmax in (0, 1):
+            out, val = run(p, v, softmax)
+            ref, value_ref = reference(p, v, softmax)
+            assert (out.double() - ref).abs().max().item() < (2e-6 if softmax else 3e-5), (B, softmax)
+            assert (val.double() - value_ref).abs().max().item() < 5e-6, (B, softmax)
+            if softmax:
+                assert (out.sum(dim=1) - 1.0).abs().max().item() < 2e-5
+    B = 131072
+    p = (torch.rand((B, 128), generator=g) * 2.0).cuda().half(); v = torch.rand((B, 2048), generator=g).cuda().half()
+    out, val = run(p, v, 1)
+    assert bool(torch.isfinite(out).all()) and (out.sum(dim=1) - 1.0).abs().max().item() < 2e-5 and bool((out >= 0).all())
+    pick = torch.arange(0, B, 997, device="cuda")
+    ref, value_ref = reference(p[pick], v[pick], 1)
+    assert (out[pick].double() - ref).abs().max().item() < 2e-6 and (val[pick].double() - value_ref).abs().max().item() < 5e-6
+    assert lib.bo_nn_heads_f16(p.data_ptr(), v.data_ptr(), wp.data_ptr(), bp.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                               b2.data_ptr(), out.data_ptr(), val.data_ptr(), out.data_ptr(), 0, 1, torch.cuda.current_stream().cuda_stream) != 0  # batch 0
+    assert lib.bo_nn_heads_f16(p.data_ptr(), v.data_ptr(), wp.data_ptr(), bp.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                               b2.data_ptr(), out.data_ptr(), val.data_ptr(), None, 64, 1, torch.cuda.current_stream().cuda_stream) != 0   # softmax without scratch
+
+
 def test_masked_stream_runs_kernels_and_refuses_an_empty_mask(backend):
     """bo_stream_create_cu_mask / engine.MaskedStream: a HIP stream confined to a quarter of the compute units is an ordinary
     stream for this library's launches and for torch (ExternalStream); an all-zero mask is refused instead of hanging every launch."""

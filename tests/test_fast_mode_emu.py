@@ -84,6 +84,26 @@ def drive_search(backend, eng, G, L, eval_fn, noise, bufs=None):
     return steps, (nn_in, pol, val)
 
 
+def test_a_full_arena_narrows_the_search_and_is_not_a_fault():
+    """Fast mode, an arena far too small for the search (bo_fastw.h: a leaf whose run does not fit stays unexpanded, its value is still
+    backed up): the search finishes all its simulations, pi is a distribution over legal moves, the slot carries the soft
+    'node overflow' bit -- check_status counts it and does not raise (a 16-ply run of 32 768 games hits this in a handful of slots)."""
+    sims, L = 150, 8
+    kw = dict(num_simulations=sims, dirichlet_alpha=0.0, fast=True, leaves_per_step=L, max_plies=256, fast_arena_granules=64)
+    eng = emu_call(E.Engine, 1, **kw)
+    eng.reset([0], [O.STARTING_FEN], [None])
+    steps, _ = drive_search("emu", eng, 1, L, softmax_eval(5), None)
+    assert eng.check_status() == 1 and eng.status_bits()[0] == E.ST_NODE_OVERFLOW
+    res = eng.result()
+    n, idx, val = int(res["n"][0]), res["idx"][0], res["val"][0]
+    assert 1 <= n <= 20 and abs(float(val[:n].sum()) - 1.0) < 1e-5 and steps >= sims // L
+    legal = {O.move_to_index(m) for m in O.Board(O.STARTING_FEN).legal_moves()}
+    assert set(int(i) for i in idx[:n]) <= legal
+    eng.close()
+    # the reference-semantics engine keeps treating the bit as a fault
+    assert E.Engine.soft_status_bits(type("X", (), {"fast": False})()) == 0
+
+
 @pytest.mark.parametrize("fen,moves,sims,L", CASES)
 def test_fast_kernels_match_numpy_restatement(fen, moves, sims, L):
     fn = softmax_eval(7)
