@@ -786,7 +786,6 @@ class CohortRollout:
         if K > 1 and self.device.type == "cuda":
             torch.cuda.synchronize(self.device)  # (buffers zeroed on the constructing stream are used on the cohorts' streams from here on)
         self.eng = _CohortEngines(self.parts)
-        self._turns = [0] * K  # cohort-plies ended per cohort
         self._rr = 0
         p0 = self.parts[0]
         self.S, self.B, self.L, self.fast = p0.S, p0.B, p0.L, p0.fast
@@ -835,39 +834,28 @@ class CohortRollout:
 
         return (fin_cb if on_finished is not None else None), ((lambda s: refill(s + base)) if refill is not None else None)
 
-    # plies a cohort may be ahead of the least advanced one.  1 (default) = every call ends exactly one ply of every cohort with work;
-    # larger values let a fast cohort be turned twice in a call -- measured equal on the bench (3.21 / 3.22 ms per ply at 4 and 1,
-    # profiles/r04_cohort_cu_masks.md), so the simpler contract stays; BETAONE_COHORT_LEAD is the lab switch
-    MAX_LEAD = max(1, int(os.environ.get("BETAONE_COHORT_LEAD", "1")))
-
     def play_ply(self, on_finished=None, refill=None, while_searching=None) -> int:
         """One cohort-ply per cohort with work, ended in the order in which the DEVICE finishes them: a cohort whose ply is done is
         turned and begun again at once, whichever it is (in a fixed rotation the host sat waiting for cohort 0 while cohort 2 had
         finished); a search that needs one more evaluation than was enqueued gets it without the host waiting for it (ply_end(block=
-        False)).  With MAX_LEAD > 1 a fast cohort may be turned twice in a call while a slow one is not turned at all.  The first
-        call begins every cohort's ply before it ends any."""
+        False)).  Every cohort is turned exactly once per call (letting fast cohorts run plies ahead of slow ones measured the same,
+        profiles/r04_cohort_cu_masks.md).  The first call begins every cohort's ply before it ends any."""
         moved = 0
         cbs = [self._callbacks(k, on_finished, refill) for k in range(self.K)]
         for k, p in enumerate(self.parts):
             if p._turn_due is None:
                 p.ply_begin(*cbs[k])
-        target = sum(1 for p in self.parts if p._turn_due is not None)
+        pending = [k for k, p in enumerate(self.parts) if p._turn_due is not None]
         if while_searching is not None:
             while_searching()
-        ended = 0
-        while ended < target:
-            due = [k for k, p in enumerate(self.parts) if p._turn_due is not None]
-            if not due:
-                break
-            floor = min(self._turns[k] for k in due)
-            k = self._pick_ready([k for k in due if self._turns[k] - floor < self.MAX_LEAD])
+        while pending:
+            k = self._pick_ready(pending)
             p = self.parts[k]
             n = p.ply_end(block=False)
             if n is None:  # (one more evaluation was enqueued for a straggling search: the cohort stays due)
                 continue
             moved += n
-            ended += 1
-            self._turns[k] += 1
+            pending.remove(k)
             p.ply_begin(*cbs[k])
         return moved
 
