@@ -1829,8 +1829,9 @@ extern "C" int bo_nn_heads(const void *p_dev, const void *v_dev, const float *wp
     a.p = p_dev; a.v = v_dev; a.wp = wp_dev; a.bp = bp_dev; a.w1 = w1_dev; a.b1 = b1_dev; a.w2 = w2_dev; a.b2 = b2_dev;
     a.policy_out = policy_out_dev; a.value_out = value_out_dev;
     a.vpart = scratch_dev;  // [16 K chunks][batch][256]
-    a.B = batch; a.softmax = flags & 1;
-    const unsigned tiles = (unsigned)(((batch + BO_HEADS_PROWS - 1) / BO_HEADS_PROWS) * (BO_HEADS_NA / 32) + ((batch + 63) / 64) * 4 * BO_HEADS_KS);
+    a.B = batch; a.softmax = flags & 1; a.pb = bo_heads_policy_boards(batch);
+    const int otw = 4 / (a.pb >> 5);
+    const unsigned tiles = (unsigned)(((batch + a.pb - 1) / a.pb) * ((BO_HEADS_NA / 32 + otw - 1) / otw) + ((batch + 63) / 64) * 4 * BO_HEADS_KS);
     if (flags & 2) hipLaunchKernelGGL(bo_k_heads_tiles<true>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);   // fp16 head planes
     else hipLaunchKernelGGL(bo_k_heads_tiles<false>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(bo_k_heads_rows, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, a);

@@ -8,8 +8,10 @@
 // As library calls this is two small GEMMs on forked streams, a softmax and a tail kernel: ~25 us of kernels that are launch-
 // and latency-bound (0.6 GFLOP in total) plus ~15 us of dependency gaps between graph nodes, behind every one of the ten
 // evaluations of a ply.  Here:
-//   bo_k_heads_tiles   workgroups 0 .. NP-1   logits tile [128 boards x 32 outputs] on v_mfma_f32_16x16x4_f32 (K = 128): every
-//                                             fragment of a wave is requested before its first MFMA (one memory round trip)
+//   bo_k_heads_tiles   workgroups 0 .. NP-1   logits tiles on v_mfma_f32_16x16x4_f32 (K = 128), a wave = [32 boards x 32 outputs]; the four
+//                                             waves of a workgroup cover [128 boards x 32 outputs] (more than 64 boards), [64 x 64] or
+//                                             [32 x 128] (a cohort's 64 boards: 73 workgroups instead of 146, none of their waves idle);
+//                                             every fragment of a wave is requested before its first MFMA (one memory round trip)
 //                      workgroups NP ..       value_fc1 partial tile [64 boards x 64 hidden x 128 of K = 2048]: both operand
 //                                             tiles are staged through LDS with coalesced loads; partial sums go to scratch
 //   bo_k_heads_rows    one board per workgroup: softmax of its logits row (the row passes through registers once) and
@@ -32,7 +34,6 @@
 #define BO_HEADS_NH 256
 #define BO_HEADS_KS 16        // K chunks of value_fc1 (partial sums reduced by the rows kernel, in a fixed order)
 #define BO_HEADS_PITCH 132    // floats per LDS tile row: 128 + 4 (conflict-free 16-byte fragment reads)
-#define BO_HEADS_PROWS 128    // boards per logits tile
 
 struct bo_heads_args {
     const void *p, *v;                        // [B,128], [B,2048]: float32, or float16 behind the fp16 tower (bo_tower_h.h)
@@ -40,7 +41,9 @@ struct bo_heads_args {
     float *policy_out, *value_out;            // [B,4672] (probabilities if softmax != 0, else logits), [B]
     float *vpart;                             // scratch [16 K chunks][B][256]: partial sums of value_fc1
     int B, softmax;
+    int pb;                                   // boards per policy workgroup: 128, 64 or 32 (bo_heads_policy_boards)
 };
+static inline int bo_heads_policy_boards(int batch) { return batch > 64 ? 128 : batch > 32 ? 64 : 32; }
 
 // four consecutive activations as float32 from a float32 or float16 array (element index e, a multiple of 4)
 template <bool HALF>
@@ -59,11 +62,15 @@ __global__ void __launch_bounds__(256)
 bo_k_heads_tiles(bo_heads_args a) {
     __shared__ __attribute__((aligned(16))) float tileA[64 * BO_HEADS_PITCH], tileW[64 * BO_HEADS_PITCH];  // value tiles [64][128 + 4]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kq = lane >> 4, i = lane & 15;
-    const int B = a.B, NPT = BO_HEADS_NA / 32, n_policy = ((B + BO_HEADS_PROWS - 1) / BO_HEADS_PROWS) * NPT;
+    // A policy workgroup's four waves cover `pb` boards x (128 / pb) output tiles of 32: pb = 128 (one output tile, the boards of four
+    // waves) down to 32 (four output tiles of the same 32 boards) -- with few boards (a cohort's 64) the launch then has half / a quarter
+    // of the workgroups and no idle waves; every output element is computed by the same instruction sequence for every pb.
+    const int B = a.B, pb = a.pb, nbw = pb >> 5, otw = 4 / nbw, NPT = (BO_HEADS_NA / 32 + otw - 1) / otw, n_policy = ((B + pb - 1) / pb) * NPT;
     const int wg = (int)blockIdx.x;
     if (wg < n_policy) {
-        // ---- logits tile: boards 128*rb + 32*wave + [0,32) (N), outputs 32*ct + [0,32) (M) ----
-        const int rb = wg / NPT, ct = wg - rb * NPT, r0 = BO_HEADS_PROWS * rb + 32 * wave, c0 = 32 * ct;
+        // ---- logits tile: boards pb*rb + 32*(wave % nbw) + [0,32) (N), outputs 32*(otw*ct + wave / nbw) + [0,32) (M) ----
+        const int rb = wg / NPT, ct = wg - rb * NPT, r0 = pb * rb + 32 * (wave % nbw), c0 = 32 * (otw * ct + wave / nbw);
+        if (c0 >= BO_HEADS_NA) return;  // (146 output tiles do not divide by four)
         const bo_f32x4 *w4 = reinterpret_cast<const bo_f32x4 *>(a.wp);
         constexpr int PG = BO_HEADS_KP / 16;
         bo_f32x4 fp[PG][2], fw[PG][2];

@@ -35,7 +35,8 @@ n = int(min(ring[0], Rollout.STAMP_CAP))
 tags, ts = ring[1:1 + 2 * n:2].astype(np.int64), ring[2:2 + 2 * n:2].astype(np.float64)
 khz = ctypes.c_int32(0); E.load_hip_library().bo_device_wall_clock_khz(0, ctypes.byref(khz))
 ts = ts / (khz.value or 100000) * 1e3  # us
-print(f"K = {K} (cu masks {getattr(ro, "cu_masks", "-")}), preroll {PREROLL}, {G} games, {steps} steps: {dt / steps * 1e3:.3f} ms per step, {n} stamps")
+MASKS = getattr(ro, "cu_masks", "-")
+print(f"K = {K} (cu masks {MASKS}), preroll {PREROLL}, {G} games, {steps} steps: {dt / steps * 1e3:.3f} ms per step, {n} stamps")
 ids = sorted(set(int(t) // 16 for t in tags))
 fw, st, gap = [], [], []
 for cid in ids:
