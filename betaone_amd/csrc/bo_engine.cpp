@@ -63,6 +63,9 @@ struct bo_engine {
     int watch_seen = 0;                        // OR of the watched status word over the fetched result blocks (bo_engine_watch)
     double *h_noise = nullptr;                // pinned [G][256]
     int *h_go = nullptr;                      // pinned [G]
+    int *h_action = nullptr;                  // pinned [2][G]: the actions of two consecutive bo_play calls (read by the kernel itself)
+    int action_flip = 0;
+    bool ship = true;                         // the turn's small blocks move by bo_k_ship instead of copy commands (BETAONE_TURN_COPIES=1: copies)
     std::vector<int> h_nl, h_term;
     bool nl_valid = false;  // h_nl holds the current roots' legal-move counts (set by bo_selfplay_begin)
     void *setup_dev = nullptr, *setup_host = nullptr;  // staging of bo_games_reset_ex (grow-only)
@@ -243,6 +246,8 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
     }
     rc |= rt_host_alloc((void **)&e->h_res, res_ints * 4); rc |= rt_host_alloc((void **)&e->h_info, info_ints * 4);
     rc |= rt_host_alloc((void **)&e->h_noise, G * BO_MAX_MOVES * sizeof(double)); rc |= rt_host_alloc((void **)&e->h_go, G * 4);
+    rc |= rt_host_alloc((void **)&e->h_action, 2 * G * 4);
+    { const char *v = getenv("BETAONE_TURN_COPIES"); e->ship = !(v && v[0] == '1'); }
     rc |= e->alloc(&d.gpos, G * c.PLY_CAP); rc |= e->alloc(&d.trk, G * c.TRK_CAP); rc |= e->alloc(&d.trk_cnt, G * c.TRK_CAP);
     rc |= e->alloc(&d.hist, G * 7);
     rc |= e->alloc(&d.n_visits, N); rc |= e->alloc(&d.parent, N); rc |= e->alloc(&d.first_child, N); rc |= e->alloc(&d.n_children, N);
@@ -320,7 +325,7 @@ extern "C" void bo_engine_destroy(bo_engine *e) {
     if (!e) return;
     rt_set_device(e->device);
     for (void *p : e->allocs) rt_free(p);
-    rt_host_free(e->h_res); rt_host_free(e->h_info); rt_host_free(e->h_noise); rt_host_free(e->h_go);
+    rt_host_free(e->h_res); rt_host_free(e->h_info); rt_host_free(e->h_noise); rt_host_free(e->h_go); rt_host_free(e->h_action);
     if (e->setup_dev) rt_free(e->setup_dev);
     if (e->setup_host) rt_host_free(e->setup_host);
     if (e->ev_begin_made) rt_event_destroy(e->ev_begin);
@@ -584,11 +589,22 @@ extern "C" int bo_search_stop(bo_engine *e, const int32_t *stop_mask, int32_t *s
 }
 
 // the result kernel and the copy of its block, enqueued (no wait)
-static int result_enqueue(bo_engine *e, void *stream) {
-    const size_t G = (size_t)e->d.c.G;
+static int ship(bo_engine *e, int *dst_a, const int *src_a, size_t n_a, int *dst_b, const int *src_b, size_t n_b, void *stream) {
+    const size_t n = n_a > n_b ? n_a : n_b;
+    const int blocks = (int)((n + 511) / 512 < 1 ? 1 : ((n + 511) / 512 > 128 ? 128 : (n + 511) / 512));  // ~8 words per lane, at most 128 waves
+    RT(RT_LAUNCH(bo_k_ship, blocks, stream, dst_a, src_a, (int)n_a, dst_b, src_b, (int)n_b, blocks));
+    (void)e;
+    return BO_OK;
+}
+
+// with_info: [phase | req_node] of every slot comes along (bo_selfplay_turn's "are all searches finished?")
+static int result_enqueue(bo_engine *e, void *stream, bool with_info = false) {
+    const size_t G = (size_t)e->d.c.G, res_words = G * (4 + 2 * (size_t)BO_RES_CAP) + 4;  // the whole result block (+ the watched word)
+    if (with_info && !e->ship) RT(rt_d2h(e->h_info, e->d_info_blk, 2 * G * 4, stream));
     if (e->fast) RT(RT_LAUNCH(bo_k_fw_result, e->d.c.G, stream, e->d, e->f));
     else RT(RT_LAUNCH(bo_k_result, e->d.c.G, stream, e->d));
-    RT(rt_d2h(e->h_res, e->d_res_blk, (G * (4 + 2 * (size_t)BO_RES_CAP) + 4) * 4, stream));  // the whole result block (+ the watched word) in one copy
+    if (e->ship) return ship(e, e->h_res, (const int *)e->d_res_blk, res_words, e->h_info, (const int *)e->d_info_blk, with_info ? 2 * G : 0, stream);
+    RT(rt_d2h(e->h_res, e->d_res_blk, res_words * 4, stream));
     return BO_OK;
 }
 
@@ -632,8 +648,14 @@ extern "C" int bo_search_result(bo_engine *e, int32_t *res_n, int32_t *res_idx, 
 
 extern "C" int bo_play(bo_engine *e, const int32_t *action, void *stream) {
     if (!e || !action) return fail(BO_E_ARG, "null argument");
-    RT(rt_h2d(e->d_action, action, (size_t)e->d.c.G * 4, stream));
-    RT(RT_LAUNCH(bo_k_play, e->d.c.G, stream, e->d, (const int *)e->d_action));
+    if (e->ship) {  // the kernel reads the actions from pinned host memory itself (two buffers: the previous call's kernel may not have run yet)
+        int *slot = e->h_action + (size_t)(e->action_flip ^= 1) * e->d.c.G;
+        memcpy(slot, action, (size_t)e->d.c.G * 4);
+        RT(RT_LAUNCH(bo_k_play, e->d.c.G, stream, e->d, (const int *)slot));
+    } else {
+        RT(rt_h2d(e->d_action, action, (size_t)e->d.c.G * 4, stream));
+        RT(RT_LAUNCH(bo_k_play, e->d.c.G, stream, e->d, (const int *)e->d_action));
+    }
     if (e->fast) RT(RT_LAUNCH(bo_k_fw_reroot, e->d.c.G, stream, e->d, e->f, e->fast_reuse));  // tree reuse: the played child becomes the root
     return BO_OK;
 }
@@ -802,12 +824,14 @@ static int selfplay_begin_lazy(bo_engine *e, const int32_t *want, float *nn_in_d
     const size_t G = (size_t)e->d.c.G;
     e->lazy_want.assign(want, want + G);
     memcpy(e->h_go, want, G * 4);
-    RT(rt_h2d(e->d_go, e->h_go, G * 4, stream));
+    if (e->ship) { int rcs = ship(e, e->d_go, e->h_go, G, nullptr, nullptr, 0, stream); if (rcs) return rcs; }  // (h_go is next written by bo_selfplay_begun, behind ev_begin)
+    else RT(rt_h2d(e->d_go, e->h_go, G * 4, stream));
     e->nl_valid = false;
     RT(RT_LAUNCH(bo_k_search_begin_want, e->d.c.G, stream, e->d, (const int *)e->d_go, nn_in_dev));
     int rc = bo_step(e, nullptr, nullptr, BO_POLICY_NONE, nn_in_dev, stream);
     if (rc) return rc;
-    RT(rt_d2h(e->h_info + 2 * G, e->d_info_blk + 2 * G, 3 * G * 4, stream));  // [root_nlegal | root_term | ply]
+    if (e->ship) { rc = ship(e, e->h_info + 2 * G, (const int *)e->d_info_blk + 2 * G, 3 * G, nullptr, nullptr, 0, stream); if (rc) return rc; }
+    else RT(rt_d2h(e->h_info + 2 * G, e->d_info_blk + 2 * G, 3 * G * 4, stream));  // [root_nlegal | root_term | ply]
     if (!e->ev_begin_made) { RT(rt_event_create(&e->ev_begin)); e->ev_begin_made = true; }
     RT(rt_event_record(e->ev_begin, stream));
     e->begin_lazy = true;
@@ -880,8 +904,7 @@ extern "C" int bo_selfplay_turn(bo_engine *e, const int32_t *active, const int32
         // step without waiting for the answer (it only reads the trees; if a search needs one more evaluation -- rare -- its
         // block is fetched again by the next call)
         const size_t G = (size_t)e->d.c.G;
-        RT(rt_d2h(e->h_info, e->d_info_blk, 2 * G * 4, stream));  // [phase | req_node]
-        rc = result_enqueue(e, stream);
+        rc = result_enqueue(e, stream, true);  // (+ [phase | req_node])
         if (rc) return rc;
         RT(rt_sync(stream));
         for (size_t g = 0; g < G; g++)

@@ -1113,6 +1113,16 @@ BO_KERNEL void bo_k_stop(Eng e, const int *mask) {
     }
 }
 
+// Two small blocks of words between device memory and PINNED, device-mapped host memory, by the compute queue itself: the turn of a
+// ply (result block out, sampled actions and go flags in, root info out) then has no copy commands between its kernels -- each
+// hipMemcpyAsync was ~10-50 us of runtime work plus a blit kernel of its own on the path the device idles through.  Either pair may be
+// empty (n = 0).  Host memory written here is visible to the host once the stream / the event behind this kernel has been waited for.
+BO_KERNEL void bo_k_ship(int *dst_a, const int *src_a, int n_a, int *dst_b, const int *src_b, int n_b, int n_blocks) {
+    const int i0 = bo_block() * 64 + bo_lane(), stride = n_blocks * 64;
+    for (int i = i0; i < n_a; i += stride) dst_a[i] = src_a[i];
+    for (int i = i0; i < n_b; i += stride) dst_b[i] = src_b[i];
+}
+
 // pi and best move of a finished search (mcts.py:259-280)
 BO_KERNEL void bo_k_result(Eng e) {
     const int g = bo_block(), lane = bo_lane();
