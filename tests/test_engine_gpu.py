@@ -740,6 +740,51 @@ def test_f16_heads_at_any_row_count_match_torch(backend):
                                b2.data_ptr(), out.data_ptr(), val.data_ptr(), None, 64, 1, torch.cuda.current_stream().cuda_stream) != 0   # softmax without scratch
 
 
+def test_turn_by_ship_kernel_plays_the_games_of_the_turn_by_copy_commands(backend, monkeypatch):
+    """The ply's turn (bo_selfplay_turn: result block and searches' state out, sampled actions in, root info out) moves its small
+    blocks by bo_k_ship between device memory and pinned host memory; BETAONE_TURN_COPIES=1 (read when an engine is created) keeps
+    the hipMemcpyAsync form.  Same seeds, same net: both forms must play the same games -- moves, pi, terminal codes."""
+    import torch
+    from betaone_amd.rollout import Rollout
+
+    class Net(torch.nn.Module):  # a cheap deterministic evaluate stage: logits and value from a fixed projection of the planes
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(11)
+            self.w = torch.nn.Parameter(torch.randn((120 * 64, 64), generator=g) * 0.05, requires_grad=False)
+            self.v = torch.nn.Parameter(torch.randn((64, 4672), generator=g) * 0.3, requires_grad=False)
+
+        def forward(self, x):
+            h = torch.tanh(x.flatten(1) @ self.w)
+            return h @ self.v, torch.tanh(h.sum(dim=1, keepdim=True) * 0.1)
+
+    def run(copies):
+        monkeypatch.setenv("BETAONE_TURN_COPIES", "1" if copies else "0")
+        net = Net().to("cuda:0").eval()
+        G = 48
+        ro = Rollout(net, G, num_simulations=96, mcts_batch_size=16, device="cuda:0", use_graph=True, rng_mode="native", max_game_moves=40)
+        ro.start_games(list(range(G)), list(range(G)), [100 + g for g in range(G)])
+        fins = {}
+        for _ in range(44):
+            ro.play_ply(on_finished=lambda f: fins.__setitem__(f.game_id, f))
+        for g in range(G):
+            if ro.games[g] is not None and ro.games[g].game_id not in fins:
+                fins[ro.games[g].game_id] = ro._finish(g, 0)
+        ro.eng.check_status()
+        ro.close()
+        return fins
+
+    a, b = run(False), run(True)
+    assert sorted(a) == sorted(b) == list(range(48))
+    for gid in a:
+        assert a[gid].moves == b[gid].moves and a[gid].terminal == b[gid].terminal and len(a[gid].moves) >= 10
+        pa, pb = a[gid].pis, b[gid].pis
+        assert len(pa) == len(pb)
+        for i in range(len(pa)):
+            (ia, va), (ib, vb) = pa[i], pb[i]
+            assert np.array_equal(ia, ib) and np.array_equal(va, vb)
+
+
 def test_masked_stream_runs_kernels_and_refuses_an_empty_mask(backend):
     """bo_stream_create_cu_mask / engine.MaskedStream: a HIP stream confined to a quarter of the compute units is an ordinary
     stream for this library's launches and for torch (ExternalStream); an all-zero mask is refused instead of hanging every launch."""
