@@ -66,6 +66,7 @@ struct bo_engine {
     int *h_action = nullptr;                  // pinned [2][G]: the actions of two consecutive bo_play calls (read by the kernel itself)
     int action_flip = 0;
     bool ship = true;                         // the turn's small blocks move by bo_k_ship instead of copy commands (BETAONE_TURN_COPIES=1: copies)
+    bool prefetch_valid = false;              // bo_search_result_prefetch has been enqueued behind the searches and nothing was stepped since
     std::vector<int> h_nl, h_term;
     bool nl_valid = false;  // h_nl holds the current roots' legal-move counts (set by bo_selfplay_begin)
     void *setup_dev = nullptr, *setup_host = nullptr;  // staging of bo_games_reset_ex (grow-only)
@@ -528,6 +529,7 @@ extern "C" int bo_step(bo_engine *e, const float *policy_dev, const float *value
                        void *stream) {
     if (!e || !nn_in_dev) return fail(BO_E_ARG, "null argument");
     if (policy_kind != BO_POLICY_NONE && (!policy_dev || !value_dev)) return fail(BO_E_ARG, "policy/value required");
+    e->prefetch_valid = false;  // (a prefetched result block is older than this step; replays of a captured step are the caller's to track)
     if (e->fast) {  // apply (one wave per row) -> backup + select (half a wave per game) -> leaf positions and planes (one wave per row)
         const int rows = e->d.c.G * e->f.L;
         if (policy_kind != BO_POLICY_NONE) RT(RT_LAUNCH(bo_k_fw_apply, rows, stream, e->d, e->f, policy_dev, policy_kind));
@@ -634,6 +636,17 @@ extern "C" int bo_engine_watch_seen(bo_engine *e, int32_t *seen_out, int32_t cle
     if (!e || !seen_out) return fail(BO_E_ARG, "bad arguments");
     *seen_out = e->watch_seen;
     if (clear) e->watch_seen = 0;
+    return BO_OK;
+}
+
+// The result block and the searches' state enqueued BEHIND the searches' last expected step, without waiting: when the caller later
+// finds the stream idle, bo_selfplay_turn(flags 2 | 8) reads both from pinned memory and needs no round trip of its own (if a search
+// turns out to need one more evaluation, the caller steps and prefetches again).  Any bo_step after it invalidates it.
+extern "C" int bo_search_result_prefetch(bo_engine *e, void *stream) {
+    if (!e) return fail(BO_E_ARG, "null engine");
+    int rc = result_enqueue(e, stream, true);
+    if (rc) return rc;
+    e->prefetch_valid = true;
     return BO_OK;
 }
 
@@ -894,8 +907,9 @@ extern "C" int bo_selfplay_turn(bo_engine *e, const int32_t *active, const int32
                                 int32_t defer_noise, int32_t *completed, void *stream) {
     if (!e || !want_next || !nn_in_dev || !completed) return fail(BO_E_ARG, "null argument");
     *completed = 0;
-    const bool poll_first = (defer_noise & 2) != 0, lazy_begin = (defer_noise & 4) != 0;
+    const bool poll_first = (defer_noise & 2) != 0, lazy_begin = (defer_noise & 4) != 0, prefetched = (defer_noise & 8) != 0;
     defer_noise &= 1;
+    if (prefetched && !poll_first) return fail(BO_E_ARG, "bo_selfplay_turn: flag 8 (result block prefetched) goes with flag 2");
     if (lazy_begin && !defer_noise) return fail(BO_E_ARG, "bo_selfplay_turn: flag 4 (begin without waiting) needs flag 1 (noise later)");
     if (e->begin_lazy) return fail(BO_E_STATE, "bo_selfplay_begun has not collected the previous turn's roots yet");
     int rc;
@@ -904,8 +918,11 @@ extern "C" int bo_selfplay_turn(bo_engine *e, const int32_t *active, const int32
         // step without waiting for the answer (it only reads the trees; if a search needs one more evaluation -- rare -- its
         // block is fetched again by the next call)
         const size_t G = (size_t)e->d.c.G;
-        rc = result_enqueue(e, stream, true);  // (+ [phase | req_node])
-        if (rc) return rc;
+        if (!(prefetched && e->prefetch_valid)) {
+            rc = result_enqueue(e, stream, true);  // (+ [phase | req_node])
+            if (rc) return rc;
+        }
+        e->prefetch_valid = false;
         RT(rt_sync(stream));
         for (size_t g = 0; g < G; g++)
             if (e->h_info[g] == PH_RUN) { *completed = -1; return BO_OK; }

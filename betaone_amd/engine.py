@@ -90,6 +90,7 @@ _SYMBOLS = {
     "bo_selfplay_turn": (C.c_int, [C.c_void_p, _I32P, _I32P, C.c_int32, C.c_double, C.c_double, _I32P, _I32P, _F32P, _I32P, _I32P, _I32P,
                                    C.c_void_p, _I32P, _I32P, _I32P, C.c_int32, _I32P, C.c_void_p]),
     "bo_selfplay_noise": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bo_search_result_prefetch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bo_selfplay_begun": (C.c_int, [C.c_void_p, _I32P, _I32P, _I32P]),
     "bo_selfplay_begin": (C.c_int, [C.c_void_p, _I32P, C.c_void_p, _I32P, _I32P, _I32P, C.c_void_p]),
     "bo_records_encode": (C.c_int, [C.c_int, C.POINTER(BoPosition), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -403,8 +404,13 @@ class Engine:
         self._check(self.lib.bo_selfplay_begun(self.h, _p(nl), _p(tm), _p(go)))
         return nl, tm, go
 
+    def result_prefetch(self, stream: int = 0) -> None:
+        """Enqueue the result block's trip to pinned host memory behind the searches (no wait): selfplay_turn(prefetched=True) then
+        needs no round trip of its own.  Stale after any further step of the searches."""
+        self._check(self.lib.bo_search_result_prefetch(self.h, stream))
+
     def selfplay_turn(self, active, move_number, temperature, out, want_next, nn_in_ptr: int, stream: int = 0, defer_noise: bool = False,
-                      poll_first: bool = False, lazy_begin: bool = False):
+                      poll_first: bool = False, lazy_begin: bool = False, prefetched: bool = False):
         """selfplay_sample + play + selfplay_begin(want_next) in one call.  Returns (out, (n_legal, terminal, go) or None):
         None when a game needs the dense NumPy sampler (action -3) -- nothing was played then.  poll_first: check that all
         searches are finished first; returns (None, None) if one is still running (issue another step and call again).
@@ -416,7 +422,7 @@ class Engine:
         done = C.c_int32(0)
         self._check(self.lib.bo_selfplay_turn(self.h, _p(a), _p(m), int(th), float(ti), float(tf), _p(out["n"]), _p(out["idx"]),
                                               _p(out["val"], _F32P), _p(out["best_idx"]), _p(out["action"]), _p(w), nn_in_ptr, _p(nl), _p(tm),
-                                              _p(go), (1 if defer_noise else 0) | (2 if poll_first else 0) | (4 if lazy_begin else 0),
+                                              _p(go), (1 if defer_noise else 0) | (2 if poll_first else 0) | (4 if lazy_begin else 0) | (8 if (prefetched and poll_first) else 0),
                                               C.byref(done), stream))
         if done.value < 0:
             return None, None

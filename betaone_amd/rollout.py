@@ -182,6 +182,7 @@ class Rollout:
         self._begun = None          # (n_legal, terminal, go) of searches already begun by the previous selfplay_turn
         self._turn_due = None       # go[G] of a ply whose searches ply_begin enqueued and ply_end has not turned yet
         self._ply_event = None      # recorded behind everything ply_begin enqueued (ply_ready)
+        self._prefetched = False    # the result block of the enqueued searches is on its way to pinned host memory (_prefetch_result)
         self._begun_want = None
         self._active = np.zeros(G, dtype=bool)
         self._plies = np.zeros(G, dtype=np.int64)
@@ -524,8 +525,19 @@ class Rollout:
             while_searching()
         if self.ply_profile is not None: self._pp("while_searching")
         self._turn_due = go
+        self._prefetch_result()
         self._mark_enqueued()
         return True
+
+    PREFETCH_RESULT = os.environ.get("BETAONE_RESULT_PREFETCH", "1") != "0"  # (0: the turn fetches the result block itself, for A/B runs)
+
+    def _prefetch_result(self) -> None:
+        """The result block's trip to pinned host memory, enqueued behind the searches' last expected step: by the time the stream is
+        idle the turn finds it there (ply_end makes no device round trip of its own)."""
+        self._prefetched = False
+        if self.PREFETCH_RESULT and not self.fast:
+            self.eng.result_prefetch(self._stream())
+            self._prefetched = True
 
     def _mark_enqueued(self) -> None:
         if self.device.type == "cuda":
@@ -555,12 +567,14 @@ class Rollout:
         # (fast mode mixes the noise into a kept root's priors when the search begins, so its draws cannot be deferred)
         while True:  # one native call per ply: "all searches finished?" + sample + play + begin the next searches
             out, begun = eng.selfplay_turn(go, move_number, self.temperature, self._out, want_next.astype(np.int32), self.nn_in.data_ptr(), stream,
-                                           defer_noise=not self.fast, poll_first=True, lazy_begin=not self.fast)
+                                           defer_noise=not self.fast, poll_first=True, lazy_begin=not self.fast, prefetched=self._prefetched)
+            self._prefetched = False
             if out is not None:
                 break
             self._eval_and_step()  # a search needed one more evaluation than expected
             if not block:
                 self._turn_due = go
+                self._prefetch_result()
                 self._mark_enqueued()
                 return None
         self.n_sims += int(np.count_nonzero(go)) * self.S

@@ -185,8 +185,15 @@ int bo_selfplay_turn(bo_engine *e, const int32_t *active, const int32_t *move_nu
  * wanted game whose new root is not terminal (mcts.py:160-162), *completed = 2, and n_legal_out / terminal_out / go_out are
  * NOT written: bo_selfplay_begun returns them (as bo_selfplay_begin would have) once the caller has enqueued the first
  * evaluation; it waits for the copy behind the begin kernels only.  Order: bo_selfplay_turn(4) -> enqueue the network
- * forward -> bo_selfplay_begun -> bo_selfplay_noise -> bo_step.  (Reference-semantics engines.) */
+ * forward -> bo_selfplay_begun -> bo_selfplay_noise -> bo_step.  (Reference-semantics engines.)
+ * Bit 3 (value 8, with bit 1): the result block and the searches' state have been enqueued behind the searches already
+ * (bo_search_result_prefetch) and no step has been issued since: the call then only waits for `stream` and reads both from pinned
+ * memory -- a cohort whose stream is idle is turned without a device round trip. */
 int bo_selfplay_begun(bo_engine *e, int32_t *n_legal_out, int32_t *terminal_out, int32_t *go_out);
+/* (ABI 4) Enqueue the result kernel and the copy of [result block | searches' state] to pinned host memory on `stream`, behind the
+ * searches' last expected step, and return without waiting (see bo_selfplay_turn, bit 3).  Replaying a CAPTURED step afterwards makes the
+ * block stale without the library knowing: the caller prefetches again (bo_step itself invalidates it). */
+int bo_search_result_prefetch(bo_engine *e, void *stream);
 int bo_selfplay_noise(bo_engine *e, void *stream);
 
 /* ---- records ------------------------------------------------------------------------------------
