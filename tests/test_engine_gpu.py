@@ -128,6 +128,8 @@ def test_rollout_with_torch_net_graph_equals_eager(backend):
 
 
 def test_records_roundtrip_and_expand(backend):
+    """Finished games -> compact wire records -> re-expanded training tensors: equal to the tensors encoded in the slot (two HIP
+    encoders) AND to the CPU oracle's encoding of the same plies (the pin: the oracle's encoder is checked against the reference's traces)."""
     import torch
     from betaone_amd import records
     from betaone_amd.rollout import Rollout
@@ -158,6 +160,16 @@ def test_records_roundtrip_and_expand(backend):
         for i, (st, pi, z) in enumerate(recs):
             assert torch.equal(st, dense[f.game_id][i])  # re-expanded on "another rank" == encoded in the slot
             assert z == f.z(i)
+        # ... and both == the CPU oracle's encode_board of the same plies with the END-of-game tracker (self_play.py:200-208)
+        from betaone_amd import engine as E
+        from oracle import oracle as O
+        b = O.Board(O.STARTING_FEN)
+        trk = O.PyTracker(); trk.add_board(b)
+        for m in f.moves:
+            b.push(E.move_to_uci(int(m))); trk.add_board(b)
+        hist = b.positions()
+        for i in range(len(recs)):
+            assert np.array_equal(recs[i][0].cpu().numpy(), O.encode_board(hist[:i + 1], trk)), (f.game_id, i)
 
 
 @pytest.mark.parametrize("shape", [(120, 64), (64, 64), (120, 128), (128, 128), (120, 256), (256, 256)])
