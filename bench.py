@@ -68,7 +68,7 @@ def parse():
     ap.add_argument("--cohorts", type=int, default=None,
                     help="the resident games as K phase-shifted cohorts, each with its own engine, HIP stream and captured graphs "
                          "(betaone_amd.rollout.CohortRollout); results per game are identical for every K; default: 4 from 256 games up, 2 from 128, else 1")
-    ap.add_argument("--cu-masks", default=None, choices=["auto", "off", "contiguous", "interleaved"],
+    ap.add_argument("--cu-masks", default=None, choices=["auto", "off", "contiguous", "interleaved", "full"],
                     help="cohort streams confined to disjoint 1/K shares of the compute units (hipExtStreamCreateWithCUMask; default: "
                          "BETAONE_COHORT_CU_MASK or off; with 4 cohorts 'contiguous' is what keeps their towers off each other's CUs)")
     ap.add_argument("--no-graph", action="store_true")

@@ -1824,8 +1824,8 @@ extern "C" int bo_debug_stamp(void *ring_dev, uint64_t tag, uint64_t capacity, v
 #endif
 }
 
-// A stream whose kernels run on the compute units named by the mask only (bit i = CU i).  K cohorts with disjoint sets: their towers
-// (one workgroup per board, grid far below the chip) no longer share CUs while others idle -- profiles/r04_cohort_cu_masks.md.
+// A stream whose kernels run on the compute units named by the mask only (bit i = CU i) -- and which has a hardware queue of its own, which
+// is what K > 2 cohorts need first (pool streams share queues; profiles/r04_cohort_cu_masks.md: full masks 3.03 ms, pool streams 4.1 ms per ply).
 extern "C" int bo_stream_create_cu_mask(int device, const uint32_t *mask_words, int n_words, void **stream_out) {
 #if defined(BO_WAVE_EMU)
     (void)device; (void)mask_words; (void)n_words; (void)stream_out;

@@ -195,7 +195,8 @@ def cu_partition_masks(n_cu: int, parts: int, layout: str = "contiguous") -> lis
     out = []
     for p in range(parts):
         m = np.zeros(words, dtype=np.uint32)
-        idx = np.arange(p * per, (p + 1) * per) if layout == "contiguous" else np.arange(per) * parts + p
+        idx = (np.arange(p * per, (p + 1) * per) if layout == "contiguous" else np.arange(n_cu) if layout == "full"  # ("full": a lab
+               else np.arange(per) * parts + p)                            # layout -- every part all CUs, only the stream's own queue)
         np.bitwise_or.at(m, idx // 32, (np.uint32(1) << (idx % 32).astype(np.uint32)))
         out.append(m)
     return out

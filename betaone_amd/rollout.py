@@ -780,12 +780,13 @@ class CohortRollout:
         # (cohort 0 keeps torch's current stream semantics only when it is alone; with K > 1 every cohort gets a stream of its own)
         # cu_masks: every cohort's stream confined to its own 1/K of the compute units ("contiguous" / "interleaved", engine.
         # cu_partition_masks); None / "off": plain streams, the dispatcher places the cohorts' workgroups as it likes.
-        # "auto" (default, or BETAONE_COHORT_CU_MASK): contiguous from three cohorts up -- unconfined, four 64-board towers land on each
-        # other's CUs (4.2-4.7 ms per ply against 2.9 confined; two cohorts place well either way) -- profiles/r04_cohort_cu_masks.md.
+        # "auto" (default, or BETAONE_COHORT_CU_MASK): contiguous from three cohorts up.  What matters most is that a stream made with a CU
+        # mask has a hardware queue of its own (torch's pool streams share queues: four cohorts then wait for each other's launches, 4.1-4.7
+        # ms per ply against 3.0); the confinement itself is worth <= 0.7 % -- profiles/r04_cohort_cu_masks.md.  "full": every CU for every cohort.
         self.cu_masks = cu_masks if cu_masks is not None else os.environ.get("BETAONE_COHORT_CU_MASK", "auto")
         if self.cu_masks == "auto":
             self.cu_masks = "contiguous" if K > 2 else "off"
-        if self.cu_masks not in ("off", "contiguous", "interleaved"):
+        if self.cu_masks not in ("off", "contiguous", "interleaved", "full"):
             raise ValueError(f"CohortRollout: cu_masks={self.cu_masks!r} (off / contiguous / interleaved / auto)")
         self._masked: List[E.MaskedStream] = []
         if K > 1 and self.device.type == "cuda" and self.cu_masks != "off":

@@ -385,8 +385,9 @@ int bo_device_wall_clock_khz(int device, int32_t *khz_out);   /* rate of that cl
  * the caller, `capacity` entries): the timeline of a stream's phases as the device ran them, also between the nodes of a captured graph. */
 int bo_debug_stamp(void *ring_dev, uint64_t tag, uint64_t capacity, void *stream);
 /* (ABI 4) A HIP stream confined to a set of compute units (hipExtStreamCreateWithCUMask): bit i of mask_words = CU i of `device`.
- * CohortRollout gives every cohort such a stream with a disjoint set, so that the cohorts' one-board-per-workgroup towers do not land on
- * the same CUs while others idle (the reference's counterpart is one OS process per game batch, main.py:160-175).  The handle is a
+ * CohortRollout gives every cohort such a stream with a disjoint set: the stream has a hardware queue of its own (pool streams share
+ * queues: four cohorts then wait for each other's launches) and its kernels stay off the other cohorts' CUs (the reference's counterpart
+ * is one OS process per game batch, main.py:160-175).  The handle is a
  * hipStream_t for every `stream` argument of this header and for torch.cuda.ExternalStream. */
 int bo_stream_create_cu_mask(int device, const uint32_t *mask_words, int n_words, void **stream_out);
 int bo_stream_destroy(void *stream);
