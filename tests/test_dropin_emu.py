@@ -481,6 +481,37 @@ def test_cohort_count_is_the_largest_share_of_config_cohorts_that_keeps_64_slots
         config.COHORTS = saved
 
 
+def test_prefetched_result_block_and_fetched_one_give_the_same_games(monkeypatch):
+    """Rollout._prefetch_result (bo_search_result_prefetch + bo_selfplay_turn flag 8): the result block enqueued behind the searches by
+    ply_begin, or fetched by the turn itself -- the same games either way, also when a search needs more evaluations than were enqueued
+    (expected_evals lowered: the turn then finds searches still running, steps them and prefetches again)."""
+    from betaone_amd import rollout as R
+    config.NUM_SIMULATIONS, config.MCTS_BATCH_SIZE, config.MAX_GAME_MOVES = 40, 8, 6
+    model = FakeNet(scale=2.0, salt=3)
+    ids, seeds = list(range(5)), [70 + i for i in range(5)]
+    runs = []
+    for prefetch, short in ((True, False), (False, False), (True, True)):
+        monkeypatch.setattr(R.Rollout, "PREFETCH_RESULT", prefetch)
+        if short:  # every ply: one evaluation fewer enqueued than the searches need
+            orig = R.Rollout.__init__
+
+            def init(self, *a, **k):
+                orig(self, *a, **k)
+                self.expected_evals -= 1
+            monkeypatch.setattr(R.Rollout, "__init__", init)
+        config.COHORTS, config.COHORT_MIN_SLOTS = 2, 1
+        try:
+            runs.append(self_play.run_self_play_games(model, ids, seeds=seeds, n_slots=4))
+        finally:
+            config.COHORTS = 1
+            del config.COHORT_MIN_SLOTS
+    for other in runs[1:]:
+        for g in ids:
+            assert len(other[g]) == len(runs[0][g]) > 0
+            for (s1, p1, z1), (s2, p2, z2) in zip(other[g], runs[0][g]):
+                assert torch.equal(s1, s2) and np.array_equal(p1, p2) and z1 == z2
+
+
 def test_one_overlong_game_does_not_end_the_others():
     """config.ENGINE_MAX_PLIES smaller than the games: a slot whose position stack is full stops THAT game like the
     reference's move limit (self_play.py:186: records of the moves played are kept) and every other game -- running or
