@@ -791,7 +791,15 @@ class CohortRollout:
         self._masked: List[E.MaskedStream] = []
         if K > 1 and self.device.type == "cuda" and self.cu_masks != "off":
             n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
-            self._masked = [E.MaskedStream(self.device, m) for m in E.cu_partition_masks(n_cu, K, self.cu_masks)]
+            try:
+                self._masked = [E.MaskedStream(self.device, m) for m in E.cu_partition_masks(n_cu, K, self.cu_masks)]
+            except E.EngineError as ex:  # (placement only: the games come out the same on pool streams, slower from three cohorts up)
+                import warnings
+                for m in self._masked:
+                    m.close()
+                self._masked = []
+                warnings.warn(f"CohortRollout: no CU-masked streams ({ex}); the cohorts run on torch's pool streams", RuntimeWarning)
+                self.cu_masks = "off"
         self.parts: List[Rollout] = []
         for k in range(K):
             st = None
