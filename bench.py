@@ -164,7 +164,8 @@ def softmax_site(net, args, rows):
 
 def select_roofline(args, device):
     """HBM roofline of the PUCT-select kernel on the SURVEY section 8d wide workload."""
-    from betaone_amd import select_wide as SW
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import select_wide_lab as SW  # lab harness of the synthetic wide-tree kernel (include/betaone_lab.h), not part of the package
 
     n_trees = args.wide_trees
     if n_trees <= 0:

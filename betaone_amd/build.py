@@ -23,9 +23,10 @@ def hipcc() -> str:
 
 def dependencies():
     """Everything libbetaone_hip.so is compiled from: every file of csrc/ (bo_engine.cpp includes all the headers), the
-    public header, and this file (the flags)."""
+    public headers, and this file (the flags)."""
     deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".cpp", ".hip"))]
-    return deps + [os.path.join(HERE, "..", "include", "betaone_engine.h"), os.path.abspath(__file__)]
+    inc = os.path.join(HERE, "..", "include")
+    return deps + [os.path.join(inc, "betaone_engine.h"), os.path.join(inc, "betaone_lab.h"), os.path.abspath(__file__)]
 
 
 def source_hash() -> str:

@@ -3,6 +3,7 @@
 // No torch types, no chess logic on the host: FEN / UCI text is parsed into plain bitboards and
 // everything else (replaying the move stack, keys, legality, draw rules) happens on the device.
 #include "../../include/betaone_engine.h"
+#include "../../include/betaone_lab.h"  // measurement / introspection entry points: exported by the same library, not part of the boundary
 
 #include "bo_tree.h"
 #include "bo_fastw.h"

@@ -32,7 +32,7 @@
 #define BO_RES_CAP 256
 #define BO_PLANES 120
 #ifndef BO_PROF_SLOTS
-#define BO_PROF_SLOTS 16  // bo_debug_profile: u64 counters per game (public: include/betaone_engine.h)
+#define BO_PROF_SLOTS 16  // bo_debug_profile: u64 counters per game (public: include/betaone_lab.h)
 #endif
 #define BO_ROW (BO_PLANES * 64)
 

@@ -66,7 +66,7 @@ _I32P = C.POINTER(C.c_int32)
 _F32P = C.POINTER(C.c_float)
 _F64P = C.POINTER(C.c_double)
 
-_SYMBOLS = {
+_SYMBOLS = {  # include/betaone_engine.h: the drop-in boundary
     "bo_abi_version": (C.c_int, []),
     "bo_last_error": (C.c_char_p, []),
     "bo_engine_create": (C.c_int, [C.POINTER(BoConfig), C.c_int, C.POINTER(C.c_void_p)]),
@@ -94,10 +94,7 @@ _SYMBOLS = {
     "bo_selfplay_begun": (C.c_int, [C.c_void_p, _I32P, _I32P, _I32P]),
     "bo_selfplay_begin": (C.c_int, [C.c_void_p, _I32P, C.c_void_p, _I32P, _I32P, _I32P, C.c_void_p]),
     "bo_records_encode": (C.c_int, [C.c_int, C.POINTER(BoPosition), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    "bo_debug_tree": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BoNode), C.c_int32, _I32P, C.c_void_p]),
-    "bo_debug_fast": (C.c_int, [C.c_void_p, C.c_int, _I32P, C.c_int32, _I32P, C.c_void_p]),
     "bo_fast_options": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
-    "bo_event_pair_overhead": (C.c_int, [_F64P, C.c_int32, C.c_void_p]),
     "bo_nn_tower_status": (C.c_int, [C.c_void_p, _I32P, C.c_void_p]),
     "bo_nn_tower_word": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "bo_replay_create": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -108,14 +105,10 @@ _SYMBOLS = {
     "bo_nn_b1_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "bo_nn_b1_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "bo_nn_b1_status": (C.c_int, [C.c_void_p, _I32P, C.c_void_p]),
-    "bo_nn_b1_profile": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.c_int]),
     "bo_nn_b1_destroy": (None, [C.c_void_p]),
     "bo_engine_watch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bo_engine_watch_seen": (C.c_int, [C.c_void_p, _I32P, C.c_int32]),
-    "bo_fast_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _I32P, C.c_int32, _F64P, C.POINTER(C.c_int64),
-                               C.c_void_p]),
     "bo_engine_status": (C.c_int, [C.c_void_p, _I32P, _I32P, _I32P, _I32P, _I32P, _I32P, C.c_void_p]),
-    "bo_debug_profile": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.c_void_p]),
     "bo_movegen_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BoPosition), _I32P, _I32P, _I32P, C.c_void_p]),
     "bo_nn_bias_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "bo_nn_se_residual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -131,13 +124,23 @@ _SYMBOLS = {
     "bo_nn_tower_create": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p,
                                      C.c_int, C.POINTER(C.c_void_p)]),
     "bo_nn_tower_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
-    "bo_debug_stamp": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
     "bo_device_wall_clock_khz": (C.c_int, [C.c_int, _I32P]),
     "bo_stream_create_cu_mask": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_void_p)]),
     "bo_stream_destroy": (C.c_int, [C.c_void_p]),
-    "bo_nn_tower_forward_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "bo_nn_value_tail": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "bo_nn_tower_destroy": (None, [C.c_void_p]),
+}
+# include/betaone_lab.h: introspection for the parity tests and in-kernel timing for bench.py / scripts/ (same library, not the boundary)
+_LAB_SYMBOLS = {
+    "bo_debug_tree": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BoNode), C.c_int32, _I32P, C.c_void_p]),
+    "bo_debug_fast": (C.c_int, [C.c_void_p, C.c_int, _I32P, C.c_int32, _I32P, C.c_void_p]),
+    "bo_event_pair_overhead": (C.c_int, [_F64P, C.c_int32, C.c_void_p]),
+    "bo_nn_b1_profile": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.c_int]),
+    "bo_fast_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _I32P, C.c_int32, _F64P, C.POINTER(C.c_int64),
+                               C.c_void_p]),
+    "bo_debug_profile": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.c_void_p]),
+    "bo_debug_stamp": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "bo_nn_tower_forward_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "bo_select_wide": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
 }
@@ -146,8 +149,8 @@ HIP_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", 
 
 
 def bind(cdll: C.CDLL) -> C.CDLL:
-    """Attach argument/return types for every symbol include/betaone_engine.h declares."""
-    for name, (res, args) in _SYMBOLS.items():
+    """Attach argument/return types for every symbol include/betaone_engine.h and include/betaone_lab.h declare."""
+    for name, (res, args) in list(_SYMBOLS.items()) + list(_LAB_SYMBOLS.items()):
         fn = getattr(cdll, name)  # AttributeError here == library does not export the ABI
         fn.restype = res
         fn.argtypes = args

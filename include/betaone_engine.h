@@ -24,12 +24,11 @@
 extern "C" {
 #endif
 
-/* Bumped whenever an output size, a struct, or the layout a caller has to produce changes (2: bo_debug_profile returns
+/* Bumped whenever an output size, a struct, or the layout a caller has to produce changes (2: bo_debug_profile (betaone_lab.h) returns
  * [G][BO_PROF_SLOTS = 16] counters, the BO_TOWER_WINOGRAD packed-weight K order for 128 filters is winograd_k_order's;
  * 3: fast-mode arenas are allocated in 128-byte granules of 8 records, bo_fast_stats counts granules).  A caller checks
  * bo_abi_version() == BO_ABI_VERSION before anything else (tests/c_abi_smoke.c). */
 #define BO_ABI_VERSION 4
-#define BO_PROF_SLOTS 16             /* uint64 counters per game returned by bo_debug_profile */
 #define BO_NUM_ACTIONS 4672          /* config.NUM_ACTIONS, config.py:29 */
 #define BO_INPUT_CHANNELS 120        /* config.INPUT_CHANNELS, config.py:28 */
 #define BO_ROW_FLOATS (120 * 64)
@@ -208,14 +207,7 @@ int bo_game_encode(bo_engine *e, int slot, int first, int n, float *out_dev, voi
  * as returned by bo_game_export (ep_key filled), plies [first, first+n) into out_dev.  Needs no engine.  Synchronises. */
 int bo_records_encode(int n_positions, const bo_position *positions, int first, int n, float *out_dev, void *stream);
 
-/* ---- introspection (parity tests, profiling) ------------------------------------------------- */
-typedef struct {
-    int32_t parent, n_visits, first_child, n_children;
-    float q_value, prior;
-    int32_t move;      /* from|to<<6|promo<<12 */
-    int32_t terminal;  /* -1 never visited as leaf, 0 no, 1 mate, 2 draw */
-} bo_node;
-int bo_debug_tree(bo_engine *e, int slot, bo_node *out, int32_t cap, int32_t *n_nodes, void *stream);
+/* ---- FAST mode options ---------------------------------------------------------------------------- */
 /* FAST mode (cfg.mode = 1; NOT the reference's semantics).  Every argument: -1 leaves the
  * setting as it is.  tree_reuse != 0 (default) keeps the played child's subtree as the next search's tree -- the reference
  * rebuilds the tree every move (mcts.py:176).  games_per_halfwave (2 or 4, default 2): games the select + backup kernel
@@ -226,57 +218,17 @@ int bo_debug_tree(bo_engine *e, int slot, bo_node *out, int32_t cap, int32_t *n_
  * All variants compute the same trees (tests/test_engine_gpu.py); the defaults are the fastest measured on an MI355X. */
 int bo_fast_options(bo_engine *e, int32_t tree_reuse, int32_t games_per_halfwave, int32_t select_flags);
 #define BO_FAST_GRANULE_BYTES 128    /* a fast-mode arena is allocated in granules of 8 16-byte records */
-/* FAST mode, per game [G]: record granules requested by PUCT descents so far (x BO_FAST_GRANULE_BYTES = bytes the select
- * path moved), path nodes updated by the backup (x 16 B; with 12 B x children_scanned + 8 B x levels of bo_engine_status
- * these are the algorithmic bytes of SURVEY.md section 8d), granules in use in the game's arena. */
-int bo_fast_stats(bo_engine *e, uint64_t *granules_read, uint64_t *path_nodes, int32_t *arena_granules, int32_t time_select, double *select_ms,
-                  int64_t *select_launches, void *stream);
-/* What a pair of HIP events around ONE kernel launch measures beyond the kernel itself on this device and stream: from the medians of
- * `samples` (1..256) pairs around one and around two empty one-wave kernels (2 * p1 - p2: the second launch's own cost taken out), in
- * milliseconds.  bench.py subtracts it from the event-timed launches of
- * the select + backup kernel (a ~60 us kernel: the pair's own ~6 us is 10 % of it) and checks the result against rocprofv3's
- * per-dispatch durations of the same command (profiles/).  Synchronises `stream`. */
-int bo_event_pair_overhead(double *ms_out, int32_t samples, void *stream);
-/* FAST mode introspection (tests, profiling): game `slot`'s control block -- ctl_out [ctl_cap >= 16 + 7 * L rounded up to 32]:
- * [0] rows, [1] simulations of the step in flight, [2] live arena, [3] granules in use, [4..8] counters, then from index 16
- * seven arrays of L: row_slot, row_plink, row_nlegal, row_term, row_sim, sim_row, sim_plen (csrc/bo_fastw.h) -- and the paths of
- * the step's simulations, paths_out [L][64] record ids root..leaf.  Either pointer may be NULL.  Synchronises. */
-int bo_debug_fast(bo_engine *e, int slot, int32_t *ctl_out, int32_t ctl_cap, int32_t *paths_out, void *stream);
-/* time_select: 1 / 0 switches timing of the select + backup kernel (bo_k_fw_select) with HIP events on its launch stream
- * on / off for the following EAGER bo_step calls (not while the stream is being captured), -1 leaves it as it is;
- * select_ms / select_launches return the time and the number of launches accumulated since it was switched on.  Any out
- * pointer may be NULL.  Synchronises. */
 /* per game [G]: status bits, NN evaluations, flushes, terminal simulations, tree levels descended,
  * children scanned by the PUCT select (the last two give the select kernel's algorithmic bytes). */
 int bo_engine_status(bo_engine *e, int32_t *status, int32_t *evals, int32_t *flushes, int32_t *term_sims,
                      int32_t *levels, int32_t *children_scanned, void *stream);
 
-/* Per-phase shader cycles of bo_step (s_memtime), accumulated per game while enabled: cycles_out [G][BO_PROF_SLOTS] (16
- * uint64 per game; size the buffer with the macro) =
- *   [0] apply, [1] select, [2] first visit (move generation + draw rules), [3] terminal backups, [4] leaf encode, [5] flush,
- *   [6] total, [7] game-steps counted, [8] simulation-loop iterations, [9] first visits, [10] terminal-burst calls,
- *   [11] simulations applied inside bursts, [12] terminal simulations on the general path, [13] cycles in burst set-up,
- *   [14] cycles in the burst loop, [15] switches between the two paths a burst holds in registers.
- * enable: 1 = every game-step, N > 1 = only game-steps longer than N cycles, 0 = off (a 0->on switch clears the
- * counters), -1 = only read.  A captured hipGraph keeps the setting it
- * was captured with.  Synchronises when cycles_out != NULL. */
-int bo_debug_profile(bo_engine *e, int enable, uint64_t *cycles_out, void *stream);
 
 /* ---- stand-alone kernels -------------------------------------------------------------------------
  * Legal moves (python-chess order) of n raw positions: moves_out [n,256] int32, n_out [n], check_out [n]. */
 int bo_movegen_batch(bo_engine *e, int n, const bo_position *pos, int32_t *moves_out, int32_t *n_out,
                      int32_t *check_out, void *stream);
 
-/* PUCT select (mcts.py:72-118 arithmetic) over caller-provided WIDE trees, the HBM-roofline workload of
- * SURVEY.md section 8d.  blocks_dev: array of 512-byte, 512-byte-aligned child blocks = 32 records
- *   { int32 n; float q; float prior; int32 child_block (-1 = not expanded) }
- * root_block_dev[t] / root_n_dev[t]: root child block and root visit count of tree t; sqrt_lut_dev[n] =
- * f32(sqrt(n + 1e-8)).  out_leaf_dev[t] = block*32 + child of the selected leaf, out_levels_dev[t] = levels
- * descended (x 392 B = algorithmic bytes).  grid_blocks <= 0 picks one 256-thread workgroup per 8 trees.
- * Asynchronous on `stream`. */
-int bo_select_wide(const void *blocks_dev, const int32_t *root_block_dev, const int32_t *root_n_dev,
-                   const float *sqrt_lut_dev, int n_trees, int max_depth, float cpuct, int grid_blocks,
-                   int32_t *out_leaf_dev, int32_t *out_levels_dev, void *stream);
 
 /* ---- fused epilogues of the evaluate stage (network.py:64-118 with BatchNorm folded), NCHW float32, 8x8 ----------
  * x = relu(x + bias[c] (+ residual)) in place; residual_dev may be NULL.  Asynchronous on `stream`. */
@@ -374,16 +326,7 @@ int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layers, const fl
                        const float *params, int64_t n_params, int channels, int algo, const bo_tower_head_desc *head, int device,
                        bo_tower **out);
 int bo_nn_tower_forward(bo_tower *tower, const float *x_dev, float *y_dev, void *head_a_dev, void *head_b_dev, int batch, void *stream);
-/* (ABI 4) bo_nn_tower_forward with the launch's duration noted by the kernel itself (BO_TOWER_SPLIT_F16): timing_dev = uint64
- * [seq | arrivals | start[4096] | end[4096]], zeroed by the caller; launch k with this buffer leaves (first workgroup's start, last
- * workgroup's end) in slot k % 4096, in ticks of the device's constant-rate clock.  One launch per buffer at a time.  Measurement aid
- * (bench.py's live roofline leg: event pairs cannot sit between the nodes of a captured graph). */
-int bo_nn_tower_forward_timed(bo_tower *tower, const float *x_dev, float *y_dev, void *head_a_dev, void *head_b_dev, int batch,
-                              void *timing_dev, void *stream);
 int bo_device_wall_clock_khz(int device, int32_t *khz_out);   /* rate of that clock (hipDeviceAttributeWallClockRate) */
-/* LAB: enqueue a one-thread kernel that appends (tag, wall_clock64()) to `ring_dev` (uint64: [count | tag0, t0 | tag1, t1 | ...], zeroed by
- * the caller, `capacity` entries): the timeline of a stream's phases as the device ran them, also between the nodes of a captured graph. */
-int bo_debug_stamp(void *ring_dev, uint64_t tag, uint64_t capacity, void *stream);
 /* (ABI 4) A HIP stream confined to a set of compute units (hipExtStreamCreateWithCUMask): bit i of mask_words = CU i of `device`.
  * CohortRollout gives every cohort such a stream with a disjoint set: the stream has a hardware queue of its own (pool streams share
  * queues: four cohorts then wait for each other's launches) and its kernels stay off the other cohorts' CUs (the reference's counterpart
@@ -450,10 +393,6 @@ int bo_nn_b1_forward(bo_b1 *tower, const float *x_dev, float *y_dev, int batch, 
  * is invalid then); or -1: an activation left the fp16 range with split weights (saturated: the output is wrong, use a handle without
  * split weights).  Synchronises `stream`. */
 int bo_nn_b1_status(bo_b1 *tower, int32_t *code_out, void *stream);
-/* LAB: per-wave shader-clock sums of a layer's phases {wait, stage, matrix pipe, reduction, epilogue + signal, layers} over the
- * launches between enable = 1 and enable = 0 (which copies [batch * tiles * 4][8] uint64 out, `cap` rows at most).  Not for graphs
- * captured before the switch (the kernel argument is frozen in them). */
-int bo_nn_b1_profile(bo_b1 *tower, int enable, uint64_t *out, int cap);
 void bo_nn_b1_destroy(bo_b1 *tower);
 
 #ifdef __cplusplus

@@ -57,6 +57,20 @@ int main() {
             snprintf(nm, sizeof nm, "K=%d part %d contiguous", K, c); run(nm, lo, dev, 1024); run(nm, lo, dev, per);
             snprintf(nm, sizeof nm, "K=%d part %d interleaved", K, c); run(nm, il, dev, 1024); run(nm, il, dev, per);
         }
+    // Round 5 ("whole-XCD masks, two XCDs = 64 CUs per cohort").  The driver deals the mask's bits over the XCCs (bit i -> XCC i % 8,
+    // position i / 8 inside it) and the hardware deals a grid's workgroups round-robin over ALL eight XCCs whatever the mask says, so a
+    // mask that leaves an XCC without CUs cannot be honoured: these show what happens instead.
+    for (int nx : {1, 2, 4}) {  // every CU of XCCs 0 .. nx-1, none elsewhere
+        std::vector<uint32_t> m(W, 0);
+        for (int i = 0; i < p.multiProcessorCount; i++) if (i % 8 < nx) m[i / 32] |= 1u << (i % 32);
+        char nm[64]; snprintf(nm, sizeof nm, "whole XCCs 0..%d only", nx - 1);
+        run(nm, m, dev, 1024); run(nm, m, dev, 64);
+    }
+    {   // every CU of XCCs 0 and 1, ONE CU in each of the other six (so that no XCC is empty)
+        std::vector<uint32_t> m(W, 0);
+        for (int i = 0; i < p.multiProcessorCount; i++) if (i % 8 < 2 || i / 8 == 0) m[i / 32] |= 1u << (i % 32);
+        run("XCC 0,1 whole + 1 CU in others", m, dev, 1024); run("XCC 0,1 whole + 1 CU in others", m, dev, 64);
+    }
     // what an unmasked stream does with a grid smaller than the chip (64 one-board workgroups, as a 64-board cohort's tower launches)
     run("no mask", {}, dev, 64); run("no mask", {}, dev, 128); run("no mask", {}, dev, 256);
     return 0;

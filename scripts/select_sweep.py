@@ -4,7 +4,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-from betaone_amd import select_wide as SW
+import select_wide_lab as SW
 
 dev = "cuda:0"
 flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev)

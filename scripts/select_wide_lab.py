@@ -1,5 +1,5 @@
 """
-betaone_amd/select_wide.py -- the wide synthetic workload for the PUCT-select kernel's HBM roofline
+scripts/select_wide_lab.py -- LAB (not part of the package): the wide synthetic workload for the PUCT-select kernel's HBM roofline
 (SURVEY.md section 8d): T trees x `nodes` expanded nodes x 32 children, child blocks of 512 B
 (32 records {int32 n, f32 q, f32 prior, int32 child_block}), fixed seed.  Visit counts are
 Zipf-like, Q ~ U(-1,1), priors = normalised Exp(1).  All trees share one random topology (random
@@ -10,7 +10,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from . import engine as E
+from betaone_amd import engine as E
 
 C = 32
 BLOCK_I32 = 4 * C        # 128 int32 = 512 B

@@ -27,7 +27,7 @@ def emu_lib():
     if _emu is None:
         srcs = [os.path.join(ROOT, "betaone_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "betaone_amd", "csrc"))
                 if f.endswith((".h", ".cpp"))] + [os.path.join(EMU_DIR, "wave_emu.h"),
-                                                  os.path.join(ROOT, "include", "betaone_engine.h")]
+                                                  os.path.join(ROOT, "include", "betaone_engine.h"), os.path.join(ROOT, "include", "betaone_lab.h")]
         if not os.path.exists(EMU_LIB) or any(os.path.getmtime(s) > os.path.getmtime(EMU_LIB) for s in srcs):
             subprocess.check_call([os.path.join(EMU_DIR, "build.sh")])
         _emu = E.bind(C.CDLL(EMU_LIB))

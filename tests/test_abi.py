@@ -9,25 +9,30 @@ from betaone_amd import build, engine as E
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "betaone_engine.h")).read()
+def declared_symbols(header="betaone_engine.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(bo_[a-z_0-9]+)\s*\(", src)))
 
 
 def test_header_and_binding_agree():
     assert declared_symbols() == sorted(E._SYMBOLS)
+    assert declared_symbols("betaone_lab.h") == sorted(E._LAB_SYMBOLS)
+    # the boundary does not lean on the lab header: no lab or debug entry point is declared in it, and it includes nothing of ours
+    engine_h = open(os.path.join(ROOT, "include", "betaone_engine.h")).read()
+    assert not re.search(r"bo_debug_|bo_select_wide|bo_event_pair|_profile\s*\(|betaone_lab", re.sub(r"/\*.*?\*/", "", engine_h, flags=re.S))
 
 
 def test_hip_library_builds_loads_and_exports_the_abi():
     lib_path = build.build()
     lib = C.CDLL(lib_path)
-    for name in declared_symbols():
+    for name in declared_symbols() + declared_symbols("betaone_lab.h"):
         assert hasattr(lib, name), name
     E.bind(lib)
     header = open(os.path.join(ROOT, "include", "betaone_engine.h")).read()
     assert lib.bo_abi_version() == E.ABI_VERSION == int(re.search(r"#define BO_ABI_VERSION (\d+)", header).group(1))
-    assert E.PROF_SLOTS == int(re.search(r"#define BO_PROF_SLOTS (\d+)", header).group(1))
+    lab_header = open(os.path.join(ROOT, "include", "betaone_lab.h")).read()
+    assert E.PROF_SLOTS == int(re.search(r"#define BO_PROF_SLOTS (\d+)", lab_header).group(1))
 
 
 def test_product_loader_has_no_fallback(monkeypatch, tmp_path):

@@ -43,7 +43,9 @@ def test_many_games_in_lockstep_match_oracle(backend):
 
 def test_select_wide_matches_numpy_reference(backend):
     import torch
-    from betaone_amd import select_wide as SW
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import select_wide_lab as SW
 
     w = SW.build(96, nodes=60, seed=3, device="cuda:0", n_max=500)
     leaf, levels = SW.run(w, max_depth=64)
