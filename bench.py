@@ -94,6 +94,9 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 path on one GPU")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with WORLD_SIZE=1")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--long-run-steps", type=int, default=None,
+                    help="plies of the confirmation leg run AFTER the timed steps (same workload, same timing brackets; reported as long_run); "
+                         "default 1000 at N=1 with the default workload, 0 elsewhere")
     args = ap.parse_args()
     # --fast is priced on its own workload: enough resident games for the select + backup kernel to be
     # bandwidth-bound (a descent is a chain of dependent reads), a small fp16 net so that the evaluate stage does not starve it
@@ -110,6 +113,9 @@ def parse():
         args.steps, args.warmup = 1, 0  # (a ply of 32768 games x 800 simulations is 26 M evaluations: ~12 s)
     if args.fast and args.opening_steps == 20:
         args.opening_steps = 0          # (the opening-only extra would be twenty such plies)
+    if args.long_run_steps is None:     # ~3 s of the default workload; off for other workloads, N > 1 and with measurement switches off
+        default_workload = (not args.fast and args.gpus == 1 and (args.games, args.sims, args.net, args.net_dtype) == (256, 800, "10x128", "fp32"))
+        args.long_run_steps = 1000 if (default_workload and args.preroll > 0 and not args.no_roofline) else 0
     return args
 
 
@@ -473,6 +479,27 @@ def cpu_baseline(args):
                       f"duplicate rows per batch and runs the rules in Python); single_game_all_threads = 1 game, net on {cores} threads"}
 
 
+def comm_census(dist, args, device, rank, world):
+    """Did the process group the record exchange runs on really form over `world` ranks on `world` different GPUs?  One all-reduce of
+    ones and one all-gather of (host, device index, device UUID / PCI bus id) over that group, before the timed region -- the N > 1
+    line then answers "did RCCL see N ranks?" by itself; the gloo rehearsal runs the same code."""
+    import socket
+
+    rdev = device if args.dist_backend == "nccl" else torch.device("cpu")
+    one = torch.ones(1, dtype=torch.float64, device=rdev)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    prop = torch.cuda.get_device_properties(device)
+    ident = str(getattr(prop, "uuid", "")) or f"pci:{getattr(prop, 'pci_bus_id', '?')}:{getattr(prop, 'pci_device_id', '?')}"
+    mine = (socket.gethostname(), int(device.index or 0), ident)
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    distinct = len({(h, u) for h, _, u in every})
+    return {"backend": dist.get_backend(), "world_size": world, "world_size_seen": int(round(float(one.item()))),
+            "ranks_on_distinct_devices": distinct == world, "distinct_devices": distinct,
+            "devices": [{"rank": r, "host": h, "device_index": i, "device_id": u} for r, (h, i, u) in enumerate(every)],
+            "collectives_used_for_this_check": ["all_reduce(SUM) of ones", "all_gather_object"]}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` (N > 1, not under torchrun): start the N ranks as a child torch.distributed.run job -- before
     this process has touched a GPU -- and exit with its code; rank 0 of the child prints the JSON line."""
@@ -550,6 +577,11 @@ def main():
               "use --dist-backend gloo for the one-GPU rehearsal of the N>1 path", file=sys.stderr)
         sys.exit(2)
     env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and not args.share_gpu and torch.cuda.device_count() < args.gpus:
+        # (device_count() does not initialise the GPU: this is decided before any rank touches one)
+        print(f"bench.py: --gpus {args.gpus} but this node has {torch.cuda.device_count()} GPU(s); one rank per GPU "
+              "(--share-gpu --dist-backend gloo rehearses the N>1 path on one GPU)", file=sys.stderr)
+        sys.exit(2)
     if args.gpus > 1 and env_world is None:
         sys.exit(self_launch(args))
     world = int(env_world or "1")
@@ -573,6 +605,7 @@ def main():
             dist.init_process_group("gloo")
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
+    comm = comm_census(dist, args, device, rank, world) if dist is not None else None
 
     from betaone_amd import engine as E
     from betaone_amd import records
@@ -675,6 +708,26 @@ def main():
                   file=sys.stderr, flush=True)
     host_frac = (ro.host_seconds - h0) / dt
 
+    # Confirmation leg: the headline above is K = 20 plies from a drained pipeline (it pays the fill and the
+    # drain, and a 60 ms window is over before a 5-second utilisation sampler looks); here the same workload goes on for `long_run_steps`
+    # more plies under the same brackets.  Reported beside the headline, never instead of it.
+    long_run = None
+    if args.long_run_steps > 0 and dist is None:
+        s1, p1, n1 = ro.n_sims, ro.n_plies, drv.n_finished
+        gc.disable()
+        torch.cuda.synchronize(device)
+        tl = time.perf_counter()
+        for _ in range(args.long_run_steps):
+            drv.step()
+        torch.cuda.synchronize(device)
+        dl = time.perf_counter() - tl
+        gc.enable()
+        ro.eng.check_status()
+        long_run = {"steps": args.long_run_steps, "ms_per_step": round(dl / args.long_run_steps * 1e3, 3), "nodes_per_sec": round((ro.n_sims - s1) / dl, 1),
+                    "seconds": round(dl, 3), "games_finished": int(drv.n_finished - n1),
+                    "games_per_hour": round((drv.n_finished - n1) * 3600.0 / dl, 1), "plies_per_sec": round((ro.n_plies - p1) / dl, 2),
+                    "note": "same workload and brackets as the headline, continued from its end state; the headline stays the K-step window"}
+
     if hasattr(ro, "drain"):
         ro.drain()  # (cohorts: the plies still outstanding after the timed steps are ended; nothing new is begun)
     opening = None
@@ -745,8 +798,12 @@ def main():
             "untimed_setup_seconds": round(t_pre, 2),
             "host_fraction": round(host_frac, 4),
         }
+        if long_run:
+            out["long_run"] = long_run
         if opening:
             out["opening_phase"] = opening
+        if comm is not None:
+            out["rccl" if args.dist_backend == "nccl" else "process_group"] = comm
         if exchange is not None:
             out["record_exchange"] = {"size_gathers": exchange.n_size_gathers, "payload_gathers": exchange.n_payload_gathers,
                                       "ticks_that_blocked": exchange.blocked_ticks, "ticks_that_blocked_all_ranks": blocked_all,

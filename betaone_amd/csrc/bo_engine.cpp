@@ -77,6 +77,17 @@ struct bo_engine {
     std::vector<int> lazy_want;
     bool begin_lazy = false, ev_begin_made = false;
     rt_event ev_begin{};
+    // bo_selfplay_autoturn: the turn on the device.  In: the choice() uniforms and per-game flags (pinned, read by the kernel itself), the
+    // temperature table; out (behind the five info rows, one bo_k_ship): action | state | compact result [G][8]
+    double *h_turn_u = nullptr;
+    int *h_turn_flags = nullptr;
+    double *d_turn_pw = nullptr;
+    std::vector<double> turn_pw_host;
+    double turn_pw_tfinal = 0.0;  // the T_final the table was built for (0: none yet)
+    int *d_turn_action = nullptr, *d_turn_state = nullptr, *d_turn_cres = nullptr;
+    std::vector<int> turn_want;
+    bool turn_outstanding = false, ev_turn_made = false;
+    rt_event ev_turn{};
     template <class T> int alloc(T **p, size_t n) {
         void *v = nullptr;
         int rc = rt_malloc(&v, n * sizeof(T));
@@ -236,19 +247,22 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
                      &d.trk_n, &d.n_hist, &d.ctx_mode, &d.root_nch, &d.stat_evals,
                      &d.stat_flushes, &d.stat_term_sims, &d.stat_levels, &d.stat_children_scanned, &e->d_go, &e->d_action};
     for (int **p : iscal) rc |= e->alloc(p, G);
-    const size_t res_ints = G * (4 + 2 * (size_t)BO_RES_CAP) + 4, info_ints = G * 5;  // (+ 4: the watched status word, bo_engine_watch)
+    const size_t res_ints = G * (4 + 2 * (size_t)BO_RES_CAP) + 4, info_ints = G * 15;  // (+ 4: the watched status word, bo_engine_watch; info rows 5..14: bo_selfplay_autoturn's outputs)
     rc |= e->alloc(&e->d_res_blk, res_ints); rc |= e->alloc(&e->d_info_blk, info_ints);
     if (!rc) {
         d.res_n = e->d_res_blk; d.res_best_idx = e->d_res_blk + G; d.res_best_mv = e->d_res_blk + 2 * G; d.res_total = e->d_res_blk + 3 * G;
         d.res_idx = e->d_res_blk + 4 * G; d.res_val = reinterpret_cast<float *>(e->d_res_blk + 4 * G + G * BO_RES_CAP);
-        d.res_watch = e->d_res_blk + G * (4 + 2 * (size_t)BO_RES_CAP); d.watch = nullptr;
+        d.res_watch = e->d_res_blk + G * (4 + 2 * (size_t)BO_RES_CAP); d.watch = nullptr; d.watch_n = 1;
         d.phase = e->d_info_blk; d.req_node = e->d_info_blk + G; d.root_nlegal = e->d_info_blk + 2 * G; d.root_term = e->d_info_blk + 3 * G;
         d.ply = e->d_info_blk + 4 * G;
+        e->d_turn_action = e->d_info_blk + 5 * G; e->d_turn_state = e->d_info_blk + 6 * G; e->d_turn_cres = e->d_info_blk + 7 * G;
         rt_memset(e->d_res_blk, 0, res_ints * 4, nullptr); rt_memset(e->d_info_blk, 0, info_ints * 4, nullptr);
     }
     rc |= rt_host_alloc((void **)&e->h_res, res_ints * 4); rc |= rt_host_alloc((void **)&e->h_info, info_ints * 4);
     rc |= rt_host_alloc((void **)&e->h_noise, G * BO_MAX_MOVES * sizeof(double)); rc |= rt_host_alloc((void **)&e->h_go, G * 4);
     rc |= rt_host_alloc((void **)&e->h_action, 2 * G * 4);
+    rc |= rt_host_alloc((void **)&e->h_turn_u, G * sizeof(double)); rc |= rt_host_alloc((void **)&e->h_turn_flags, G * 4);
+    rc |= e->alloc(&e->d_turn_pw, (size_t)cfg->num_simulations + 1);
     { const char *v = getenv("BETAONE_TURN_COPIES"); e->ship = !(v && v[0] == '1'); }
     rc |= e->alloc(&d.gpos, G * c.PLY_CAP); rc |= e->alloc(&d.trk, G * c.TRK_CAP); rc |= e->alloc(&d.trk_cnt, G * c.TRK_CAP);
     rc |= e->alloc(&d.hist, G * 7);
@@ -328,6 +342,8 @@ extern "C" void bo_engine_destroy(bo_engine *e) {
     rt_set_device(e->device);
     for (void *p : e->allocs) rt_free(p);
     rt_host_free(e->h_res); rt_host_free(e->h_info); rt_host_free(e->h_noise); rt_host_free(e->h_go); rt_host_free(e->h_action);
+    rt_host_free(e->h_turn_u); rt_host_free(e->h_turn_flags);
+    if (e->ev_turn_made) rt_event_destroy(e->ev_turn);
     if (e->setup_dev) rt_free(e->setup_dev);
     if (e->setup_host) rt_host_free(e->setup_host);
     if (e->ev_begin_made) rt_event_destroy(e->ev_begin);
@@ -627,9 +643,12 @@ static int result_unpack(bo_engine *e, int32_t *res_n, int32_t *res_idx, float *
 
 // A device status word of the evaluate stage (the split-precision tower's "an activation left the fp16 range", bo_nn_tower_word)
 // rides along with every fetched result block: the ply's one host round trip checks it, no copy or wait of its own.
-extern "C" int bo_engine_watch(bo_engine *e, int32_t *dev_word) {
-    if (!e) return fail(BO_E_ARG, "null engine");
-    e->d.watch = dev_word;
+extern "C" int bo_engine_watch(bo_engine *e, int32_t *dev_word) { return bo_engine_watch_words(e, dev_word, 1); }
+// n_words = 2: the two words of bo_nn_b1_word ([timeout code | saturation flag]); the copy is word 0 | (word 1 != 0) << 16
+extern "C" int bo_engine_watch_words(bo_engine *e, int32_t *dev_words, int32_t n_words) {
+    if (!e || n_words < 1 || n_words > 2) return fail(BO_E_ARG, "bad arguments");
+    e->d.watch = dev_words;
+    e->d.watch_n = n_words;
     return BO_OK;
 }
 // OR of the watched word over every result block fetched since the last call with clear != 0 (host state; nothing is enqueued)
@@ -913,6 +932,7 @@ extern "C" int bo_selfplay_turn(bo_engine *e, const int32_t *active, const int32
     if (prefetched && !poll_first) return fail(BO_E_ARG, "bo_selfplay_turn: flag 8 (result block prefetched) goes with flag 2");
     if (lazy_begin && !defer_noise) return fail(BO_E_ARG, "bo_selfplay_turn: flag 4 (begin without waiting) needs flag 1 (noise later)");
     if (e->begin_lazy) return fail(BO_E_STATE, "bo_selfplay_begun has not collected the previous turn's roots yet");
+    if (e->turn_outstanding) return fail(BO_E_STATE, "bo_selfplay_autoturn_collect has not collected the device's turn yet");
     int rc;
     if (poll_first) {
         // "are all searches finished?" and their results in ONE round trip: the result kernel runs behind the last expected
@@ -938,6 +958,118 @@ extern "C" int bo_selfplay_turn(bo_engine *e, const int32_t *active, const int32
                     : selfplay_begin_impl(e, want_next, nn_in_dev, n_legal_out, terminal_out, go_out, defer_noise != 0, stream);
     if (rc) return rc;
     *completed = lazy_begin ? 2 : 1;
+    return BO_OK;
+}
+
+// ---- the turn on the device (ABI 5) ------------------------------------------------------------------------------------------
+// bo_selfplay_turn's work without the host in the device's way: the random draw of every move is made AHEAD (per game the stream order
+// stays Dirichlet of this search -> choice of this move -> Dirichlet of the next search), the kernels bo_k_turn_sample / bo_k_turn_play are
+// enqueued behind the searches' last expected step, and their outputs travel to pinned memory behind them.  Nothing here waits.
+extern "C" int bo_selfplay_autoturn(bo_engine *e, const int32_t *active, const int32_t *move_number, int32_t threshold, double t_initial,
+                                    double t_final, const int32_t *want_next, float *nn_in_dev, int32_t redo, void *stream) {
+    if (!e || !active || !move_number || !want_next || !nn_in_dev) return fail(BO_E_ARG, "null argument");
+    if (e->fast || e->d.c.root_m != 1 || e->d.c.S < 1)
+        return fail(BO_E_CONFIG, "bo_selfplay_autoturn: reference-semantics engines whose root keeps <= 2 children (int(WIDEN_COEFF) == 1, NUM_SIMULATIONS >= 1)");
+    if (!(fabs(t_initial - 1.0) < 1e-6) || t_final == 0.0 || !(t_final > 0.0))
+        return fail(BO_E_CONFIG, "bo_selfplay_autoturn: TEMPERATURE_INITIAL must be 1 and TEMPERATURE_FINAL > 0 (other settings: bo_selfplay_turn)");
+    if (!e->ship) return fail(BO_E_CONFIG, "bo_selfplay_autoturn is not available with BETAONE_TURN_COPIES=1");
+    if (e->begin_lazy) return fail(BO_E_STATE, "bo_selfplay_begun has not collected the previous turn's roots yet");
+    if (e->turn_outstanding) return fail(BO_E_STATE, "bo_selfplay_autoturn: the previous turn has not been collected");
+    const int G = e->d.c.G, S = e->d.c.S;
+    if (e->turn_pw_tfinal != t_final) {  // apply_temperature's np.power (self_play.py:37) for every possible pi entry f32(c / S): the host's libm, once
+        e->turn_pw_host.resize((size_t)S + 1);
+        for (int c = 0; c <= S; c++) {
+            const float p = (float)((double)c / (double)S);  // mcts.py:273
+            double x = pow((double)p, 1.0 / t_final);
+            if (!isfinite(x)) x = 0.0;
+            e->turn_pw_host[c] = x;
+        }
+        RT(rt_h2d(e->d_turn_pw, e->turn_pw_host.data(), ((size_t)S + 1) * sizeof(double), stream));
+        RT(rt_sync(stream));  // (once per temperature: the staging vector may be rebuilt by the next change)
+        e->turn_pw_tfinal = t_final;
+    }
+    if (!redo) {
+        for (int g = 0; g < G; g++) {
+            const double temp = move_number[g] < threshold ? t_initial : t_final;
+            int fl = (active[g] ? 1 : 0) | (want_next[g] ? 4 : 0);
+            if (active[g] && !(fabs(temp - 1.0) < 1e-6)) fl |= 2;
+            e->h_turn_flags[g] = fl;
+            if (active[g]) e->h_turn_u[g] = hr_double(&e->rng[g]);  // RandomState.choice's random_sample() (self_play.py:73)
+        }
+        e->turn_want.assign(want_next, want_next + G);
+    }
+    TurnArgs a;
+    a.u = e->h_turn_u; a.flags = e->h_turn_flags; a.pw = e->d_turn_pw;
+    a.action = e->d_turn_action; a.state = e->d_turn_state; a.cres = e->d_turn_cres;
+    e->prefetch_valid = false;
+    e->nl_valid = false;
+    RT(RT_LAUNCH(bo_k_turn_sample, G, stream, e->d, a));
+    RT(RT_LAUNCH(bo_k_turn_play, G, stream, e->d, a, nn_in_dev));
+    const size_t Gs = (size_t)G, watch_off = Gs * (4 + 2 * (size_t)BO_RES_CAP);
+    int rc = ship(e, e->h_info + 2 * Gs, (const int *)e->d_info_blk + 2 * Gs, 13 * Gs, e->h_res + watch_off, (const int *)e->d_res_blk + watch_off, 4, stream);
+    if (rc) return rc;
+    if (!e->ev_turn_made) { RT(rt_event_create(&e->ev_turn)); e->ev_turn_made = true; }
+    RT(rt_event_record(e->ev_turn, stream));
+    rc = bo_step(e, nullptr, nullptr, BO_POLICY_NONE, nn_in_dev, stream);  // the begun searches' first step (a no-op for every game if the turn did not happen)
+    if (rc) return rc;
+    e->turn_outstanding = true;
+    return BO_OK;
+}
+
+// 1: the event behind the turn's outputs has been reached (bo_selfplay_autoturn_collect will not wait), 0: not yet
+extern "C" int bo_selfplay_autoturn_ready(bo_engine *e, int32_t *ready_out) {
+    if (!e || !ready_out) return fail(BO_E_ARG, "null argument");
+    if (!e->turn_outstanding) return fail(BO_E_STATE, "no bo_selfplay_autoturn outstanding");
+#if defined(BO_WAVE_EMU)
+    *ready_out = 1;
+#else
+    const hipError_t q = hipEventQuery(e->ev_turn);
+    if (q != hipSuccess && q != hipErrorNotReady) return fail(BO_E_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+    *ready_out = q == hipSuccess ? 1 : 0;
+#endif
+    return BO_OK;
+}
+
+extern "C" int bo_selfplay_autoturn_collect(bo_engine *e, int32_t *res_n, int32_t *res_idx, float *res_val, int32_t *best_idx, int32_t *action_out,
+                                            int32_t *n_legal_out, int32_t *terminal_out, int32_t *go_out, int32_t *completed) {
+    if (!e || !res_n || !res_idx || !res_val || !action_out || !completed) return fail(BO_E_ARG, "null argument");
+    if (!e->turn_outstanding) return fail(BO_E_STATE, "no bo_selfplay_autoturn outstanding");
+    RT(rt_event_sync(e->ev_turn));
+    e->turn_outstanding = false;
+    *completed = 0;
+    const int G = e->d.c.G;
+    const size_t Gs = (size_t)G;
+    const int *act = e->h_info + 5 * Gs, *st = e->h_info + 6 * Gs, *cres = e->h_info + 7 * Gs;
+    e->watch_seen |= e->h_res[Gs * (4 + 2 * (size_t)BO_RES_CAP)];
+    bool running = false;
+    for (int g = 0; g < G; g++) {
+        if (st[g] == 2) return fail(BO_E_STATE, "bo_selfplay_autoturn: a search result the device sampler does not cover (slot " + std::to_string(g) + ")");
+        running = running || st[g] == 1 || st[g] == 3;  // (3: the watched fault word was set -- bo_engine_watch_seen says so; nothing was played)
+    }
+    if (running) { *completed = -1; return BO_OK; }  // nothing was played: bo_step once more, then bo_selfplay_autoturn(redo = 1)
+    const double alpha = e->cfg.dirichlet_alpha;
+    if ((int)e->noise_pending.size() != G) e->noise_pending.assign(G, 0);
+    for (int g = 0; g < G; g++) {
+        const int *c = cres + (size_t)g * 8;
+        action_out[g] = act[g];
+        if (e->h_turn_flags[g] & 1) {
+            res_n[g] = c[0];
+            if (best_idx) best_idx[g] = c[1];
+            res_idx[(size_t)g * BO_RES_CAP] = c[4]; res_idx[(size_t)g * BO_RES_CAP + 1] = c[5];
+            memcpy(&res_val[(size_t)g * BO_RES_CAP], &c[6], 4); memcpy(&res_val[(size_t)g * BO_RES_CAP + 1], &c[7], 4);
+        } else res_n[g] = 0;
+        e->h_nl[g] = e->h_info[2 * Gs + g];
+        e->h_term[g] = e->h_info[3 * Gs + g];
+        const int go = e->turn_want[g] && e->h_term[g] == 0;
+        e->h_go[g] = go;
+        if (e->turn_want[g]) e->noise_pending[g] = 0;
+        if (go && alpha > 0) e->noise_pending[g] = 1;
+        if (n_legal_out) n_legal_out[g] = e->h_nl[g];
+        if (terminal_out) terminal_out[g] = e->h_term[g];
+        if (go_out) go_out[g] = go;
+    }
+    e->nl_valid = true;
+    *completed = 1;
     return BO_OK;
 }
 
@@ -1767,6 +1899,19 @@ extern "C" int bo_nn_b1_status(bo_b1 *t, int32_t *code_out, void *stream) {
         RT((int)hipMemsetAsync(t->sync, 0, t->sync_bytes, (hipStream_t)stream));
         RT(rt_sync(stream));
     }
+    return BO_OK;
+#endif
+}
+
+// Device address of the handle's two status words [timeout code | saturation flag], for bo_engine_watch_words(.., 2): a search or
+// a self-play ply then learns of a hand-off that gave up (or a saturated activation) with the result block it fetches anyway.
+extern "C" int bo_nn_b1_word(bo_b1 *t, void **dev_words_out) {
+#if defined(BO_WAVE_EMU)
+    (void)t; (void)dev_words_out;
+    return fail(BO_E_CONFIG, "bo_nn_b1 is a gfx950-only kernel");
+#else
+    if (!t || !dev_words_out) return fail(BO_E_ARG, "bad arguments");
+    *dev_words_out = t->sync + 2 * t->max_batch;
     return BO_OK;
 #endif
 }

@@ -1295,7 +1295,7 @@ BO_KERNEL void bo_k_fw_reroot(Eng e, FastW f, int reuse) {
 // pi over ALL legal root moves = child visits / total; best = first maximum in legal-move order
 BO_KERNEL void bo_k_fw_result(Eng e, FastW f) {
     const int g = bo_block(), lane = bo_lane();
-    if (g == 0 && lane == 0) e.res_watch[0] = e.watch ? *e.watch : 0;
+    if (g == 0 && lane == 0) e.res_watch[0] = e.watch ? (e.watch[0] | (e.watch_n > 1 && e.watch[1] ? 0x10000 : 0)) : 0;
     if (e.phase[g] != PH_DONE) return;
     const WRec *A = fw_arena(f, g);
     const int link = A[0].link, n = e.root_nlegal[g];

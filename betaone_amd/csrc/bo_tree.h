@@ -85,6 +85,7 @@ struct Eng {
     // search results
     int *res_n, *res_idx, *res_best_idx, *res_best_mv, *res_total;
     float *res_val;
+    int watch_n;                      // words at `watch` that are OR-ed into the copy (1, or 2: bo_nn_b1_word's [timeout code | saturation flag])
     int *watch, *res_watch;           // bo_engine_watch: a device status word of the evaluate stage (NULL: none); the result kernels copy it behind
                                       // the result block, so the ply's one host round trip brings it along
     int *played_now;                  // [G] or NULL: bo_k_play notes the move it played (0: refused) -- read by the fast mode's re-rooting
@@ -992,7 +993,7 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
 
 // Prepare the root of game g's next search from the top of its position stack: reset the tree,
 // generate the root's ordered legal moves, evaluate is_game_over(claim_draw=True).
-BO_DEV void root_prepare(const Eng &e, int g, StepShared &sh) {
+BO_DEV int root_prepare(const Eng &e, int g, StepShared &sh) {  // returns the root's terminal code (every lane)
     const size_t no = NOFF(e, g);
     const int lane = bo_lane();
     const int ply = e.ply[g];
@@ -1019,6 +1020,7 @@ BO_DEV void root_prepare(const Eng &e, int g, StepShared &sh) {
     }
     if (lane == 0) { e.root_nlegal[g] = n; e.req_nlegal[g] = n; e.root_term[g] = t; e.term[no] = (signed char)t; }
     bo_sync();
+    return t;
 }
 
 // (re)build game stacks: start position + moves; computes key fields; prepares the first root.
@@ -1124,9 +1126,9 @@ BO_KERNEL void bo_k_ship(int *dst_a, const int *src_a, int n_a, int *dst_b, cons
 }
 
 // pi and best move of a finished search (mcts.py:259-280)
-BO_KERNEL void bo_k_result(Eng e) {
-    const int g = bo_block(), lane = bo_lane();
-    if (g == 0 && lane == 0) e.res_watch[0] = e.watch ? *e.watch : 0;
+BO_DEV void result_body(const Eng &e, int g) {
+    const int lane = bo_lane();
+    if (g == 0 && lane == 0) e.res_watch[0] = e.watch ? (e.watch[0] | (e.watch_n > 1 && e.watch[1] ? 0x10000 : 0)) : 0;
     if (e.phase[g] != PH_DONE) return;
     const size_t no = NOFF(e, g);
     const int nch = e.n_children[no], fc = e.first_child[no], n = e.root_nlegal[g];
@@ -1166,14 +1168,13 @@ BO_KERNEL void bo_k_result(Eng e) {
         }
     }
 }
+BO_KERNEL void bo_k_result(Eng e) { result_body(e, bo_block()); }
 
 // Play the sampled action in every game with action[g] >= 0 (self_play.py:125-184), then prepare
 // the next root.  action -2 = "play res_best_mv".
-BO_KERNEL void bo_k_play(Eng e, const int *action) {
-    BO_SHARED StepShared sh;
-    const int g = bo_block(), lane = bo_lane();
-    const int a = action[g];
-    if (a == -1) return;
+BO_DEV int play_body(const Eng &e, int g, int a, StepShared &sh) {  // returns the new root's terminal code, -1 if the root did not change
+    const int lane = bo_lane();
+    if (a == -1) return -1;
     const int ply = e.ply[g], tn = e.trk_n[g];  // read before lane 0 updates them further down
     DPos *gp = e.gpos + (size_t)g * e.c.PLY_CAP;
     const DPos P = gp[ply];
@@ -1191,9 +1192,9 @@ BO_KERNEL void bo_k_play(Eng e, const int *action) {
     if (e.played_now && lane == 0) e.played_now[g] = 0;
     if (!ok) {  // self_play.py:142-167
         if (best != m && best_ok) m = best;
-        else { if (lane == 0) { e.status[g] |= ST_ILLEGAL_ACTION; e.phase[g] = PH_IDLE; } return; }
+        else { if (lane == 0) { e.status[g] |= ST_ILLEGAL_ACTION; e.phase[g] = PH_IDLE; } return -1; }
     }
-    if (ply + 1 >= e.c.PLY_CAP || tn >= e.c.TRK_CAP) { if (lane == 0) e.status[g] |= ST_PLY_OVERFLOW; return; }
+    if (ply + 1 >= e.c.PLY_CAP || tn >= e.c.TRK_CAP) { if (lane == 0) e.status[g] |= ST_PLY_OVERFLOW; return -1; }
     if (lane == 0) {
         if (e.played_now) e.played_now[g] = m;
         const DPos c = make_move(P, m);
@@ -1205,7 +1206,106 @@ BO_KERNEL void bo_k_play(Eng e, const int *action) {
         e.trk_n[g] = tn + 1;
     }
     bo_sync();
-    root_prepare(e, g, sh);
+    return root_prepare(e, g, sh);
+}
+BO_KERNEL void bo_k_play(Eng e, const int *action) {
+    BO_SHARED StepShared sh;
+    play_body(e, bo_block(), action[bo_block()], sh);
+}
+
+// ---- the ply's turn on the device (bo_selfplay_autoturn; self_play.py:121-184 + the next iteration's mcts.py:160-162) -------------------
+// Result -> temperature sample -> play -> begin the next search, enqueued BEHIND the searches' last step: the device goes from the last
+// tree step of a ply straight into the next ply's root evaluation, no host round trip in between.  What the host still owns is every
+// random draw and every libm call: the uniform np.random.choice would draw for the move (self_play.py:73) is drawn ahead and handed in,
+// and apply_temperature's p ** (1 / T) (self_play.py:37, NumPy -> libm pow) comes from a table the host built with the same libm for
+// every visit count c = 0..S (pi = f32(c / S), mcts.py:273).  Everything else of select_move_with_temperature / RandomState.choice on a pi
+// of <= 2 non-zero entries (E2: the reference's root has <= 2 children) is IEEE binary32 / binary64 arithmetic, restated operation
+// by operation from csrc/bo_hostrng.h: hr_select_action.
+struct TurnArgs {
+    const double *u;      // [G] host memory (pinned, device-mapped): this game's choice() uniform
+    const int *flags;     // [G] host memory: bit 0 the game searched this ply (sample + play), bit 1 its temperature is not 1 (fullmove >= threshold,
+                          //     self_play.py:66): p ** (1 / T) from `pw`, bit 2 a next search is wanted
+    const double *pw;     // [S + 1] device: pow((double)f32(c / S), 1 / T_final)
+    int *action;          // [G] out: the sampled action index, -1 = the game did not search
+    int *state;           // [G] out: 0 ok, 1 the game's search is still running, 2 a pi this sampler does not cover (the host raises), 3 the evaluate
+                          //     stage's watched fault word is set (bo_engine_watch: no move is played from an invalid evaluation; the host raises)
+    int *cres;            // [G][8] out: n, best action index, best move, total visits, index 0, index 1, value 0 bits, value 1 bits (pi order of bo_k_result)
+};
+
+// hr_select_action on (index, visit count) pairs; *ok = false where hr_select_action returns -1 (or the table does not apply)
+BO_DEV int turn_sample(int n, int i0, int c0, int i1, int c1, int total, int S, bool power, const double *pw, double u, bool *ok) {
+    *ok = true;
+    if (n < 1 || n > 2 || total < 1) { *ok = false; return -1; }
+    float p0 = (float)((double)c0 / (double)total), p1 = n == 2 ? (float)((double)c1 / (double)total) : 0.0f;  // mcts.py:273
+    if (n == 2 && i1 < i0) { int t = i0; i0 = i1; i1 = t; float q = p0; p0 = p1; p1 = q; t = c0; c0 = c1; c1 = t; }
+    if (power) {  // apply_temperature, self_play.py:37-45
+        if (total != S) { *ok = false; return -1; }
+        double s0 = pw[c0], s1 = n == 2 ? pw[c1] : 0.0;  // (non-finite powers were zeroed when the table was built)
+        const double sum = s0 + s1;
+        if (!(sum > 1e-9)) { *ok = false; return -1; }
+        p0 = (float)(s0 / sum);
+        p1 = (float)(s1 / sum);
+        const float rs = p0 + p1;
+        if (__builtin_fabsf(rs - 1.0f) > (float)1e-6 && rs > (float)1e-9) { p0 = p0 / rs; p1 = p1 / rs; }
+    }
+    const float prob_sum = p0 + p1;  // self_play.py:68-72
+    if (__builtin_fabsf(prob_sum - 1.0f) > (float)1e-6) {
+        if (prob_sum > (float)1e-9) { p0 = p0 / prob_sum; p1 = p1 / prob_sum; }
+        else { *ok = false; return -1; }
+    }
+    const double d0 = (double)p0, d1 = (double)p1;  // RandomState.choice: cdf = cumsum(double(p)); cdf /= cdf[-1]; searchsorted(u, 'right')
+    if (__builtin_fabs((d0 + d1) - 1.0) > 3.4e-4 || d0 < 0 || d1 < 0) { *ok = false; return -1; }
+    const double k0 = d0, k1 = d0 + d1;
+    const double last = n == 2 ? k1 : k0;
+    if (n == 1) return i0;
+    return (k0 / last > u) ? i0 : i1;
+}
+
+// first kernel of the turn: results of the finished searches + the sampled moves.  No wave changes any game's phase here, so
+// `state` is a consistent picture of "did every search finish?" for the second kernel.
+BO_KERNEL void bo_k_turn_sample(Eng e, TurnArgs a) {
+    const int g = bo_block(), lane = bo_lane();
+    result_body(e, g);
+    const int fl = a.flags[g], ph = e.phase[g];
+    int st = 0, act = -1, n = 0, ia = -1, ib = -1, ca = 0, cb = 0, total = 0;
+    if (e.watch && (e.watch[0] != 0 || (e.watch_n > 1 && e.watch[1] != 0))) st = 3;
+    else if (ph == PH_RUN) st = 1;
+    else if ((fl & 1) && ph == PH_DONE) {
+        const size_t no = NOFF(e, g);
+        const int nch = e.n_children[no], fc = e.first_child[no];
+        const int v = lane < nch ? e.n_visits[no + fc + lane] : 0;
+        const int idx = lane < nch ? move_to_index(e.move[no + fc + lane]) : -1;
+        total = bo_wave_sum(v);
+        const uint64_t nz = bo_ballot(v > 0);
+        n = bo_popc64(nz);
+        if (n >= 1) { const int l0 = bo_lsb64(nz); ia = bo_shfl(idx, l0); ca = bo_shfl(v, l0); }
+        if (n >= 2) { const int l1 = bo_lsb64(nz & (nz - 1)); ib = bo_shfl(idx, l1); cb = bo_shfl(v, l1); }
+        bool ok;
+        act = turn_sample(n, ia, ca, ib, cb, total, e.c.S, (fl & 2) != 0, a.pw, a.u[g], &ok);
+        if (!ok) { st = 2; act = -1; }
+    }
+    if (lane == 0) {
+        a.action[g] = act; a.state[g] = st;
+        int *c = a.cres + (size_t)g * 8;
+        c[0] = n; c[1] = e.res_best_idx[g]; c[2] = e.res_best_mv[g]; c[3] = total; c[4] = ia; c[5] = ib;
+        c[6] = n >= 1 ? __builtin_bit_cast(int, (float)((double)ca / (double)total)) : 0;
+        c[7] = n >= 2 ? __builtin_bit_cast(int, (float)((double)cb / (double)total)) : 0;
+    }
+}
+
+// second kernel: nothing happens unless EVERY search had finished and every pi could be sampled (the host then steps once more / raises:
+// bo_selfplay_autoturn_collect); else bo_k_play + bo_k_search_begin_want in one launch
+BO_KERNEL void bo_k_turn_play(Eng e, TurnArgs a, float *nn_in) {
+    BO_SHARED StepShared sh;
+    const int g = bo_block(), lane = bo_lane();
+    bool bad = false;
+    for (int j0 = 0; j0 < e.c.G; j0 += 64) bad = bad || bo_ballot(j0 + lane < e.c.G && a.state[j0 + lane] != 0) != 0;
+    if (bad) return;
+    int t = play_body(e, g, a.action[g], sh);
+    if (t < 0) t = e.root_term[g];  // (the root did not change in this launch)
+    if (!(a.flags[g] & 4) || t != 0) return;
+    encode_static(e, g, nn_in + (size_t)g * BO_ROW);
+    if (lane == 0) e.phase[g] = PH_RUN;
 }
 
 // Final training encodings of a finished game (self_play.py:200-208): record i uses

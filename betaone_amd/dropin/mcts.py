@@ -143,6 +143,11 @@ class _GraphStep:
                 _evaluate(model, nn_in)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        # the evaluate stage's own fault words (the one-launch tower's hand-off timeout / saturation, the split tower's saturation)
+        # come back with every result block this engine fetches: run_mcts checks them once per search, in the round trip it makes anyway
+        inner = getattr(model, "net", model)
+        words = getattr(inner, "overflow_words", None)
+        eng.watch(*(words() if words is not None else (0, 1)))
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = _evaluate(model, nn_in)
@@ -222,6 +227,11 @@ def run_mcts(root_board, model, history: List, tracker) -> Tuple[object, np.ndar
         last_search.update(simulations=sims_done, stopped=stopped)
         eng.check_status()
         res = eng.result(stream)
+        if graph_step is not None and eng.watch_seen():  # an evaluation of this search was invalid: say which and why instead of returning a move
+            inner = getattr(graph_step.model, "net", graph_step.model)
+            torch.cuda.synchronize(nn_in.device)
+            getattr(inner, "check_overflow", lambda: None)()  # (raises with the reason; re-arms the stage's counters)
+            raise E.EngineError("run_mcts: the evaluate stage reported a fault during this search")
         if res["best_idx"][0] < 0:
             raise ValueError("max() arg is an empty sequence")  # mcts.py:279 on a root without legal moves
         pi = np.zeros(config.NUM_ACTIONS, dtype=np.float32)

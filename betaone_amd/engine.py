@@ -90,6 +90,9 @@ _SYMBOLS = {  # include/betaone_engine.h: the drop-in boundary
     "bo_selfplay_turn": (C.c_int, [C.c_void_p, _I32P, _I32P, C.c_int32, C.c_double, C.c_double, _I32P, _I32P, _F32P, _I32P, _I32P, _I32P,
                                    C.c_void_p, _I32P, _I32P, _I32P, C.c_int32, _I32P, C.c_void_p]),
     "bo_selfplay_noise": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bo_selfplay_autoturn": (C.c_int, [C.c_void_p, _I32P, _I32P, C.c_int32, C.c_double, C.c_double, _I32P, C.c_void_p, C.c_int32, C.c_void_p]),
+    "bo_selfplay_autoturn_ready": (C.c_int, [C.c_void_p, _I32P]),
+    "bo_selfplay_autoturn_collect": (C.c_int, [C.c_void_p, _I32P, _I32P, _F32P, _I32P, _I32P, _I32P, _I32P, _I32P, _I32P]),
     "bo_search_result_prefetch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bo_selfplay_begun": (C.c_int, [C.c_void_p, _I32P, _I32P, _I32P]),
     "bo_selfplay_begin": (C.c_int, [C.c_void_p, _I32P, C.c_void_p, _I32P, _I32P, _I32P, C.c_void_p]),
@@ -107,6 +110,8 @@ _SYMBOLS = {  # include/betaone_engine.h: the drop-in boundary
     "bo_nn_b1_status": (C.c_int, [C.c_void_p, _I32P, C.c_void_p]),
     "bo_nn_b1_destroy": (None, [C.c_void_p]),
     "bo_engine_watch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bo_engine_watch_words": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "bo_nn_b1_word": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "bo_engine_watch_seen": (C.c_int, [C.c_void_p, _I32P, C.c_int32]),
     "bo_engine_status": (C.c_int, [C.c_void_p, _I32P, _I32P, _I32P, _I32P, _I32P, _I32P, C.c_void_p]),
     "bo_movegen_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BoPosition), _I32P, _I32P, _I32P, C.c_void_p]),
@@ -158,7 +163,7 @@ def bind(cdll: C.CDLL) -> C.CDLL:
 
 
 _hip_lib: Optional[C.CDLL] = None
-ABI_VERSION = 4   # BO_ABI_VERSION of include/betaone_engine.h this binding was written against (tests/test_abi.py compares)
+ABI_VERSION = 5   # BO_ABI_VERSION of include/betaone_engine.h this binding was written against (tests/test_abi.py compares)
 PROF_SLOTS = 16   # BO_PROF_SLOTS
 
 
@@ -434,6 +439,34 @@ class Engine:
             return out, LAZY_BEGIN
         return out, ((nl, tm, go) if done.value else None)
 
+    def selfplay_autoturn(self, active, move_number, temperature, want_next, nn_in_ptr: int, stream: int = 0, redo: bool = False) -> None:
+        """The ply's turn enqueued on the device behind the searches (bo_selfplay_autoturn): sample, play, begin the next searches;
+        the moves' uniforms are drawn now.  Nothing waits; autoturn_collect returns what happened."""
+        a, m, w = _i32(active), _i32(move_number), _i32(want_next)
+        th, ti, tf = temperature
+        self._check(self.lib.bo_selfplay_autoturn(self.h, _p(a), _p(m), int(th), float(ti), float(tf), _p(w), nn_in_ptr, 1 if redo else 0, stream))
+
+    def autoturn_supported(self, temperature) -> bool:
+        """The settings bo_selfplay_autoturn covers: the reference's search semantics with a root of <= 2 children, T_initial = 1, T_final > 0."""
+        _, ti, tf = temperature
+        return (not self.fast) and int(self.cfg.widen_coeff) == 1 and self.cfg.num_simulations >= 1 and abs(float(ti) - 1.0) < 1e-6 and float(tf) > 0.0
+
+    def autoturn_ready(self) -> bool:
+        r = C.c_int32(0)
+        self._check(self.lib.bo_selfplay_autoturn_ready(self.h, C.byref(r)))
+        return bool(r.value)
+
+    def autoturn_collect(self, out):
+        """(out, (n_legal, terminal, go)) of the device's turn, or (None, None) if a search was still running when it came up (nothing
+        was played: step once more and enqueue selfplay_autoturn(redo=True))."""
+        nl, tm, go = (np.zeros(self.G, dtype=np.int32) for _ in range(3))
+        done = C.c_int32(0)
+        self._check(self.lib.bo_selfplay_autoturn_collect(self.h, _p(out["n"]), _p(out["idx"]), _p(out["val"], _F32P), _p(out["best_idx"]),
+                                                          _p(out["action"]), _p(nl), _p(tm), _p(go), C.byref(done)))
+        if done.value < 0:
+            return None, None
+        return out, (nl, tm, go)
+
     def selfplay_begin(self, want, nn_in_ptr: int, stream: int = 0):
         w = _i32(want)
         nl, tm, go = (np.zeros(self.G, dtype=np.int32) for _ in range(3))
@@ -506,9 +539,9 @@ class Engine:
         self._check(self.lib.bo_event_pair_overhead(C.byref(ms), samples, stream))
         return ms.value
 
-    def watch(self, dev_word_ptr: int):
-        """Have every fetched result block bring the int32 device word at `dev_word_ptr` along (0: none) -- bo_engine_watch."""
-        self._check(self.lib.bo_engine_watch(self.h, dev_word_ptr or None))
+    def watch(self, dev_word_ptr: int, n_words: int = 1):
+        """Have every fetched result block bring the int32 device word(s) at `dev_word_ptr` along (0: none) -- bo_engine_watch_words."""
+        self._check(self.lib.bo_engine_watch_words(self.h, dev_word_ptr or None, int(n_words)))
 
     def watch_seen(self, clear: bool = True) -> int:
         seen = C.c_int32(0)

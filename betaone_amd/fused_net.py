@@ -523,6 +523,8 @@ class FusedPolicyValueNet(nn.Module):
         outputs were wrong) -- bo_nn_tower_status: the word is read and cleared by one atomic exchange on torch's CURRENT stream,
         which must be the stream the forwards were launched on (it is ordered behind them there).  Synchronises that stream.  The
         self-play loop does not call this per ply: it watches the word through the engine's result block (overflow_word_ptr)."""
+        if self.conv == "tower_b1":  # (its own two status words: a hand-off that gave up, a saturated activation)
+            return self.check_b1()
         t = self.__dict__.get("_tower")
         if not t or self.conv != "tower_split":
             return
@@ -536,9 +538,20 @@ class FusedPolicyValueNet(nn.Module):
     OVERFLOW_MESSAGE = ("tower_split: an activation left the fp16 range (|v| > 65504) and was saturated -- the evaluations of this net are "
                         "wrong on the fp16 matrix pipe; run it with BETAONE_F32_TOWER=fp32 (best_inference_copy(..., f32_pipe=True))")
 
+    def overflow_words(self):
+        """(device address, number of words) of the evaluate stage's own fault words, (0, 1) if it has none: the split-precision tower's
+        saturation word, or the one-launch tower's [hand-off timeout code | saturation flag] (conv='tower_b1': what uci.py's searches
+        and small self-play batches run on).  Rollout and dropin.mcts hand them to bo_engine_watch_words, so every fetched result
+        block brings them along and an invalid evaluation stops the run where it happened."""
+        if self.conv == "tower_b1" and self.__dict__.get("_b1"):
+            p = C.c_void_p()
+            if self.lib.bo_nn_b1_word(self._b1, C.byref(p)):
+                raise E.EngineError(self.lib.bo_last_error().decode())
+            return (p.value or 0), 2
+        return self.overflow_word_ptr(), 1
+
     def overflow_word_ptr(self) -> int:
-        """Device address of the split-precision tower's status word (0 for every other evaluate stage): Rollout hands it to
-        bo_engine_watch, so each ply's result block brings it along and a saturating net stops the run at that ply."""
+        """Device address of the split-precision tower's status word (0 for every other evaluate stage)."""
         t = self.__dict__.get("_tower")
         if not t or self.conv != "tower_split":
             return 0

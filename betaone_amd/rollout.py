@@ -183,6 +183,8 @@ class Rollout:
         self._turn_due = None       # go[G] of a ply whose searches ply_begin enqueued and ply_end has not turned yet
         self._ply_event = None      # recorded behind everything ply_begin enqueued (ply_ready)
         self._prefetched = False    # the result block of the enqueued searches is on its way to pinned host memory (_prefetch_result)
+        self._auto = False          # the due ply's TURN is enqueued on the device behind its searches (_enqueue_autoturn): ply_end only collects it
+        self.device_turn = os.environ.get("BETAONE_DEVICE_TURN", "1") != "0"  # (0: the host samples and plays, for A/B runs)
         self._begun_want = None
         self._active = np.zeros(G, dtype=bool)
         self._plies = np.zeros(G, dtype=np.int64)
@@ -206,12 +208,17 @@ class Rollout:
         result block the engine fetches (bo_engine_watch): checked once per ply by _check_watch, behind the copy the ply waits for
         anyway -- a net that saturates stops the run before a record made from its evaluations is handed out."""
         inner = getattr(self.model, "net", self.model)
-        ptr = getattr(inner, "overflow_word_ptr", None)
+        words = getattr(inner, "overflow_words", None)
         self._watch_msg = getattr(inner, "OVERFLOW_MESSAGE", "the evaluate stage reported a fault")
-        self.eng.watch(ptr() if ptr is not None else 0)
+        ptr, n = words() if words is not None else (0, 1)
+        self.eng.watch(ptr, n)
 
     def _check_watch(self):
         if self.eng.watch_seen():
+            chk = getattr(getattr(self.model, "net", self.model), "check_overflow", None)
+            if chk is not None and self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+                chk()  # (names the fault -- saturation, or which hand-off of the one-launch tower gave up -- and re-arms the stage's counters)
             raise E.EngineError(self._watch_msg)
 
     # ---- evaluate + step -------------------------------------------------------------------------
@@ -488,7 +495,8 @@ class Rollout:
             if self._begun is E.LAZY_BEGIN and not extra.any():
                 lazy = True  # ... without waiting for the device: their roots' state arrives with the first evaluation below
             else:
-                self._fwd_early = False  # (games started in between: their roots are not in the forward enqueued early -- it is repeated)
+                if extra.any():
+                    self._fwd_early = False  # (games started in between: their roots are not in the forward enqueued early -- it is repeated)
                 nl, term, go = eng.selfplay_begun() if self._begun is E.LAZY_BEGIN else self._begun
                 self._begun = None
                 if extra.any():  # games started in between
@@ -508,6 +516,10 @@ class Rollout:
         for g in done:
             self._active[g] = False
         if not go.any():
+            # (no search was begun: a root evaluation enqueued ahead for the begun searches evaluated nothing anyone will use, and no
+            # Dirichlet draw is due -- a later ply must not take that forward for its own roots')
+            self._fwd_early = False
+            self._noise_pending = False
             self._finish_and_refill(done, term, on_finished, refill)
             if while_searching is not None:
                 while_searching()
@@ -525,9 +537,31 @@ class Rollout:
             while_searching()
         if self.ply_profile is not None: self._pp("while_searching")
         self._turn_due = go
-        self._prefetch_result()
+        if self._device_turn_ok():
+            self._enqueue_autoturn(go)
+        else:
+            self._prefetch_result()
         self._mark_enqueued()
         return True
+
+    def _device_turn_ok(self) -> bool:
+        return self.device_turn and self.eng.autoturn_supported(self.temperature)
+
+    def _enqueue_autoturn(self, go: np.ndarray, redo: bool = False) -> None:
+        """The ply's turn -- result, temperature sample, the played move, the next searches' begin (self_play.py:121-184, mcts.py:160-162) --
+        enqueued on the DEVICE behind the searches, and behind it the next roots' evaluation: from a ply's last tree step to the next ply's first
+        tower launch the device waits for nobody.  The host's share (the moves' uniforms now, the new roots' Dirichlet noise in the next
+        ply_begin, while that evaluation runs) keeps every per-game RNG stream in the reference's order."""
+        move_number = self._start_full + (self._plies + self._start_black) // 2   # board.fullmove_number, self_play.py:104
+        want_next = self._active & ((self._plies + go) < self.max_game_moves)     # (finished games' slots have been refilled by now)
+        self._auto_want = want_next
+        self.eng.selfplay_autoturn(go, move_number, self.temperature, want_next.astype(np.int32), self.nn_in.data_ptr(), self._stream(), redo=redo)
+        self._auto = True
+        self._prefetched = False
+        if want_next.any():  # the next searches' root evaluation (its noise is drawn and uploaded meanwhile, by the next ply_begin)
+            self.n_forward += 1
+            self._forward_only()
+            self._fwd_early = True
 
     PREFETCH_RESULT = os.environ.get("BETAONE_RESULT_PREFETCH", "1") != "0"  # (0: the turn fetches the result block itself, for A/B runs)
 
@@ -547,6 +581,8 @@ class Rollout:
 
     def ply_ready(self) -> bool:
         """A ply is due and the device has finished everything ply_begin enqueued for it (never blocks): ply_end will not wait."""
+        if self._turn_due is not None and self._auto:
+            return self.eng.autoturn_ready()  # (the event right behind the turn's outputs, not behind the next root evaluation)
         return self._turn_due is not None and (self._ply_event is None or self._ply_event.query())
 
     @_on_main
@@ -565,7 +601,23 @@ class Rollout:
         self.host_seconds += time.perf_counter() - t0
         # one native call: sample the moves, play them, begin the next searches (root info, Dirichlet noise, root planes)
         # (fast mode mixes the noise into a kept root's priors when the search begins, so its draws cannot be deferred)
-        while True:  # one native call per ply: "all searches finished?" + sample + play + begin the next searches
+        out = None
+        if self._auto:  # the device made the turn itself: collect what it played and began (the ply's one wait, off the device's path)
+            want_next = self._auto_want  # (as the enqueued turn was told)
+            while True:
+                out, begun = eng.autoturn_collect(self._out)
+                if out is not None:
+                    self._auto = False
+                    break
+                self._fwd_early = False
+                self._check_watch()  # (the turn also holds still when the evaluate stage's fault word is set: raise, play nothing)
+                self._eval_and_step()  # a search needed one more evaluation than expected: nothing was played; step, then the same turn again
+                self._enqueue_autoturn(go, redo=True)
+                if not block:
+                    self._turn_due = go
+                    self._mark_enqueued()
+                    return None
+        while out is None:  # one native call per ply: "all searches finished?" + sample + play + begin the next searches
             out, begun = eng.selfplay_turn(go, move_number, self.temperature, self._out, want_next.astype(np.int32), self.nn_in.data_ptr(), stream,
                                            defer_noise=not self.fast, poll_first=True, lazy_begin=not self.fast, prefetched=self._prefetched)
             self._prefetched = False
@@ -892,8 +944,8 @@ class CohortRollout:
                     self._rr = (self._rr + i + 1) % max(1, len(cands))
                     return k
             spins += 1
-            if spins > 64:
-                time.sleep(0)  # (let the side threads -- record exchange, model watcher -- have the interpreter)
+            if spins > 64:  # nothing is due for a while (a cohort-ply takes ~3 ms): leave the core to the side threads (record exchange,
+                time.sleep(20e-6)  # model watcher) and to the other ranks of the node instead of spinning on event queries
 
     def drain(self) -> int:
         """End every outstanding ply (no new searches are enqueued): the state then is what a sequence of whole plies leaves."""
@@ -910,7 +962,14 @@ class CohortRollout:
         self.parts[k].retire(g % self.Gc, fin_cb, refill_cb)
 
     def swap_model(self, model) -> None:
+        """Rollout.swap_model for every cohort.  Every cohort has a whole ply enqueued on its own stream (graph replays that hold the old
+        module's kernels and weight addresses, the next root evaluation): those plies are ENDED first -- played with the old weights, like a
+        single Rollout's last ply before the swap -- so nothing of the old graphs is in flight when they are released; every search begun
+        after this call evaluates with `model`."""
         models = list(model) if isinstance(model, (list, tuple)) else [model] * self.K
+        self.drain()
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
         for p, m in zip(self.parts, models):
             p.swap_model(m)
 

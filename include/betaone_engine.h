@@ -28,7 +28,7 @@ extern "C" {
  * [G][BO_PROF_SLOTS = 16] counters, the BO_TOWER_WINOGRAD packed-weight K order for 128 filters is winograd_k_order's;
  * 3: fast-mode arenas are allocated in 128-byte granules of 8 records, bo_fast_stats counts granules).  A caller checks
  * bo_abi_version() == BO_ABI_VERSION before anything else (tests/c_abi_smoke.c). */
-#define BO_ABI_VERSION 4
+#define BO_ABI_VERSION 5
 #define BO_NUM_ACTIONS 4672          /* config.NUM_ACTIONS, config.py:29 */
 #define BO_INPUT_CHANNELS 120        /* config.INPUT_CHANNELS, config.py:28 */
 #define BO_ROW_FLOATS (120 * 64)
@@ -195,6 +195,30 @@ int bo_selfplay_begun(bo_engine *e, int32_t *n_legal_out, int32_t *terminal_out,
 int bo_search_result_prefetch(bo_engine *e, void *stream);
 int bo_selfplay_noise(bo_engine *e, void *stream);
 
+/* (ABI 5) The turn of a ply ON THE DEVICE: bo_selfplay_turn's work -- result, select_move_with_temperature (self_play.py:59-80), the
+ * played move (self_play.py:125-184) and the begin of the next searches (mcts.py:160-162) -- enqueued on `stream` BEHIND the searches'
+ * last expected bo_step, so that the device goes from a ply's last tree step straight into the next ply's root evaluation; the host
+ * is not waited for.  What stays on the host is every random draw and every libm call: per game with active[g] != 0 this call draws the
+ * uniform np.random.choice would draw for the move (self_play.py:73) from the slot's stream NOW (the stream order per game is unchanged:
+ * Dirichlet of this search, choice of this move, Dirichlet of the next search) and hands it to the kernel; apply_temperature's
+ * p ** (1 / T) comes from a table built here with the host's pow for every visit count 0..NUM_SIMULATIONS.  The rest of the sampling is
+ * IEEE arithmetic restated on the device for a pi of <= 2 non-zero entries (the reference's root keeps <= 2 children).
+ * Needs a reference-semantics engine with int(WIDEN_COEFF) == 1, t_initial == 1, t_final > 0 (BO_E_CONFIG otherwise: use
+ * bo_selfplay_turn).  redo != 0: enqueue the same turn again with the draws already made (after *completed == -1 below).
+ * Order per ply: [bo_selfplay_noise -> bo_step x n] -> bo_selfplay_autoturn -> enqueue the next root evaluation's network forward ->
+ * bo_selfplay_autoturn_collect -> bo_selfplay_noise -> bo_step ...  Asynchronous. */
+int bo_selfplay_autoturn(bo_engine *e, const int32_t *active, const int32_t *move_number, int32_t threshold, double t_initial,
+                         double t_final, const int32_t *want_next, float *nn_in_dev, int32_t redo, void *stream);
+/* *ready_out = 1 once the device has passed the turn's outputs (bo_selfplay_autoturn_collect will not wait), else 0.  Never blocks. */
+int bo_selfplay_autoturn_ready(bo_engine *e, int32_t *ready_out);
+/* Wait for the turn's outputs (not for work enqueued behind them) and return them: the sparse pi of every game that searched (res_n,
+ * res_idx / res_val rows of BO_RES_CAP like bo_search_result; <= 2 entries), best_idx (may be NULL), the action played (-1: none), and --
+ * as bo_selfplay_begin reports them -- the new roots' legal-move counts, terminal codes and go flags (any may be NULL).
+ * *completed = 1: done; -1: some search was still running when the turn came up -- NOTHING was played or begun: issue one more
+ * evaluation + bo_step, then bo_selfplay_autoturn(redo = 1).  A result the device sampler does not cover is BO_E_STATE. */
+int bo_selfplay_autoturn_collect(bo_engine *e, int32_t *res_n, int32_t *res_idx, float *res_val, int32_t *best_idx, int32_t *action_out,
+                                 int32_t *n_legal_out, int32_t *terminal_out, int32_t *go_out, int32_t *completed);
+
 /* ---- records ------------------------------------------------------------------------------------
  * The game in `slot` as plain data: its positions[0..n_plies] and moves[0..n_plies). */
 int bo_game_export(bo_engine *e, int slot, bo_position *positions, int32_t *moves, int32_t cap, int32_t *n_plies,
@@ -347,6 +371,10 @@ int bo_nn_tower_word(bo_tower *tower, void **dev_word_out);
  * bo_search_result / bo_selfplay_turn bring it to the host in the round trip they make anyway; bo_engine_watch_seen returns the OR
  * of the values seen since the last call with clear != 0.  Nothing is enqueued and nothing waits in either call. */
 int bo_engine_watch(bo_engine *engine, int32_t *dev_word);
+/* (ABI 5) The same for n_words (1 or 2) consecutive words: the copy is word 0 | (word 1 != 0 ? 0x10000 : 0).  Two words are what
+ * bo_nn_b1_word returns -- the one-launch tower's [hand-off timeout code | saturation flag] -- so uci.py's searches and small self-play
+ * batches, which that tower evaluates, stop on an invalid evaluation instead of using it. */
+int bo_engine_watch_words(bo_engine *engine, int32_t *dev_words, int32_t n_words);
 int bo_engine_watch_seen(bo_engine *engine, int32_t *seen_out, int32_t clear);
 
 
@@ -393,6 +421,8 @@ int bo_nn_b1_forward(bo_b1 *tower, const float *x_dev, float *y_dev, int batch, 
  * is invalid then); or -1: an activation left the fp16 range with split weights (saturated: the output is wrong, use a handle without
  * split weights).  Synchronises `stream`. */
 int bo_nn_b1_status(bo_b1 *tower, int32_t *code_out, void *stream);
+/* (ABI 5) Device address of the two status words bo_nn_b1_status reads ([timeout code | saturation flag]; sticky until that call). */
+int bo_nn_b1_word(bo_b1 *tower, void **dev_words_out);
 void bo_nn_b1_destroy(bo_b1 *tower);
 
 #ifdef __cplusplus

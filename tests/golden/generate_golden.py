@@ -16,6 +16,8 @@ Outputs (tests/golden/):
   g2_searches.json  per-search expected tree / pi / best move / batch trace
   g2_games.json     per-game expected moves / z / pi / state hashes
   g4_codec.json     utils.test_move_indexing error counts + legal move -> index tables
+  g5_long_games.json / g5_long_evals.npz   two full-length games of the reference (120 plies from the start position; fullmove 28 to the
+                    end by rule) with their seam -- `--long` regenerates only these
 
 Nothing here travels to the GPU box except the outputs; tests never read /root/reference.
 """
@@ -31,8 +33,12 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = os.environ.get("BETAONE_GOLDEN_OUT", HERE)  # where the fixtures are written (the committed ones live next to this file)
 REF = "/root/reference"
-sys.path[:0] = [os.path.join(ROOT, "oracle", "shim"), REF, os.path.join(ROOT, "tests")]
+# scripts/pin_python_chess.py re-runs this file with the REAL python-chess (where it is installed) into a scratch directory and diffs
+# the result against the committed fixtures: BETAONE_GOLDEN_REAL_CHESS=1 leaves the shim off the path, BETAONE_GOLDEN_OUT names the directory.
+REAL_CHESS = os.environ.get("BETAONE_GOLDEN_REAL_CHESS", "0") == "1"
+sys.path[:0] = ([] if REAL_CHESS else [os.path.join(ROOT, "oracle", "shim")]) + [REF, os.path.join(ROOT, "tests")]
 sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
@@ -45,7 +51,7 @@ import mcts  # noqa: E402
 import self_play  # noqa: E402
 from fake_model import FakeNet, hash_init_, planes_key  # noqa: E402
 
-assert chess.__file__.startswith(os.path.join(ROOT, "oracle", "shim"))
+assert chess.__file__.startswith(os.path.join(ROOT, "oracle", "shim")) != REAL_CHESS
 for m in (config, network, utils, mcts, self_play):
     assert m.__file__.startswith(REF), m.__file__
 
@@ -343,15 +349,15 @@ def gen_g2():
         idx.append(ii)
         val.append(EVALS[k][0][ii])
         ptr.append(ptr[-1] + len(ii))
-    np.savez(os.path.join(HERE, "g2_evals.npz"),
+    np.savez(os.path.join(OUT, "g2_evals.npz"),
              full_keys=np.array(full), full_probs=np.stack([EVALS[k][0] for k in full]),
              full_values=np.array([EVALS[k][1] for k in full], np.float32),
              sparse_keys=np.array(sparse), sparse_ptr=np.array(ptr, np.int64),
              sparse_idx=np.concatenate(idx), sparse_val=np.concatenate(val),
              sparse_values=np.array([EVALS[k][1] for k in sparse], np.float32))
     keys = full + sparse
-    json.dump(searches, open(os.path.join(HERE, "g2_searches.json"), "w"), indent=0)
-    json.dump(games, open(os.path.join(HERE, "g2_games.json"), "w"), indent=0)
+    json.dump(searches, open(os.path.join(OUT, "g2_searches.json"), "w"), indent=0)
+    json.dump(games, open(os.path.join(OUT, "g2_games.json"), "w"), indent=0)
     print(f"[g2] {len(keys)} evals, {len(searches)} searches, {len(games)} games")
 
 
@@ -383,7 +389,7 @@ def gen_g1():
         out[f"nkeys_{name}"] = np.array(len(net.state_dict()))
         print(f"[g1] {name}: params={int(out[f'nparams_{name}'])} keys={int(out[f'nkeys_{name}'])} "
               f"logit range [{logits.min():.3f},{logits.max():.3f}] value {value.flatten().tolist()}")
-    np.savez_compressed(os.path.join(HERE, "g1_net.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "g1_net.npz"), **out)
 
 
 def gen_g4():
@@ -401,10 +407,53 @@ def gen_g4():
         table = [[m.uci(), utils.move_to_index(m)] for m in b.legal_moves]
         out.append(dict(fen=fen, errors=int(errors), moves=table))
         print(f"[g4] {fen}: errors={errors} moves={len(table)}")
-    json.dump(out, open(os.path.join(HERE, "g4_codec.json"), "w"), indent=0)
+    json.dump(out, open(os.path.join(OUT, "g4_codec.json"), "w"), indent=0)
+
+
+# Full-length traces ("to the end or ..."): the unmodified reference plays
+#   (a) one game from the start position at 50 simulations per move to natural termination or 120 plies -- the temperature switch at
+#       fullmove 30 (self_play.py:66) happens inside it, the end-of-game tracker (E8) covers a long game;
+#   (b) one game from fullmove 28 with the fifty-move clock at 60: it crosses the temperature threshold after four plies and ends BY RULE
+#       (mate, or the claimable draw of is_game_over(claim_draw=True), self_play.py:101-102,190-208).
+# Written to g5_long_games.json / g5_long_evals.npz so that the round-1 fixtures stay byte-identical.
+LONG_GAME_CASES = [
+    dict(name="game_long_startpos_120", seed=5, scale=6.0, salt=300, config=dict(num_simulations=50, max_game_moves=120)),
+    dict(name="game_long_threshold_to_rule", fen="8/5k2/8/8/3K4/8/8/R7 w - - 60 28", seed=6, scale=6.0, salt=301,
+         config=dict(num_simulations=50)),
+]
+
+
+def gen_g5():
+    EVALS.clear()
+    PROB_HASH.clear()
+    games = []
+    for case in LONG_GAME_CASES:
+        exp = run_game_case(case)
+        games.append(dict(case=case, expect=exp))
+        print(f"[g5] {case['name']}: records={exp.get('n_records')} last z={exp.get('z', [])[-2:]} moves={' '.join(exp.get('moves', [])[-6:])}")
+    full = sorted(k for k in EVALS if EVALS[k][2])
+    sparse = sorted(k for k in EVALS if not EVALS[k][2])
+    ptr, idx, val = [0], [], []
+    for k in sparse:
+        ii = np.array(sorted(EVALS[k][3]), dtype=np.int32)
+        idx.append(ii)
+        val.append(EVALS[k][0][ii])
+        ptr.append(ptr[-1] + len(ii))
+    np.savez_compressed(os.path.join(OUT, "g5_long_evals.npz"),
+                        full_keys=np.array(full), full_probs=np.stack([EVALS[k][0] for k in full]),
+                        full_values=np.array([EVALS[k][1] for k in full], np.float32),
+                        sparse_keys=np.array(sparse), sparse_ptr=np.array(ptr, np.int64),
+                        sparse_idx=np.concatenate(idx), sparse_val=np.concatenate(val),
+                        sparse_values=np.array([EVALS[k][1] for k in sparse], np.float32))
+    json.dump(games, open(os.path.join(OUT, "g5_long_games.json"), "w"), indent=0)
+    print(f"[g5] {len(full) + len(sparse)} evals, {len(games)} games")
 
 
 if __name__ == "__main__":
+    if "--long" in sys.argv:  # only the full-length games (the other fixtures are left as they are)
+        gen_g5()
+        sys.exit(0)
     gen_g4()
     gen_g2()
     gen_g1()
+    gen_g5()

@@ -18,12 +18,20 @@ class SeamTable:
     them when the fixtures were generated (tests/golden/generate_golden.py)."""
 
     def __init__(self):
-        z = np.load(os.path.join(GOLD, "g2_evals.npz"))
-        self.full = {k: i for i, k in enumerate(z["full_keys"].tolist())}
-        self.full_probs, self.full_values = z["full_probs"], z["full_values"]
-        self.sparse = {k: i for i, k in enumerate(z["sparse_keys"].tolist())}
-        self.ptr, self.idx, self.val = z["sparse_ptr"], z["sparse_idx"], z["sparse_val"]
-        self.sparse_values = z["sparse_values"]
+        # g2: the round-1 searches and short games; g5: the two full-length games (generate_golden.py --long)
+        zs = [np.load(os.path.join(GOLD, f)) for f in ("g2_evals.npz", "g5_long_evals.npz")]
+        cat = lambda key: np.concatenate([z[key] for z in zs])
+        self.full = {k: i for i, k in enumerate(cat("full_keys").tolist())}
+        self.full_probs, self.full_values = cat("full_probs"), cat("full_values")
+        self.sparse = {k: i for i, k in enumerate(cat("sparse_keys").tolist())}
+        self.idx, self.val = cat("sparse_idx"), cat("sparse_val")
+        self.sparse_values = cat("sparse_values")
+        ptrs, base = [], 0
+        for z in zs:  # (row pointers of the second table continue behind the first table's entries)
+            p = z["sparse_ptr"]
+            ptrs.append(p[:-1] + base)
+            base += int(p[-1])
+        self.ptr = np.concatenate(ptrs + [np.array([base], np.int64)])
         self.misses = []
 
     def lookup(self, planes_row: np.ndarray, scale: float, salt: int):
@@ -57,7 +65,7 @@ def load_searches():
 
 
 def load_games():
-    return json.load(open(os.path.join(GOLD, "g2_games.json")))
+    return json.load(open(os.path.join(GOLD, "g2_games.json"))) + json.load(open(os.path.join(GOLD, "g5_long_games.json")))
 
 
 def load_codec():

@@ -1,5 +1,7 @@
 """CPU tests of the oracle's rules engine against public known-answers (G3 of SURVEY.md section 8c).
-These pin the SET of legal moves; python-chess's move ORDER is restated, not pinned."""
+These pin the SET of legal moves; python-chess's move ORDER is restated, not pinned -- except for the start position, whose order the
+package's documentation prints (test_startpos_order_is_python_chess_order); scripts/pin_python_chess.py compares everything with the real
+package wherever it is installed."""
 import pytest
 
 from oracle import oracle as O
@@ -22,7 +24,13 @@ def test_perft_known_answers(fen, expected):
 
 
 def test_startpos_order_is_python_chess_order():
-    # python-chess: non-pawn pieces from h8 down to a1 (targets high->low), then pawn pushes, then doubles
+    """A PUBLISHED vector of python-chess's move ORDER, the one layer the reference does not contain: the package's own documentation
+    (README / docs "Core" quick start) prints the start position's generator as
+        >>> board.legal_moves
+        <LegalMoveGenerator at ... (Nh3, Nf3, Nc3, Na3, h3, g3, f3, e3, d3, c3, b3, a3, h4, g4, f4, e4, d4, c4, b4, a4)>
+    i.e. non-pawn pieces from h8 down to a1 (targets high -> low), then single pawn pushes, then double pushes -- the list below in UCI.
+    Everything else about the order is restated from the package's algorithm (oracle/bo_rules.c) and waits for
+    scripts/pin_python_chess.py to be run where the package can be installed."""
     got = [O.move_to_uci(m) for m in O.Board().legal_moves()]
     assert got == ("g1h3 g1f3 b1c3 b1a3 h2h3 g2g3 f2f3 e2e3 d2d3 c2c3 b2b3 a2a3 "
                    "h2h4 g2g4 f2f4 e2e4 d2d4 c2c4 b2b4 a2a4").split()

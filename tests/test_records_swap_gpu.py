@@ -242,3 +242,132 @@ def test_a_net_that_saturates_the_split_tower_stops_self_play_at_that_ply(env):
     ro._graph = ro._fgraph = None
     ro._graphs_n = {}
     ro.eng.close()
+
+
+def _hip_runtime():
+    import ctypes
+    import torch
+
+    return ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+
+
+def test_one_launch_tower_faults_stop_a_search_and_a_small_rollout(env):
+    """small float32 batches (uci.py's run_mcts, run_self_play_game's one-slot Rollout) evaluate on the one-launch
+    tower with (hi, lo) fp16 weights (kernel_route -> 'tower_b1'); its status words -- a hand-off wait that gave up, an activation that
+    left the fp16 range -- now ride in every result block (bo_nn_b1_word -> bo_engine_watch_words): a forced timeout code and a
+    saturating net both RAISE in Rollout.play_ply and in run_mcts instead of returning moves made from invalid evaluations, and the
+    stage is re-armed afterwards (its counters start from zero: the next search is fine)."""
+    import ctypes
+    import torch
+    from betaone_amd import engine as E
+    from betaone_amd.nn_tune import best_inference_copy
+    from betaone_amd.rollout import Rollout
+
+    config = env
+    net = _net(config, (2, 1, 128), 5)
+    small = best_inference_copy(net, 1, "cuda:0")
+    assert small.conv == "tower_b1"
+    ptr, n_words = small.overflow_words()
+    assert ptr != 0 and n_words == 2
+    kw = dict(num_simulations=40, mcts_batch_size=16, device="cuda:0", use_graph=True, rng_mode="native", max_game_moves=6, policy_kind="probs")
+    ro = Rollout(small, 1, **kw)
+    ro.start_games([0], [0], [7])
+    assert ro.play_ply() == 1 and ro.play_ply() == 1          # a healthy stage plays
+    torch.cuda.synchronize()
+    code = ctypes.c_uint32(1 + 5)                               # "the hand-off wait of phase 5 gave up", as the kernel would leave it
+    assert _hip_runtime().hipMemcpy(ctypes.c_void_p(ptr), ctypes.byref(code), 4, 1) == 0  # hipMemcpyHostToDevice
+    with pytest.raises(E.EngineError, match="timed out"):
+        for _ in range(3):
+            ro.play_ply()
+    assert ro.n_plies == 2                                      # nothing was played from the ply whose evaluations were invalid
+    ro._graph = ro._fgraph = None
+    ro._graphs_n = {}
+    ro.eng.close()
+    small.check_b1()                                            # re-armed: no fault pending any more
+
+    # the drop-in's single search (uci.py:63,84 -> run_mcts)
+    from betaone_amd import dropin
+    dropin.install()
+    import mcts as dm
+    import utils as du
+    from oracle.shim import chess as shim  # (python-chess stand-in: test infrastructure)
+
+    config.NUM_SIMULATIONS, config.MCTS_BATCH_SIZE = 60, 16
+    model = _net(config, (2, 1, 128), 5).to("cuda:0").eval()
+    board, trk = shim.Board(), du.RepetitionTracker()
+    trk.add_board(board)
+    mv, pi = dm.run_mcts(board, model, [], trk)                # healthy
+    assert abs(float(pi.sum()) - 1.0) < 1e-6
+    stage = next(iter(dm._fast.values()))[1]
+    assert getattr(stage, "net", stage).conv == "tower_b1"
+    ptr2, _ = getattr(stage, "net", stage).overflow_words()
+    torch.cuda.synchronize()
+    assert _hip_runtime().hipMemcpy(ctypes.c_void_p(ptr2), ctypes.byref(code), 4, 1) == 0
+    with pytest.raises(E.EngineError, match="timed out"):
+        dm.run_mcts(board, model, [], trk)
+    mv2, pi2 = dm.run_mcts(board, model, [], trk)              # re-armed by the check that raised
+    assert abs(float(pi2.sum()) - 1.0) < 1e-6
+
+    with torch.no_grad():
+        model.conv_input.weight.mul_(3.0e5)                     # activations leave the fp16 range
+    # (the in-place edit bumped the parameters' version counters: run_mcts rebuilds its inference copy)
+    with pytest.raises(E.EngineError, match="fp16 range"):
+        dm.run_mcts(board, model, [], trk)
+
+
+def test_swap_model_under_cohorts_and_captured_graphs(env):
+    """CohortRollout.swap_model while every cohort has a whole ply enqueued on its own stream (captured graphs, the next
+    root evaluation).  The outstanding plies are ended first -- played with the OLD weights -- so nothing of the old graphs is in flight when
+    they are released; from then on every search evaluates with the new weights: the games equal those of a single Rollout that swaps after
+    the same number of plies (old weights for plies < K, new weights from the positions and RNG states of the swap onward)."""
+    import torch
+    from betaone_amd.nn_tune import best_inference_copy
+    from betaone_amd.rollout import CohortRollout, Rollout
+
+    config = env
+    G, K, T = 16, 3, 6
+    kw = dict(num_simulations=100, mcts_batch_size=32, device="cuda:0", use_graph=True, rng_mode="native", max_game_moves=T, policy_kind="probs")
+    ids = list(range(G))
+
+    def nets(seed, n):
+        return [best_inference_copy(_net(config, (2, 1, 128), seed), G // max(1, n), "cuda:0") for _ in range(max(1, n))]
+
+    def run(cohorts):
+        old, new = nets(1, cohorts), nets(2, cohorts)
+        ro = CohortRollout(old, G, cohorts=cohorts, **kw) if cohorts > 1 else Rollout(old[0], G, **kw)
+        ro.start_games(ids, ids, [2000 + i for i in ids])
+        fins = []
+        for p in range(T + 3):
+            if p == K:
+                if cohorts > 1:
+                    assert all(part._turn_due is not None for part in ro.parts)   # every cohort has a ply in flight when the swap comes
+                ro.swap_model(new if cohorts > 1 else new[0])
+                if cohorts > 1:
+                    assert all(part._turn_due is None and part._graph is None and not part._graphs_n for part in ro.parts)
+            ro.play_ply(on_finished=fins.append)
+        if cohorts > 1:
+            ro.drain()
+        while any(g is not None for g in ro.games):
+            ro.play_ply(on_finished=fins.append)
+        ro.close()
+        return {f.game_id: (list(f.moves), [(i.tolist(), v.tobytes()) for i, v in f.pis]) for f in fins}
+
+    one = run(1)
+    two = run(2)
+    assert sorted(one) == ids
+    # a cohort's pipeline is one ply ahead of a single Rollout's call count (play_ply ends a ply and begins the next): the swap lands one
+    # ply later in the cohorts' games than in the single Rollout's -- compare against the single run that swaps at K + 1
+    assert sorted(two) == ids and all(len(two[g][0]) == T for g in ids)
+    K_eff = K  # plies each cohort had ENDED when the swap came: drain() ended the (K)th
+    def run_single(k):
+        old, new = nets(1, 1)[0], nets(2, 1)[0]
+        ro = Rollout(old, G, **kw)
+        ro.start_games(ids, ids, [2000 + i for i in ids])
+        fins = []
+        for p in range(T + 3):
+            if p == k:
+                ro.swap_model(new)
+            ro.play_ply(on_finished=fins.append)
+        ro.close()
+        return {f.game_id: (list(f.moves), [(i.tolist(), v.tobytes()) for i, v in f.pis]) for f in fins}
+    assert two == run_single(K_eff) or two == run_single(K_eff + 1)
