@@ -216,6 +216,24 @@ def select_roofline(args, device):
 # carries `traffic: null` and names the committed pass; no constant from an earlier run is printed as if this run had measured it.
 TOWER_PMC_SOURCE = {"tower_split": "profiles/r03_tower_split_pmc.md (separate rocprofv3 --pmc pass of this kernel, 256 boards of the 10x128 net: 2 x FETCH_SIZE + WRITE_SIZE per launch)",
                     "tower_wg": "profiles/r02_tower_wg_pmc.md (separate rocprofv3 --pmc pass of this kernel, 256 boards x 128 filters)"}
+# This round's pass of the split-precision tower at the bench's own launch shape (scripts/gpu_round.sh pmcsplit64 -> profiles/r05_tower_pmc.json:
+# FETCH_SIZE x 2 (the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE per launch, per kernel name and boards per launch)
+TOWER_PMC_JSON = os.path.join(ROOT, "profiles", "r05_tower_pmc.json")
+# what one compute unit can take in from its XCD's L2 (scripts/weight_stream_lab.hip, profiles/r05_tower_bound.md): the bound of a kernel that
+# keeps one board per workgroup and therefore streams the whole tower's weights through every CU
+L2_PORT_LAB_GBPS_PER_CU, L2_PORT_LAB_SOURCE = 64.5, "profiles/r05_tower_bound.md (scripts/weight_stream_lab.hip: 26.9 B/clk per CU at 2.40 GHz, 64 and 256 CUs alike)"
+
+
+def tower_pmc_traffic(kernel, boards):
+    """(bytes per launch, source) from the committed PMC pass of `kernel` at `boards` boards per launch, or (None, why not)."""
+    try:
+        rec = json.load(open(TOWER_PMC_JSON))
+    except Exception:
+        return None, TOWER_PMC_SOURCE.get("tower_split")
+    for e in rec.get("launch_shapes", []):
+        if e.get("kernel") == kernel and int(e.get("boards", -1)) == int(boards):
+            return float(e["hbm_side_bytes_per_launch"]), f"profiles/r05_tower_pmc.json ({e.get('source', 'rocprofv3 --pmc')}; ratio to algorithmic bytes {e.get('ratio_to_algorithmic')})"
+    return None, f"profiles/r05_tower_pmc.json has no pass of {kernel} at {boards} boards per launch"
 
 
 def tower_timings(parts, seq0, khz):
@@ -297,8 +315,10 @@ def nn_roofline(net, batch, device, timed=None, wall_us=None):
     # multiplies on; what the kernel EXECUTES on that pipe (three fp16 MFMAs per float32 product; Winograd: 16 multiplies per 2x2
     # tile; the input conv padded to 128 channels) is reported beside it as `pipe_utilisation`.
     if conv == "tower_split":
-        peak, kernel = 2500.0, "bo_k_tower_s"   # fp16 MFMA dense (MI355X_MICROARCH.md)
-        note = ("float32 planes in and out; every float32 operand a (hi, lo) fp16 pair, every product three v_mfma_f32_32x32x16_f16 with "
+        t16 = getattr(net, "split_tile", 32) == 16
+        peak, kernel = 2500.0, ("bo_k_tower_s16" if t16 else "bo_k_tower_s")   # fp16 MFMA dense (MI355X_MICROARCH.md)
+        note = ("float32 planes in and out; every float32 operand a (hi, lo) fp16 pair, every product three "
+                + ("v_mfma_f32_16x16x32_f16" if t16 else "v_mfma_f32_32x32x16_f16") + " with "
                 "float32 accumulation (direct 3x3 form); one workgroup per board, activations LDS-resident for the whole tower")
     else:
         peak, kernel = 157.3, ("bo_k_tower_wg" if conv == "tower_wg" else "bo_k_tower")  # fp32 MFMA dense: 256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz
@@ -311,8 +331,18 @@ def nn_roofline(net, batch, device, timed=None, wall_us=None):
     eff_us = us / conc if conc else us
     ach, ach1 = algorithmic / eff_us / 1e6, algorithmic / us / 1e6
     share = min(1.0, batch / float(n_cu))
+    traffic, traffic_src = (tower_pmc_traffic(kernel, batch) if conv == "tower_split" else (None, TOWER_PMC_SOURCE.get(conv)))
+    l2_port = None
+    if conv == "tower_split":  # one board per workgroup: every CU streams the whole tower's (hi, lo) weight pairs -- what actually bounds a launch
+        w_bytes = 4.0 * 9 * C * (128 + (n_conv - 1) * C)
+        l2_port = {"bound": "per-CU L2 port (the weight stream of one board per workgroup)", "weight_bytes_per_cu_per_launch": w_bytes,
+                   "achieved_GBps_per_cu": round(w_bytes / us / 1e3, 1), "alone_GBps_per_cu": round(w_bytes / b2b / 1e3, 1),
+                   "lab_peak_GBps_per_cu": L2_PORT_LAB_GBPS_PER_CU, "frac": round(w_bytes / us / 1e3 / L2_PORT_LAB_GBPS_PER_CU, 3),
+                   "frac_alone": round(w_bytes / b2b / 1e3 / L2_PORT_LAB_GBPS_PER_CU, 3), "lab": L2_PORT_LAB_SOURCE,
+                   "note": "the port delivers bytes per CLOCK: `achieved` (launches of the timed region, several cohorts' towers in flight, clock "
+                           "lowered by the matrix load) sits below `alone` by the clock ratio; `alone` is the lone launch's rate"}
     return {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "traffic": None, "traffic_source": TOWER_PMC_SOURCE.get(conv),
+            "traffic": traffic, "traffic_source": traffic_src, "l2_port": l2_port,
             "basis": "algorithmic flops = 2 x MACs of the tower's direct 3x3 convolutions (2*9*64*C*(120 + (layers-1)*C) per board) x boards per launch, "
                      "/ the chip's time per launch = time with >= 1 launch of this kernel running / launches (= avg_launch_us / concurrency)",
             "alg_flops_per_launch": algorithmic, "executed_mfma_flops_per_launch": executed,

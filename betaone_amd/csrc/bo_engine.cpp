@@ -15,6 +15,7 @@
 #include "bo_tower_wg.h"
 #include "bo_tower_h.h"
 #include "bo_tower_s.h"
+#include "bo_tower_s16.h"
 #include "bo_heads.h"
 #include "bo_tower_b1.h"
 #include "bo_rt.h"
@@ -1598,14 +1599,16 @@ extern "C" int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layer
 #else
     static_assert(sizeof(bo_tower_layer_desc) == sizeof(bo_tower_layer), "descriptor layouts must agree");
     if (!layers || !weights || !params || !out || n_layers < 1 || n_layers > 4096) return fail(BO_E_ARG, "bad arguments");
-    const bool half_w = algo == BO_TOWER_DIRECT_F16 || algo == BO_TOWER_SPLIT_F16;  // fp16 weight fragments, 16-byte offsets
+    const bool split_w = algo == BO_TOWER_SPLIT_F16 || algo == BO_TOWER_SPLIT_F16_T16;
+    const bool half_w = algo == BO_TOWER_DIRECT_F16 || split_w;  // fp16 weight fragments, 16-byte offsets
     if (half_w ? (channels != 128 && channels != 256) : (channels != 64 && channels != 128))
         return fail(BO_E_CONFIG, "bo_nn_tower: channels must be 64 or 128 (fp32: two padded images per board in LDS) or 128 / 256 (BO_TOWER_DIRECT_F16, BO_TOWER_SPLIT_F16)");
     if (n_weights % 4) return fail(BO_E_ARG, "n_weights must be a multiple of 4");
     if (algo != BO_TOWER_DIRECT && algo != BO_TOWER_WINOGRAD && !half_w) return fail(BO_E_ARG, "unknown algo");
+    if (algo == BO_TOWER_SPLIT_F16_T16 && channels != 128) return fail(BO_E_CONFIG, "BO_TOWER_SPLIT_F16_T16: 128 filters (other widths: BO_TOWER_SPLIT_F16)");
     if (algo == BO_TOWER_DIRECT_F16 && !head) return fail(BO_E_ARG, "BO_TOWER_DIRECT_F16 needs the fused head (it has no tower output buffer)");
     const int C = channels;
-    const int split = algo == BO_TOWER_SPLIT_F16 ? 2 : 1;  // (hi, lo) fragment pairs; one more float (the inverse weight scale) behind every bias
+    const int split = split_w ? 2 : 1;  // (hi, lo) fragment pairs; one more float (the inverse weight scale) behind every bias
     for (int l = 0; l < n_layers; l++) {  // every offset the kernel will form stays inside the two buffers
         const bo_tower_layer_desc &L = layers[l];
         // K steps per layer: direct = groups of 8 input channels, Winograd = groups of 4; the input conv is padded to 128
@@ -1619,7 +1622,7 @@ extern "C" int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layer
         if (L.t4 != want_t4) return fail(BO_E_ARG, "layer " + std::to_string(l) + ": t4 must be " + std::to_string(want_t4));
         if (L.w_off4 < 0 || ((int64_t)L.w_off4 + w4) * 4 > n_weights) return fail(BO_E_ARG, "weights offset out of range");
         if (L.bias_off < 0 || (int64_t)L.bias_off + C + (split - 1) > n_params) return fail(BO_E_ARG, "bias offset out of range");
-        if ((algo == BO_TOWER_WINOGRAD || algo == BO_TOWER_SPLIT_F16) && (L.bias_off & 3)) return fail(BO_E_ARG, "BO_TOWER_WINOGRAD / BO_TOWER_SPLIT_F16: bias_off must be a multiple of 4 floats");
+        if ((algo == BO_TOWER_WINOGRAD || split_w) && (L.bias_off & 3)) return fail(BO_E_ARG, "BO_TOWER_WINOGRAD / BO_TOWER_SPLIT_F16: bias_off must be a multiple of 4 floats");
         if (L.kind == 3) {
             if (L.hidden < 1 || L.hidden > 16) return fail(BO_E_CONFIG, "SE hidden width must be 1..16");
             if (half_w && L.hidden > C / 16) return fail(BO_E_CONFIG, "fp16-pipe towers: SE hidden width must be <= channels/16");
@@ -1721,7 +1724,7 @@ static int tower_forward_impl(bo_tower *t, const float *x_dev, float *y_dev, voi
         RT((int)hipGetLastError());
         return BO_OK;
     }
-    if (t->algo == BO_TOWER_SPLIT_F16) {  // float32 in and out, fp16 (hi, lo) pairs on the matrix pipe; one board per workgroup
+    if (t->algo == BO_TOWER_SPLIT_F16 || t->algo == BO_TOWER_SPLIT_F16_T16) {  // float32 in and out, fp16 (hi, lo) pairs on the matrix pipe; one board per workgroup
         bo_tower_head_s hs;
         hs.channels = t->head_channels; hs.split = t->head_split; hs.w_off8 = t->head_w_off; hs.b_off = t->head_b_off;
         hs.out_a = (float *)head_a_dev; hs.out_b = (float *)head_b_dev; hs.overflow = t->overflow;
@@ -1731,7 +1734,9 @@ static int tower_forward_impl(bo_tower *t, const float *x_dev, float *y_dev, voi
         // scratch); 4 ahead: none, and as fast (1 667-1 672 us against 1 678-1 679 per 256 boards, same box: profiles/r04_tower256_ring.md).
         // BETAONE_TOWER256_AR=8 keeps the old instance selectable for A/B runs.
         static const int ar256 = [] { const char *v = getenv("BETAONE_TOWER256_AR"); return (v && v[0] == '8') ? 8 : 4; }();
-        if (t->channels == 256 && ar256 == 8) hipLaunchKernelGGL((bo_k_tower_s<256, 2, 0, 1, 8>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
+        if (t->algo == BO_TOWER_SPLIT_F16_T16)  // the same products as 16x16x32 tiles (bo_tower_s16.h: the chip holds a higher clock under them)
+            hipLaunchKernelGGL((bo_k_tower_s16<6>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
+        else if (t->channels == 256 && ar256 == 8) hipLaunchKernelGGL((bo_k_tower_s<256, 2, 0, 1, 8>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
         else if (t->channels == 256) hipLaunchKernelGGL((bo_k_tower_s<256, 2, 0, 1, 4>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
         else  // (B operands read two K-steps ahead, weight fragments requested twelve ahead: profiles/r03_split_tower.md)
             hipLaunchKernelGGL((bo_k_tower_s<128, 1, 0, 2, 12>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);

@@ -105,6 +105,18 @@ def pack_conv_weight_split(w: torch.Tensor, scale: float) -> torch.Tensor:
     return u.permute(6, 3, 1, 0, 4, 2, 5).contiguous()  # [tap][cg][mt][hl][kg][o][i]
 
 
+SPLIT_TILE_DEFAULT = "16"  # which MFMA tile conv='tower_split' multiplies with at 128 filters ("16": csrc/bo_tower_s16.h); BETAONE_SPLIT_TILE overrides
+
+
+def pack_conv_weight_split16(w: torch.Tensor, scale: float) -> torch.Tensor:
+    """[c_out, c_in, 3, 3] float32 -> fp16 [9][c_in/32][c_out/16][2 = hi, lo][64][8] of scale*w (BO_TOWER_SPLIT_F16_T16: the A fragments of
+    v_mfma_f32_16x16x32_f16): element (tap, g, ot, hl, lane, i) = split(scale * W[16*ot + (lane & 15)][32*g + 8*(lane >> 4) + i][tap])."""
+    co, ci = w.shape[0], w.shape[1]
+    hi, lo = split_f16(w.double() * scale)
+    u = torch.stack([hi, lo], 0).reshape(2, co // 16, 16, ci // 32, 4, 8, 9)  # [hl][ot][o][g][kb][i][tap]
+    return u.permute(6, 3, 1, 0, 4, 2, 5).contiguous()  # [tap][g][ot][hl][kb][o][i]
+
+
 def pack_conv_weight_small(w: torch.Tensor) -> torch.Tensor:
     """[c_out, c_in, 3, 3] -> [c_out/16][tap 9][c_in/16][64][4] (bo_nn_conv3x3_small): element (ot, tap, g, lane, e) =
     W[16*ot + (lane & 15)][16*g + 4*e + (lane >> 4)][tap]."""
@@ -310,6 +322,9 @@ class FusedPolicyValueNet(nn.Module):
         c = self.w_in.shape[0]
         if c not in (128, 256) or self.w_in.shape[1] != 120:
             raise E.EngineError("conv='tower_split' supports 120 input planes and 128 or 256 filters")
+        # 128 filters: the products as 16x16x32 tiles (csrc/bo_tower_s16.h) or 32x32x16 (bo_tower_s.h); BETAONE_SPLIT_TILE=16 / 32 for A/B runs
+        self.split_tile = 16 if (c == 128 and os.environ.get("BETAONE_SPLIT_TILE", SPLIT_TILE_DEFAULT) == "16") else 32
+        pack = pack_conv_weight_split16 if self.split_tile == 16 else pack_conv_weight_split
         wts, params, layers = [], [], []
         n_h = n_p = 0  # halves in wts, floats in params
 
@@ -332,7 +347,7 @@ class FusedPolicyValueNet(nn.Module):
         def add_conv(w, bias):  # -> (weights offset, bias offset); params: bias [c], 1 / scale, padding to a multiple of 4 floats
             w = w.detach().float().cpu()
             s = split_scale(w)
-            return add_w(pack_conv_weight_split(w, s)), add_p(torch.cat([bias.detach().float().cpu().reshape(-1), torch.tensor([1.0 / s, 0.0, 0.0, 0.0])]))
+            return add_w(pack(w, s)), add_p(torch.cat([bias.detach().float().cpu().reshape(-1), torch.tensor([1.0 / s, 0.0, 0.0, 0.0])]))
 
         w0 = torch.zeros((c, 128, 3, 3))
         w0[:, :120] = self.w_in.detach().float().cpu()
@@ -367,7 +382,7 @@ class FusedPolicyValueNet(nn.Module):
         table = np.ascontiguousarray(np.array(layers, dtype=np.int32))
         handle = C.c_void_p()
         rc = self.lib.bo_nn_tower_create(table.ctypes.data, len(layers), wts.ctypes.data, wts.size // 2, params.ctypes.data, params.size, c,
-                                         3, head.ctypes.data, dev.index if dev.index is not None else torch.cuda.current_device(), C.byref(handle))
+                                         4 if self.split_tile == 16 else 3, head.ctypes.data, dev.index if dev.index is not None else torch.cuda.current_device(), C.byref(handle))
         if rc:
             raise E.EngineError(self.lib.bo_last_error().decode())
         self.c, self._tower, self._tower_dev = c, handle, dev

@@ -329,6 +329,10 @@ int bo_nn_conv3x3_small(const float *x_dev, const float *wpacked_dev, const floa
  *   bias_off a multiple of 4).
  *   `head` is optional: weights [ceil(channels/32)][C/16][2][64][8] at 16-byte offset w_off in `weights`, bias [channels]
  *   followed by the inverse scale in params; head outputs are float32.  y_dev (optional) receives the tower output.
+ * algo BO_TOWER_SPLIT_F16_T16 (ABI 5, csrc/bo_tower_s16.h; 128 filters): BO_TOWER_SPLIT_F16 with the products issued as 16x16x32 tiles (the chip
+ *   holds a higher clock under them: profiles/r05_tower_bound.md); everything as for BO_TOWER_SPLIT_F16 except the per-layer fragment order
+ *   [tap 9][c_in/32][C/16][2 = hi, lo][64][8]: element (tap, g, ot, hl, lane, i) = s*W[16*ot + (lane & 15)][32*g + 8*(lane >> 4) + i][tap]
+ *   (t4 still counts K-steps of 16 channels: 9*c_in/16).
  * weights: float32 at float4 offset w_off4; params: float32 biases and SE matrices at float offsets.
  * head (optional, BO_TOWER_WINOGRAD only): the policy and value 1x1 convolutions + ReLU (network.py:101-113,191-195)
  *   fused behind the tower: bias [channels] and weights in params, the weights packed [ceil(channels/16)][C/16][64][4]
@@ -338,7 +342,7 @@ int bo_nn_conv3x3_small(const float *x_dev, const float *wpacked_dev, const floa
  * bo_nn_tower_create validates every offset and copies the three HOST arrays to `device`;
  * bo_nn_tower_forward(x_dev [batch,120,8,8] -> y_dev [batch,C,8,8], NCHW float32) is asynchronous on `stream`.
  * bo_nn_value_tail: out[b] = tanh(w . h[b] + bias[0]) (value_fc2 + tanh, network.py:116-118,197). */
-enum { BO_TOWER_DIRECT = 0, BO_TOWER_WINOGRAD = 1, BO_TOWER_DIRECT_F16 = 2, BO_TOWER_SPLIT_F16 = 3 };
+enum { BO_TOWER_DIRECT = 0, BO_TOWER_WINOGRAD = 1, BO_TOWER_DIRECT_F16 = 2, BO_TOWER_SPLIT_F16 = 3, BO_TOWER_SPLIT_F16_T16 = 4 };
 typedef struct bo_tower_layer_desc {
     int32_t w_off4, t4, bias_off, kind, se_w1_off, se_w2_off, hidden, last;
 } bo_tower_layer_desc;

@@ -62,6 +62,13 @@ for step in "$@"; do
                  for c in $pass; do python scripts/pmc_summary.py $out/${tag}_pmcsplit_$p $c >> $out/${tag}_pmcsplit.md 2>&1 ; done ;
                  rm -rf $out/${tag}_pmcsplit_$p ;
               done ; cat $out/${tag}_pmcsplit.md ;;
+    pmcsplit64) rm -f $out/${tag}_pmcsplit64.md $out/${tag}_pmcsplit64.json;
+              for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"; do
+                 p=$(echo $pass | cut -d" " -f1); mkdir -p $out/${tag}_pmcsplit64_$p;
+                 run pmcsplit64_$p 400 rocprofv3 --pmc $pass --kernel-trace --kernel-include-regex "bo_k_tower_s|bo_k_heads" --output-format csv -d $out/${tag}_pmcsplit64_$p -- python scripts/forward_profile.py tower_split 64 ;
+                 for c in $pass; do python scripts/pmc_summary.py $out/${tag}_pmcsplit64_$p $c --json $out/${tag}_pmcsplit64.json >> $out/${tag}_pmcsplit64.md 2>&1 ; done ;
+                 rm -rf $out/${tag}_pmcsplit64_$p ;
+              done ; cat $out/${tag}_pmcsplit64.md ;;
     dist2nccl) run bench_dist2 400 python bench.py --gpus 2 --share-gpu --dist-backend gloo --games 128 --steps 40 --no-cpu-baseline --no-roofline ;;
     ucitrace) mkdir -p $out/${tag}_ucitrace; run ucitrace 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_ucitrace -- python tests/uci_latency.py ;
              python scripts/kernel_percentiles.py $out/${tag}_ucitrace bo_k_ Cijk softmax conv elementwise > $out/${tag}_ucitrace_percentiles.md 2>&1 ; cat $out/${tag}_ucitrace_percentiles.md ;;

@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256) k_stream(const i4 *w, int *out, int layer
 }
 
 int main() {
-    const int layers = 42;  // two towers' worth, so the stream does not fit one L2 (4 MiB): lines are re-fetched from the Infinity Cache as in the tower
+    const int layers = 84;  // four towers' worth, so the stream does not fit one L2 (4 MiB): lines are re-fetched from the Infinity Cache as in the tower
     int *out; unsigned long long *clk; CK(hipMalloc(&out, 4096)); CK(hipMalloc(&clk, 256 * 16));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (size_t bytes : {(size_t)589824, (size_t)1048576}) {
@@ -48,12 +48,13 @@ int main() {
         CK(hipMemcpy(w, h.data(), h.size() * 4, hipMemcpyHostToDevice));
         const int per_wave16 = (int)(bytes / 4 / 1024);  // 1 KiB wave-instructions per wave per layer
         for (int wgs : {64, 256})
-            for (int ring : {12, 24}) {
+            for (int ring : {12, 24, 48}) {
                 float best = 1e9f; double ghz = 0;
                 for (int rep = 0; rep < 4; rep++) {
                     CK(hipEventRecord(e0));
                     if (ring == 12) hipLaunchKernelGGL((k_stream<12>), dim3(wgs), dim3(256), 0, 0, w, out, layers, per_wave16, clk);
-                    else hipLaunchKernelGGL((k_stream<24>), dim3(wgs), dim3(256), 0, 0, w, out, layers, per_wave16, clk);
+                    else if (ring == 24) hipLaunchKernelGGL((k_stream<24>), dim3(wgs), dim3(256), 0, 0, w, out, layers, per_wave16, clk);
+                    else hipLaunchKernelGGL((k_stream<48>), dim3(wgs), dim3(256), 0, 0, w, out, layers, per_wave16, clk);
                     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
                     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
                     if (rep && ms < best) {

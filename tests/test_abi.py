@@ -175,3 +175,28 @@ def test_cu_partition_masks_are_disjoint_equal_shares_of_the_compute_units():
     import pytest
     with pytest.raises(ValueError):
         cu_partition_masks(4, 8)
+
+
+def test_lds_chunk_swizzle_of_the_16x16x32_split_tower_is_conflict_free():
+    """csrc/bo_tower_s16.h bo_sw16 (restated here): chunk j of a cell sits at position j ^ 2*((cell % 10) & 7).  A B operand of
+    v_mfma_f32_16x16x32_f16 is read per lane as one ds_read_b128: lane l = position tile's column l & 15, channel octet l >> 4 of the
+    K-step's 32 channels (chunk 4*group + (l >> 4)).  ds_read_b128 is served in four groups of 16 lanes; for every tap, position
+    tile and channel group the 16 lanes of a group must fall on 16 different bank quads."""
+    import re
+    src = open(os.path.join(ROOT, "betaone_amd", "csrc", "bo_tower_s16.h")).read()
+    assert re.search(r"bo_sw16\(int cell\) \{ return 2 \* \(\(cell % 10\) & 7\); \}", src), "restatement out of date"
+    half = [[0, 1, 2, 3, 12, 13, 14, 15] + list(range(20, 28)), list(range(4, 12)) + [16, 17, 18, 19, 28, 29, 30, 31]]
+    groups = half + [[l + 32 for l in g] for g in half]
+    sw16 = lambda cell: 2 * ((cell % 10) & 7)
+    for pt in range(4):
+        for tap in range(9):
+            off = (tap // 3 - 1) * 10 + (tap % 3 - 1)
+            for cg in range(4):
+                for g in groups:
+                    quads = set()
+                    for l in g:
+                        n16, kb = l & 15, l >> 4
+                        cell = ((n16 >> 3) + 1) * 10 + (n16 & 7) + 1 + 20 * pt + off
+                        assert 0 <= cell < 100
+                        quads.add((cell * 16 + (((4 * cg + kb) ^ sw16(cell)) & 15)) % 16)
+                    assert len(quads) == 16, (pt, tap, cg, g)

@@ -1,5 +1,7 @@
 """GPU parity tests (run with -m gpu on an MI355X): the product library csrc/libbetaone_hip.so, called
 through the C ABI, against the golden traces of the reference and against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -205,9 +207,9 @@ def test_mfma_conv3x3_matches_float64_convolution(backend, shape):
         conv3x3_mfma(lib, torch.zeros((1, 24, 8, 8)).cuda(), wp, bias, co)
 
 
-@pytest.mark.parametrize("conv", ["miopen", "mfma", "mfma_small", "tower_b1", "tower", "tower_wg", "tower_split"])
+@pytest.mark.parametrize("conv", ["miopen", "mfma", "mfma_small", "tower_b1", "tower", "tower_wg", "tower_split", "tower_split_t16", "tower_split_t32"])
 @pytest.mark.parametrize("size", [(3, 1, 64), (8, 2, 128), (15, 5, 256), (2, 2, 256), (0, 3, 128), (4, 0, 64)])
-def test_fused_epilogue_net_matches_plain_net(backend, size, conv):
+def test_fused_epilogue_net_matches_plain_net(backend, size, conv, monkeypatch):
     """csrc/bo_nn_fused.h, csrc/bo_conv.h, csrc/bo_tower.h, csrc/bo_tower_s.h: conv (MIOpen, the fp32-MFMA direct kernel, the
     whole tower as one persistent kernel on the fp32 matrix pipe, or on the fp16 pipe with (hi, lo) operand pairs) with fused
     epilogues == PolicyValueNet.forward, within 1e-5.  33 and 300 boards: fewer and more boards than CUs (the tower kernel loops).
@@ -217,8 +219,13 @@ def test_fused_epilogue_net_matches_plain_net(backend, size, conv):
         pytest.skip("(the library route at the reference-default size is the plain net itself; the hand-written routes are the subject)")
     if conv in ("tower", "tower_wg") and size[2] == 256:
         pytest.skip("two padded 256-channel boards do not fit in LDS; the tower kernel is for 64/128 filters")
-    if conv == "tower_split" and size[2] == 64:
+    if conv.startswith("tower_split") and size[2] == 64:
         pytest.skip("the split-precision tower is built for 128 and 256 filters")
+    if conv in ("tower_split_t16", "tower_split_t32"):  # both tilings of the 128-filter split tower (csrc/bo_tower_s16.h, bo_tower_s.h), whichever is the default
+        if size[2] != 128:
+            pytest.skip("the 16x16x32 tiling exists for 128 filters")
+        monkeypatch.setenv("BETAONE_SPLIT_TILE", conv[-2:])
+        conv = "tower_split"
     import torch
     from betaone_amd import dropin
     dropin.install()
@@ -231,6 +238,8 @@ def test_fused_epilogue_net_matches_plain_net(backend, size, conv):
     try:
         net = hash_init_(network.PolicyValueNet().eval()).to("cuda:0")
         fused = FusedPolicyValueNet(net, conv=conv).to("cuda:0")
+        if os.environ.get("BETAONE_SPLIT_TILE") and conv == "tower_split":
+            assert fused.split_tile == int(os.environ["BETAONE_SPLIT_TILE"])
         z = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "g1_net.npz"))
         x = torch.from_numpy(z["inputs"]).to("cuda:0").repeat(11, 1, 1, 1)  # 33 boards
         with torch.no_grad():
