@@ -221,7 +221,7 @@ TOWER_PMC_SOURCE = {"tower_split": "profiles/r03_tower_split_pmc.md (separate ro
 TOWER_PMC_JSON = os.path.join(ROOT, "profiles", "r05_tower_pmc.json")
 # what one compute unit can take in from its XCD's L2 (scripts/weight_stream_lab.hip, profiles/r05_tower_bound.md): the bound of a kernel that
 # keeps one board per workgroup and therefore streams the whole tower's weights through every CU
-L2_PORT_LAB_GBPS_PER_CU, L2_PORT_LAB_SOURCE = 64.5, "profiles/r05_tower_bound.md (scripts/weight_stream_lab.hip: 26.9 B/clk per CU at 2.40 GHz, 64 and 256 CUs alike)"
+L2_PORT_LAB_GBPS_PER_CU, L2_PORT_LAB_SOURCE = 70.2, "profiles/r05_tower_bound.md (scripts/weight_stream_lab.hip: 29.4 B/clk per CU at 2.39 GHz with 48 KiB in flight per wave, 64 and 256 CUs alike; 27.0 B/clk with 24 KiB)"
 
 
 def tower_pmc_traffic(kernel, boards):

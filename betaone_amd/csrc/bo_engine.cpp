@@ -1735,6 +1735,8 @@ static int tower_forward_impl(bo_tower *t, const float *x_dev, float *y_dev, voi
         // BETAONE_TOWER256_AR=8 keeps the old instance selectable for A/B runs.
         static const int ar256 = [] { const char *v = getenv("BETAONE_TOWER256_AR"); return (v && v[0] == '8') ? 8 : 4; }();
         if (t->algo == BO_TOWER_SPLIT_F16_T16)  // the same products as 16x16x32 tiles (bo_tower_s16.h: the chip holds a higher clock under them)
+            // (weight fragments 6 K-steps = 24 KiB per wave ahead; 12 ahead needs all 512 registers + 12 spilled and measured 185 us
+            // against 179 for a lone 64-board launch: profiles/r05_device_turn_and_tiles.md)
             hipLaunchKernelGGL((bo_k_tower_s16<6>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
         else if (t->channels == 256 && ar256 == 8) hipLaunchKernelGGL((bo_k_tower_s<256, 2, 0, 1, 8>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
         else if (t->channels == 256) hipLaunchKernelGGL((bo_k_tower_s<256, 2, 0, 1, 4>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);

@@ -449,6 +449,8 @@ class Engine:
     def autoturn_supported(self, temperature) -> bool:
         """The settings bo_selfplay_autoturn covers: the reference's search semantics with a root of <= 2 children, T_initial = 1, T_final > 0."""
         _, ti, tf = temperature
+        if os.environ.get("BETAONE_TURN_COPIES", "0") == "1":  # (the A/B switch that moves the turn's blocks by copy commands: host turn only)
+            return False
         return (not self.fast) and int(self.cfg.widen_coeff) == 1 and self.cfg.num_simulations >= 1 and abs(float(ti) - 1.0) < 1e-6 and float(tf) > 0.0
 
     def autoturn_ready(self) -> bool:
