@@ -16,6 +16,7 @@
 #include "bo_tower_h.h"
 #include "bo_tower_s.h"
 #include "bo_tower_s16.h"
+#include "bo_tower_h16.h"
 #include "bo_heads.h"
 #include "bo_tower_b1.h"
 #include "bo_rt.h"
@@ -67,6 +68,8 @@ struct bo_engine {
     int *h_go = nullptr;                      // pinned [G]
     int *h_action = nullptr;                  // pinned [2][G]: the actions of two consecutive bo_play calls (read by the kernel itself)
     int action_flip = 0;
+    rt_event ev_action[2]{};                  // behind the bo_k_play that reads each half: a third bo_play waits for the first one's kernel
+    bool ev_action_made[2] = {false, false};
     bool ship = true;                         // the turn's small blocks move by bo_k_ship instead of copy commands (BETAONE_TURN_COPIES=1: copies)
     bool prefetch_valid = false;              // bo_search_result_prefetch has been enqueued behind the searches and nothing was stepped since
     std::vector<int> h_nl, h_term;
@@ -345,6 +348,7 @@ extern "C" void bo_engine_destroy(bo_engine *e) {
     rt_host_free(e->h_res); rt_host_free(e->h_info); rt_host_free(e->h_noise); rt_host_free(e->h_go); rt_host_free(e->h_action);
     rt_host_free(e->h_turn_u); rt_host_free(e->h_turn_flags);
     if (e->ev_turn_made) rt_event_destroy(e->ev_turn);
+    for (int i = 0; i < 2; i++) if (e->ev_action_made[i]) rt_event_destroy(e->ev_action[i]);
     if (e->setup_dev) rt_free(e->setup_dev);
     if (e->setup_host) rt_host_free(e->setup_host);
     if (e->ev_begin_made) rt_event_destroy(e->ev_begin);
@@ -683,9 +687,13 @@ extern "C" int bo_search_result(bo_engine *e, int32_t *res_n, int32_t *res_idx, 
 extern "C" int bo_play(bo_engine *e, const int32_t *action, void *stream) {
     if (!e || !action) return fail(BO_E_ARG, "null argument");
     if (e->ship) {  // the kernel reads the actions from pinned host memory itself (two buffers: the previous call's kernel may not have run yet)
-        int *slot = e->h_action + (size_t)(e->action_flip ^= 1) * e->d.c.G;
+        const int half = (e->action_flip ^= 1);
+        int *slot = e->h_action + (size_t)half * e->d.c.G;
+        if (e->ev_action_made[half]) RT(rt_event_sync(e->ev_action[half]));  // (the kernel that read this half two calls ago has run: normally long since)
         memcpy(slot, action, (size_t)e->d.c.G * 4);
         RT(RT_LAUNCH(bo_k_play, e->d.c.G, stream, e->d, (const int *)slot));
+        if (!e->ev_action_made[half]) { RT(rt_event_create(&e->ev_action[half])); e->ev_action_made[half] = true; }
+        RT(rt_event_record(e->ev_action[half], stream));
     } else {
         RT(rt_h2d(e->d_action, action, (size_t)e->d.c.G * 4, stream));
         RT(RT_LAUNCH(bo_k_play, e->d.c.G, stream, e->d, (const int *)e->d_action));
@@ -1600,13 +1608,14 @@ extern "C" int bo_nn_tower_create(const bo_tower_layer_desc *layers, int n_layer
     static_assert(sizeof(bo_tower_layer_desc) == sizeof(bo_tower_layer), "descriptor layouts must agree");
     if (!layers || !weights || !params || !out || n_layers < 1 || n_layers > 4096) return fail(BO_E_ARG, "bad arguments");
     const bool split_w = algo == BO_TOWER_SPLIT_F16 || algo == BO_TOWER_SPLIT_F16_T16;
-    const bool half_w = algo == BO_TOWER_DIRECT_F16 || split_w;  // fp16 weight fragments, 16-byte offsets
+    const bool f16_w = algo == BO_TOWER_DIRECT_F16 || algo == BO_TOWER_DIRECT_F16_T16;
+    const bool half_w = f16_w || split_w;  // fp16 weight fragments, 16-byte offsets
     if (half_w ? (channels != 128 && channels != 256) : (channels != 64 && channels != 128))
         return fail(BO_E_CONFIG, "bo_nn_tower: channels must be 64 or 128 (fp32: two padded images per board in LDS) or 128 / 256 (BO_TOWER_DIRECT_F16, BO_TOWER_SPLIT_F16)");
     if (n_weights % 4) return fail(BO_E_ARG, "n_weights must be a multiple of 4");
     if (algo != BO_TOWER_DIRECT && algo != BO_TOWER_WINOGRAD && !half_w) return fail(BO_E_ARG, "unknown algo");
     if (algo == BO_TOWER_SPLIT_F16_T16 && channels != 128) return fail(BO_E_CONFIG, "BO_TOWER_SPLIT_F16_T16: 128 filters (other widths: BO_TOWER_SPLIT_F16)");
-    if (algo == BO_TOWER_DIRECT_F16 && !head) return fail(BO_E_ARG, "BO_TOWER_DIRECT_F16 needs the fused head (it has no tower output buffer)");
+    if (f16_w && !head) return fail(BO_E_ARG, "BO_TOWER_DIRECT_F16 needs the fused head (it has no tower output buffer)");
     const int C = channels;
     const int split = split_w ? 2 : 1;  // (hi, lo) fragment pairs; one more float (the inverse weight scale) behind every bias
     for (int l = 0; l < n_layers; l++) {  // every offset the kernel will form stays inside the two buffers
@@ -1712,14 +1721,18 @@ static int tower_forward_impl(bo_tower *t, const float *x_dev, float *y_dev, voi
     const int slots = t->n_cu * (t->channels == 64 && t->algo == BO_TOWER_DIRECT ? 2 : 1);  // direct, 64 filters: two 2-wave workgroups share a CU
     const unsigned grid = (unsigned)(batch < slots ? batch : slots);
     hipStream_t st = (hipStream_t)stream;
-    if (t->algo == BO_TOWER_DIRECT_F16) {  // two boards per workgroup
+    if (t->algo == BO_TOWER_DIRECT_F16 || t->algo == BO_TOWER_DIRECT_F16_T16) {  // two boards per workgroup
         bo_tower_head_h hh;
         hh.channels = t->head_channels; hh.split = t->head_split; hh.w_off8 = t->head_w_off; hh.b_off = t->head_b_off;
         hh.out_a = (_Float16 *)head_a_dev; hh.out_b = (_Float16 *)head_b_dev;
         const int pairs = (batch + 1) / 2;
         const unsigned g2 = (unsigned)(pairs < t->n_cu ? pairs : t->n_cu);
         const bo_h8 *w8 = reinterpret_cast<const bo_h8 *>(t->wts);
-        if (t->channels == 256) hipLaunchKernelGGL((bo_k_tower_h<256, 2>), dim3(g2), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, batch, hh);
+        static const int ar_h16 = [] { const char *v = getenv("BETAONE_TOWER_H16_AR"); return (v && atoi(v) == 6) ? 6 : 3; }();  // (LAB: ring depth of the 256-filter instance)
+        if (t->algo == BO_TOWER_DIRECT_F16_T16 && t->channels == 256 && ar_h16 == 6) hipLaunchKernelGGL((bo_k_tower_h16<256, 2, 6>), dim3(g2), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, batch, hh);
+        else if (t->algo == BO_TOWER_DIRECT_F16_T16 && t->channels == 256) hipLaunchKernelGGL((bo_k_tower_h16<256, 2, 3>), dim3(g2), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, batch, hh);
+        else if (t->algo == BO_TOWER_DIRECT_F16_T16) hipLaunchKernelGGL((bo_k_tower_h16<128, 1>), dim3(g2), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, batch, hh);
+        else if (t->channels == 256) hipLaunchKernelGGL((bo_k_tower_h<256, 2>), dim3(g2), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, batch, hh);
         else hipLaunchKernelGGL((bo_k_tower_h<128, 1>), dim3(g2), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, batch, hh);
         RT((int)hipGetLastError());
         return BO_OK;

@@ -80,6 +80,17 @@ def pack_conv_weight_f16(w: torch.Tensor) -> torch.Tensor:
     return u.permute(5, 2, 0, 3, 1, 4).contiguous().half()  # [tap][cg][mt][kg][o][i]
 
 
+def pack_conv_weight_f16_t16(w: torch.Tensor) -> torch.Tensor:
+    """[c_out, c_in, 3, 3] -> fp16 [9][c_in/32][c_out/16][64][8] (BO_TOWER_DIRECT_F16_T16: the A fragments of v_mfma_f32_16x16x32_f16):
+    element (tap, g, ot, lane, i) = W[16*ot + (lane & 15)][32*g + 8*(lane >> 4) + i][tap]."""
+    co, ci = w.shape[0], w.shape[1]
+    u = w.reshape(co // 16, 16, ci // 32, 4, 8, 9)  # [ot][o][g][kb][i][tap]
+    return u.permute(5, 2, 0, 3, 1, 4).contiguous().half()  # [tap][g][ot][kb][o][i]
+
+
+F16_TILE_DEFAULT = "32"  # which MFMA tile conv='tower_f16' multiplies with ("16": csrc/bo_tower_h16.h); BETAONE_F16_TILE overrides
+
+
 def split_scale(w: torch.Tensor) -> float:
     """The power of two s that puts the largest |s*w| in [2^14, 2^15) (BO_TOWER_SPLIT_F16: fp16 pairs of s*w)."""
     m = float(w.abs().max())
@@ -389,6 +400,8 @@ class FusedPolicyValueNet(nn.Module):
 
     def _build_tower_f16(self, dev):
         """fp16 tower (bo_nn_tower_create, BO_TOWER_DIRECT_F16) + half copies of the three head Linear layers."""
+        self.f16_tile = 16 if os.environ.get("BETAONE_F16_TILE", F16_TILE_DEFAULT) == "16" else 32
+        pack16 = pack_conv_weight_f16_t16 if self.f16_tile == 16 else pack_conv_weight_f16
         c = self.w_in.shape[0]
         if c not in (128, 256) or self.w_in.shape[1] != 120:
             raise E.EngineError("conv='tower_f16' supports 120 input planes and 128 or 256 filters")
@@ -413,10 +426,10 @@ class FusedPolicyValueNet(nn.Module):
 
         w0 = torch.zeros((c, 128, 3, 3))
         w0[:, :120] = self.w_in.detach().float().cpu()
-        layers.append([add_w(pack_conv_weight_f16(w0)), 9 * 128 // 16, add_p(self.b_in), 0, 0, 0, 0, 0])
+        layers.append([add_w(pack16(w0)), 9 * 128 // 16, add_p(self.b_in), 0, 0, 0, 0, 0])
         for w1, b1, w2, b2, se in self.blocks:
-            layers.append([add_w(pack_conv_weight_f16(w1.detach().float().cpu())), 9 * c // 16, add_p(b1), 1, 0, 0, 0, 0])
-            p2 = add_w(pack_conv_weight_f16(w2.detach().float().cpu()))
+            layers.append([add_w(pack16(w1.detach().float().cpu())), 9 * c // 16, add_p(b1), 1, 0, 0, 0, 0])
+            p2 = add_w(pack16(w2.detach().float().cpu()))
             if se is not None:
                 if se[0].shape[0] > 16:
                     raise E.EngineError("conv='tower_f16' supports SE hidden widths up to 16")
@@ -437,7 +450,7 @@ class FusedPolicyValueNet(nn.Module):
         table = np.ascontiguousarray(np.array(layers, dtype=np.int32))
         handle = C.c_void_p()
         rc = self.lib.bo_nn_tower_create(table.ctypes.data, len(layers), wts.ctypes.data, wts.size // 2, params.ctypes.data, params.size, c,
-                                         2, head.ctypes.data, dev.index if dev.index is not None else torch.cuda.current_device(), C.byref(handle))
+                                         (5 if self.f16_tile == 16 else 2), head.ctypes.data, dev.index if dev.index is not None else torch.cuda.current_device(), C.byref(handle))
         if rc:
             raise E.EngineError(self.lib.bo_last_error().decode())
         self.c, self._tower, self._tower_dev = c, handle, dev

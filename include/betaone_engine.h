@@ -146,7 +146,9 @@ int bo_search_result(bo_engine *e, int32_t *res_n, int32_t *res_idx, float *res_
 
 /* self_play.py:125-184: play action[g] (an index into the 4672 actions; -2 = play the search's
  * best move; -1 = leave the game alone) with the reference's decode-error / illegal-move
- * fallbacks, push it on the game's stack and tracker, prepare the next root.  Asynchronous. */
+ * fallbacks, push it on the game's stack and tracker, prepare the next root.  Asynchronous: the kernel reads the actions from a
+ * two-deep pinned ring of the engine's when it runs; a call whose half of the ring is still unread (two calls back-to-back without
+ * the device catching up) waits for that kernel first, so any number of calls may be enqueued. */
 int bo_play(bo_engine *e, const int32_t *action, void *stream);
 
 /* ---- per-move host work, natively -----------------------------------------------------------------
@@ -333,6 +335,8 @@ int bo_nn_conv3x3_small(const float *x_dev, const float *wpacked_dev, const floa
  *   holds a higher clock under them: profiles/r05_tower_bound.md); everything as for BO_TOWER_SPLIT_F16 except the per-layer fragment order
  *   [tap 9][c_in/32][C/16][2 = hi, lo][64][8]: element (tap, g, ot, hl, lane, i) = s*W[16*ot + (lane & 15)][32*g + 8*(lane >> 4) + i][tap]
  *   (t4 still counts K-steps of 16 channels: 9*c_in/16).
+ * algo BO_TOWER_DIRECT_F16_T16 (ABI 5, csrc/bo_tower_h16.h; 128 or 256 filters): BO_TOWER_DIRECT_F16 as 16x16x32 tiles; per-layer fragment order
+ *   [tap 9][c_in/32][C/16][64][8]: element (tap, g, ot, lane, i) = W[16*ot + (lane & 15)][32*g + 8*(lane >> 4) + i][tap]; head weights unchanged.
  * weights: float32 at float4 offset w_off4; params: float32 biases and SE matrices at float offsets.
  * head (optional, BO_TOWER_WINOGRAD only): the policy and value 1x1 convolutions + ReLU (network.py:101-113,191-195)
  *   fused behind the tower: bias [channels] and weights in params, the weights packed [ceil(channels/16)][C/16][64][4]
@@ -342,7 +346,7 @@ int bo_nn_conv3x3_small(const float *x_dev, const float *wpacked_dev, const floa
  * bo_nn_tower_create validates every offset and copies the three HOST arrays to `device`;
  * bo_nn_tower_forward(x_dev [batch,120,8,8] -> y_dev [batch,C,8,8], NCHW float32) is asynchronous on `stream`.
  * bo_nn_value_tail: out[b] = tanh(w . h[b] + bias[0]) (value_fc2 + tanh, network.py:116-118,197). */
-enum { BO_TOWER_DIRECT = 0, BO_TOWER_WINOGRAD = 1, BO_TOWER_DIRECT_F16 = 2, BO_TOWER_SPLIT_F16 = 3, BO_TOWER_SPLIT_F16_T16 = 4 };
+enum { BO_TOWER_DIRECT = 0, BO_TOWER_WINOGRAD = 1, BO_TOWER_DIRECT_F16 = 2, BO_TOWER_SPLIT_F16 = 3, BO_TOWER_SPLIT_F16_T16 = 4, BO_TOWER_DIRECT_F16_T16 = 5 };
 typedef struct bo_tower_layer_desc {
     int32_t w_off4, t4, bias_off, kind, se_w1_off, se_w2_off, hidden, last;
 } bo_tower_layer_desc;

@@ -46,6 +46,8 @@ for step in "$@"; do
               run stepprof_slow 400 python scripts/step_profile.py 640 100 300000 ;;
     trace)   mkdir -p $out/${tag}_trace; run trace 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace -- python bench.py --steps 200 --opening-steps 0 --no-cpu-baseline --no-roofline ;
              python scripts/kernel_percentiles.py $out/${tag}_trace > $out/${tag}_trace_percentiles.md 2>&1 ; rm -f $out/${tag}_trace/*/*_kernel_trace.csv.keep ; tail -n 40 $out/${tag}_trace_percentiles.md ;;
+    drvtrace) mkdir -p $out/${tag}_drvtrace; run drvtrace 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_drvtrace -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline ;
+             python scripts/kernel_percentiles.py $out/${tag}_drvtrace > $out/${tag}_drvtrace_percentiles.md 2>&1 ; cp $out/${tag}_drvtrace/*/*_kernel_stats.csv $out/${tag}_drvtrace_kernel_stats.csv 2>/dev/null ; rm -rf $out/${tag}_drvtrace ; tail -n 30 $out/${tag}_drvtrace_percentiles.md ;;
     pmcfast) mkdir -p $out/${tag}_pmcfast; run pmcfast 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex "bo_k_fw_select" --output-format csv -d $out/${tag}_pmcfast -- python bench.py --fast --preroll 2 --steps 1 --warmup 0 --opening-steps 0 --no-cpu-baseline --no-graph --roofline-steps 32 ;
              python scripts/pmc_summary.py $out/${tag}_pmcfast FETCH_SIZE 32 > $out/${tag}_pmcfast.md 2>&1 ; cat $out/${tag}_pmcfast.md ; rm -rf $out/${tag}_pmcfast ;;
     pmcfastw) mkdir -p $out/${tag}_pmcfastw; run pmcfastw 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --kernel-include-regex "bo_k_fw_select" --output-format csv -d $out/${tag}_pmcfastw -- python bench.py --fast --preroll 2 --steps 1 --warmup 0 --opening-steps 0 --no-cpu-baseline --no-graph --roofline-steps 32 ;

@@ -383,9 +383,10 @@ def test_split_precision_tower_reports_activations_beyond_the_fp16_range(backend
         config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = saved
 
 
+@pytest.mark.parametrize("tile", ["32", "16"])
 @pytest.mark.parametrize("size", [(2, 1, 128), (3, 2, 256)])
-def test_fp16_tower_matches_half_precision_net(backend, size):
-    """csrc/bo_tower_h.h (fp16 weights/activations, fp32 accumulation, two boards per workgroup) against the same net in
+def test_fp16_tower_matches_half_precision_net(backend, size, tile, monkeypatch):
+    """csrc/bo_tower_h.h / bo_tower_h16.h (both tilings; fp16 weights/activations, fp32 accumulation, two boards per workgroup) against the same net in
     float32 and against PyTorch's own float16 evaluation: its error vs the float32 net must be of the size of torch-fp16's
     own error (fp16 has 11 significand bits: outputs agree to ~1e-2 at these magnitudes, not 1e-4)."""
     import torch
@@ -399,7 +400,9 @@ def test_fp16_tower_matches_half_precision_net(backend, size):
     config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = size
     try:
         net = hash_init_(network.PolicyValueNet().eval()).to("cuda:0")
+        monkeypatch.setenv("BETAONE_F16_TILE", tile)
         fused = FusedPolicyValueNet(net, conv="tower_f16").to("cuda:0")
+        assert fused.f16_tile == int(tile)
         half = net.for_inference(dtype=torch.float16, channels_last=False)
         z = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "g1_net.npz"))
         base = torch.from_numpy(z["inputs"]).to("cuda:0")
