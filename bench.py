@@ -289,7 +289,7 @@ def nn_roofline(net, batch, device, timed=None, wall_us=None):
         torch.cuda.synchronize(device)
         per_graph, replays = 20, 4
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):  # (the RCCL watchdog thread may query events meanwhile)
             keep = [net._tower_forward(x, heads=heads) for _ in range(per_graph)]
         g.replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -524,6 +524,7 @@ def comm_census(dist, args, device, rank, world):
     every = [None] * world
     dist.all_gather_object(every, mine)
     distinct = len({(h, u) for h, _, u in every})
+    torch.cuda.synchronize(device)  # (the census is over before anything else is enqueued)
     return {"backend": dist.get_backend(), "world_size": world, "world_size_seen": int(round(float(one.item()))),
             "ranks_on_distinct_devices": distinct == world, "distinct_devices": distinct,
             "devices": [{"rank": r, "host": h, "device_index": i, "device_id": u} for r, (h, i, u) in enumerate(every)],

@@ -149,7 +149,7 @@ class _GraphStep:
         words = getattr(inner, "overflow_words", None)
         eng.watch(*(words() if words is not None else (0, 1)))
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):  # (other threads -- uci.py's stdin loop, a process group's watchdog -- are not held to capture-safe calls)
             self.out = _evaluate(model, nn_in)
             eng.step(self.out[0].data_ptr(), self.out[1].data_ptr(), self.kind, nn_in.data_ptr(),
                      torch.cuda.current_stream(dev).cuda_stream)

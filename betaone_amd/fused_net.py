@@ -88,7 +88,10 @@ def pack_conv_weight_f16_t16(w: torch.Tensor) -> torch.Tensor:
     return u.permute(5, 2, 0, 3, 1, 4).contiguous().half()  # [tap][g][ot][kb][o][i]
 
 
-F16_TILE_DEFAULT = "32"  # which MFMA tile conv='tower_f16' multiplies with ("16": csrc/bo_tower_h16.h); BETAONE_F16_TILE overrides
+# which MFMA tile conv='tower_f16' multiplies with, by filter count ("16": csrc/bo_tower_h16.h); BETAONE_F16_TILE overrides.  Same-box A/Bs
+# (profiles/r05_all_configs.md): 128 filters (fast mode) 4.78 s against 5.00 s per ply of 16 384 games with 16x16x32 tiles; 256 filters
+# (configs[4]) 13.0 against 12.2-12.5 ms -- the 256-filter instance of the new tiling spills registers.
+F16_TILE_DEFAULT = {128: "16", 256: "32"}
 
 
 def split_scale(w: torch.Tensor) -> float:
@@ -400,7 +403,7 @@ class FusedPolicyValueNet(nn.Module):
 
     def _build_tower_f16(self, dev):
         """fp16 tower (bo_nn_tower_create, BO_TOWER_DIRECT_F16) + half copies of the three head Linear layers."""
-        self.f16_tile = 16 if os.environ.get("BETAONE_F16_TILE", F16_TILE_DEFAULT) == "16" else 32
+        self.f16_tile = 16 if os.environ.get("BETAONE_F16_TILE", F16_TILE_DEFAULT.get(self.w_in.shape[0], "32")) == "16" else 32
         pack16 = pack_conv_weight_f16_t16 if self.f16_tile == 16 else pack_conv_weight_f16
         c = self.w_in.shape[0]
         if c not in (128, 256) or self.w_in.shape[1] != 120:

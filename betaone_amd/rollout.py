@@ -28,6 +28,13 @@ import torch
 from . import engine as E
 from . import sampling
 
+# hipGraph capture mode of every capture this package makes.  "thread_local": only the CAPTURING thread is held to capture-safe calls.
+# The default ("global") forbids capture-unsafe HIP calls in EVERY thread while a capture is open -- and torch.distributed's RCCL
+# watchdog thread polls its collectives' events (hipEventQuery) at any time: with a record exchange in flight, or right after the
+# bench's communicator census, a capture in global mode dies with "operation not permitted when stream is capturing" (found by the
+# N = 1 RCCL rehearsal of round 5; the N > 1 run would have hit it on every rank).
+CAPTURE_MODE = "thread_local"
+
 
 @dataclass
 class GameState:
@@ -262,7 +269,7 @@ class Rollout:
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
             logits, value = self._forward()
             self.eng.step(logits.data_ptr(), value.data_ptr(), self.policy_kind, self.nn_in.data_ptr(), self._stream())
         self._graph, self._logits, self._value = g, logits, value
@@ -297,7 +304,7 @@ class Rollout:
             if self._graph is None:
                 self._capture()  # warms the allocator / MIOpen up as well
             cg, keep = torch.cuda.CUDAGraph(), []
-            with torch.cuda.graph(cg):
+            with torch.cuda.graph(cg, capture_error_mode=CAPTURE_MODE):
                 for _ in range(n):
                     self._stamp(1)
                     logits, value = self._forward()
@@ -424,7 +431,7 @@ class Rollout:
             if self._graph is None:
                 self._capture()  # warms the allocator / MIOpen up as well
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                 logits, value = self._forward()
             self._fgraph, self._f_logits, self._f_value = g, logits, value
         self._fgraph.replay()
