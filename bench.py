@@ -823,6 +823,7 @@ def main():
             "games_per_hour_measured": (round(fin_timed * 3600.0 / dt, 1) if fin_timed else None),
             "mean_plies_of_finished_games": (round(fin_plies_timed / fin_timed, 1) if fin_timed else None),
             "step_ms_min_p50_p90_max": [round(float(x), 3) for x in (step_ms.min(), np.percentile(step_ms, 50), np.percentile(step_ms, 90), step_ms.max())],
+            "step_ms_each": ([round(float(x), 2) for x in step_ms] if len(step_ms) <= 64 else None),  # (host-side period of every timed step, in order)
             "games_finished_since_start": int(fin_all),
             "mean_plies_of_all_finished_games": (round(mean_len, 1) if mean_len else None),
             "games_per_hour_from_ply_rate": (round(plies / dt * 3600.0 / mean_len, 1) if mean_len else None),

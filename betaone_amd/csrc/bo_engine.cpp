@@ -1751,10 +1751,10 @@ static int tower_forward_impl(bo_tower *t, const float *x_dev, float *y_dev, voi
             // (weight fragments 6 K-steps = 24 KiB per wave ahead; 12 ahead needs all 512 registers + 12 spilled and measured 185 us
             // against 179 for a lone 64-board launch: profiles/r05_device_turn_and_tiles.md)
             hipLaunchKernelGGL((bo_k_tower_s16<6>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
-        else if (t->channels == 256 && ar256 == 8) hipLaunchKernelGGL((bo_k_tower_s<256, 2, 0, 1, 8>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
-        else if (t->channels == 256) hipLaunchKernelGGL((bo_k_tower_s<256, 2, 0, 1, 4>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
+        else if (t->channels == 256 && ar256 == 8) hipLaunchKernelGGL((bo_k_tower_s<256, 2, 1, 8>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
+        else if (t->channels == 256) hipLaunchKernelGGL((bo_k_tower_s<256, 2, 1, 4>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
         else  // (B operands read two K-steps ahead, weight fragments requested twelve ahead: profiles/r03_split_tower.md)
-            hipLaunchKernelGGL((bo_k_tower_s<128, 1, 0, 2, 12>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
+            hipLaunchKernelGGL((bo_k_tower_s<128, 1, 2, 12>), dim3(grid), dim3(256), 0, st, x_dev, w8, t->params, t->layers, t->n_layers, y_dev, batch, hs);
         RT((int)hipGetLastError());
         return BO_OK;
     }

@@ -58,11 +58,9 @@ __device__ inline void bo_split4_pos(const float (&v)[4], bo_h4 &hi, bo_h4 &lo, 
     }
 }
 
-// LAB (scripts/split_lab.hip only): 0 = the kernel; 1 = no weight loads; 2 = no B operand reads; 3 = B operand reads into a dead
-// register set (issued, never waited for by an MFMA); 4 = no epilogue; 5 = 1 + 2 + 4
 // BD = how many K-steps ahead of its MFMAs a B operand is read from LDS (1: two register sets; 2, 3: four);
 // AR = weight-fragment sets = how many K-steps ahead a weight fragment is requested (4 or 8, or 12 with the loop unrolled 24-fold)
-template <int C, int MT, int LAB = 0, int BD = 1, int AR = 8>
+template <int C, int MT, int BD = 1, int AR = 8>
 __global__ void __launch_bounds__(256)
 bo_k_tower_s(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const float *__restrict__ params,
              const bo_tower_layer *__restrict__ layers, int n_layers, float *__restrict__ y, int B, bo_tower_head_s head) {
@@ -90,7 +88,6 @@ bo_k_tower_s(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
     bo_h8 a[AR][MT][2];        // A fragments (hi, lo) of AR consecutive K-steps
     constexpr int BM = BD == 1 ? 1 : 3;
     bo_h8 bq[BM + 1][2][2];    // B operands of consecutive K-steps: [set][position half][hi | lo]
-    bo_h8 bdead[2][2];         // (LAB 3)
     float skip[MT][2][16];     // block input at this lane's (channels, positions), float32
     const int sw0 = bo_sw(cell0);  // (position n + 32 sits 4 rows further down: the same swizzle)
     // B operand address (in halves) of K-step j of a group of 8: tap cell offset `tc`, first channel group cg0 (a multiple of 8)
@@ -98,7 +95,6 @@ bo_k_tower_s(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bo_h8 *>(wts), 0, 0x7fffffff, 0x00020000);
     const int wvoff = ((wave * MT * 2) * 64 + lane) * 16;
     auto load_a = [&](int j, int w_off8, int step) {
-        if (LAB == 1 || LAB >= 5) return;
         typedef int bo_i32x4_t __attribute__((ext_vector_type(4)));
         const int soff = __builtin_amdgcn_readfirstlane((w_off8 + step * (C / 32) * 2 * 64) * 16);
 #pragma unroll
@@ -109,9 +105,7 @@ bo_k_tower_s(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
                 a[j][mt][hl] = __builtin_bit_cast(bo_h8, v);
             }
     };
-    auto read_b = [&](bo_h8(&b0)[2][2], int base, int j) {  // K-step j of the group whose b_base() is `base`
-        if (LAB == 2 || LAB >= 5) return;
-        bo_h8(&b)[2][2] = LAB == 3 ? bdead : b0;
+    auto read_b = [&](bo_h8(&b)[2][2], int base, int j) {  // K-step j of the group whose b_base() is `base`
         const _Float16 *p = X + (base ^ (j << 4));
         b[0][0] = *reinterpret_cast<const bo_h8 *>(p);
         b[0][1] = *reinterpret_cast<const bo_h8 *>(p + IMGH);
@@ -273,9 +267,7 @@ bo_k_tower_s(const float *__restrict__ x, const bo_h8 *__restrict__ wts, const f
                 if (__ballot(sat) != 0ull && lane == 0 && head.overflow) atomicOr(head.overflow, 1);
             };
             using std::integral_constant;
-            if (LAB >= 4) {
-                if (acc[0][0][0] == 123.456f) X[tid] = (_Float16)(acc[0][1][1] + acc[MT - 1][0][2] + acc[MT - 1][1][3] + (LAB == 3 ? (float)bdead[0][0][0] + (float)bdead[1][1][7] : 0.0f));
-            } else if (L.last && y) {
+            if (L.last && y) {
                 if (L.kind == 3) write_back(integral_constant<int, 3>{}, std::true_type{});
                 else write_back(integral_constant<int, 2>{}, std::true_type{});
             } else if (L.kind == 0) write_back(integral_constant<int, 0>{}, std::false_type{});

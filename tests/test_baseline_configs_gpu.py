@@ -109,6 +109,7 @@ LATE_GAME_FENS = [
     "8/8/4k3/8/8/3K4/8/6R1 w - - 98 80",                # halfmove clock 98: claimable fifty-move draws in the tree
     "k7/8/1K6/8/8/8/8/7R w - - 96 60",                  # mate in one AND the 50-move claim close
     "8/5k2/8/8/8/2K5/8/4R3 b - - 90 75",                # black to move, long reversible chains (repetition claims)
+    "r1bq1rk1/pp2bppp/2n1pn2/3p4/3P1B2/2PBPN2/PP1N1PPP/R2QK2R w KQ - 4 29",  # a middlegame that crosses the temperature threshold (fullmove 30) after three plies
 ]
 
 
@@ -281,6 +282,47 @@ def test_cohorts_on_their_own_streams_finish_the_games_of_the_single_rollout(env
         a, b = one[gid], many[gid]
         assert list(a.moves) == list(b.moves) and a.terminal == b.terminal and a.outcome == b.outcome, gid
         assert len(a.pis) == len(b.pis) == len(a.moves) - a.first_ply, gid
+        for (ia, va), (ib, vb) in zip(a.pis, b.pis):
+            assert ia.tolist() == ib.tolist() and va.view(np.uint32).tolist() == vb.view(np.uint32).tolist(), gid
+
+
+@pytest.mark.parametrize("cohorts", [1, 4])
+def test_device_turn_finishes_the_games_of_the_host_turn_on_the_bench_like_run(env, cohorts, monkeypatch):
+    """bo_selfplay_autoturn (the ply's turn as two kernels behind the searches: csrc/bo_tree.h bo_k_turn_sample / bo_k_turn_play) against
+    the host-made turn (bo_selfplay_turn; BETAONE_DEVICE_TURN=0), which the oracle replay above pins: the bench-like run -- 256 slots x
+    800 sims, the real net on the split-precision tower, captured graphs, refills on the side streams, late-game start positions whose
+    games cross the temperature threshold (fullmove 30: p ** 10 through the host-built table) and end by rule -- finishes the same games
+    either way: moves, pi bits, z, terminal code.  As one Rollout and as four cohorts on CU-masked streams."""
+    import torch
+    import network
+    from betaone_amd.fused_net import FusedPolicyValueNet
+    from betaone_amd.rollout import Rollout
+
+    config = env
+    config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 8, 2, 128
+    G, SIMS, LIMIT, PREROLL, STEPS = 256, 800, 28, 40, 36
+    torch.manual_seed(0)
+    net = FusedPolicyValueNet(network.PolicyValueNet().to("cuda:0").eval(), conv="tower_split").to("cuda:0")
+    seen = []
+    orig = Rollout._enqueue_autoturn
+
+    def counting(self, *a, **kw):
+        seen.append(1)
+        return orig(self, *a, **kw)
+
+    monkeypatch.setattr(Rollout, "_enqueue_autoturn", counting)
+    monkeypatch.setenv("BETAONE_DEVICE_TURN", "0")
+    host, fens_h, _, _, _ = _bench_like_run(net, G, SIMS, LIMIT, PREROLL, STEPS + (1 if cohorts > 1 else 0), (), record=False, cohorts=cohorts)
+    assert not seen
+    monkeypatch.setenv("BETAONE_DEVICE_TURN", "1")
+    dev, fens_d, _, _, _ = _bench_like_run(net, G, SIMS, LIMIT, PREROLL, STEPS + (1 if cohorts > 1 else 0), (), record=False, cohorts=cohorts)
+    assert len(seen) >= STEPS * cohorts  # (the device turn is what ran)
+    both = [gid for gid in host if gid in dev and fens_h.get(gid) == fens_d.get(gid)]
+    assert len(both) >= G and sum(1 for gid in both if host[gid].terminal != 0) >= 4
+    for gid in both:
+        a, b = host[gid], dev[gid]
+        assert list(a.moves) == list(b.moves) and a.terminal == b.terminal and a.outcome == b.outcome, gid
+        assert len(a.pis) == len(b.pis), gid
         for (ia, va), (ib, vb) in zip(a.pis, b.pis):
             assert ia.tolist() == ib.tolist() and va.view(np.uint32).tolist() == vb.view(np.uint32).tolist(), gid
 
