@@ -8,4 +8,4 @@ ROOT=$(cd "$HERE/../.." && pwd)
 "$HERE/build.sh" -fsanitize=address -fno-omit-frame-pointer -o /tmp/libbetaone_emu_asan.so
 cd "$ROOT"
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 \
-BO_EMU_LIB=/tmp/libbetaone_emu_asan.so python -m pytest tests/test_engine_emu.py tests/test_fast_mode_emu.py tests/test_hostrng.py -x -q "$@"
+BO_EMU_LIB=/tmp/libbetaone_emu_asan.so python -m pytest tests/test_engine_emu.py tests/test_fast_mode_emu.py tests/test_hostrng.py tests/test_device_turn_emu.py -x -q "$@"
