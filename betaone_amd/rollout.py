@@ -943,16 +943,20 @@ class CohortRollout:
 
     def _pick_ready(self, cands) -> int:
         """The first of `cands` (rotating start) whose enqueued work the device has finished; polls without blocking, then yields."""
-        spins = 0
+        t0 = None
         while True:
             for i in range(len(cands)):
                 k = cands[(self._rr + i) % len(cands)]
                 if self.parts[k].ply_ready():
                     self._rr = (self._rr + i + 1) % max(1, len(cands))
                     return k
-            spins += 1
-            if spins > 64:  # nothing is due for a while (a cohort-ply takes ~3 ms): leave the core to the side threads (record exchange,
-                time.sleep(20e-6)  # model watcher) and to the other ranks of the node instead of spinning on event queries
+            # Cohorts come due every ~0.7 ms: poll on (yielding the core between polls -- a timer sleep's wake-up latency would land on the
+            # device's critical path) for 2 ms; only a wait longer than that (a long search, a stalled device) backs off to 50 us sleeps,
+            # so that an idle rank does not hold a core at 100 % for the side threads' and the other ranks' account.
+            now = time.perf_counter()
+            if t0 is None:
+                t0 = now
+            time.sleep(0 if now - t0 < 2e-3 else 50e-6)
 
     def drain(self) -> int:
         """End every outstanding ply (no new searches are enqueued): the state then is what a sequence of whole plies leaves."""
