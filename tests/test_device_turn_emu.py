@@ -87,3 +87,40 @@ def test_device_turn_made_again_when_a_search_was_still_running():
     a, sa = _play(False, **kw)
     b, sb = _play(True, expected_evals=2, **kw)  # 1 + ceil(64 / 16) = 5 are needed: the first turns find searches running
     assert a == b and sa == sb
+
+
+def test_device_turn_calls_out_of_order_and_uncovered_settings_are_refused():
+    """bo_selfplay_autoturn's guards: one turn outstanding per engine (a second one, or the host-made turn, before the collect is
+    BO_E_STATE); a collect without a turn is BO_E_STATE; settings the device sampler does not cover (T_initial != 1, T_final = 0, a root
+    that may keep more than two children) are BO_E_CONFIG -- and Rollout routes those to the host-made turn by itself."""
+    from betaone_amd import engine as E
+
+    with H.emulator_backend():
+        eng = E.Engine(2, num_simulations=16, mcts_batch_size=8, max_plies=64)
+        eng.reset([0, 1])
+        nn_in = H.Buf("emu", (2, 120, 8, 8))
+        out = dict(n=np.zeros(2, np.int32), idx=np.zeros((2, E.RES_CAP), np.int32), val=np.zeros((2, E.RES_CAP), np.float32),
+                   best_idx=np.zeros(2, np.int32), action=np.zeros(2, np.int32))
+        go, mv = np.ones(2, np.int32), np.ones(2, np.int32)
+        with pytest.raises(E.EngineError, match="no bo_selfplay_autoturn outstanding"):
+            eng.autoturn_collect(out)
+        for bad in ((30, 0.5, 0.1), (30, 1.0, 0.0)):
+            assert not eng.autoturn_supported(bad)
+            with pytest.raises(E.EngineError, match="TEMPERATURE"):
+                eng.selfplay_autoturn(go, mv, bad, go, nn_in.ptr)
+        wide = E.Engine(1, num_simulations=16, mcts_batch_size=8, widen_coeff=2.0, max_plies=64)
+        assert not wide.autoturn_supported((30, 1.0, 0.1))
+        with pytest.raises(E.EngineError, match="WIDEN_COEFF"):
+            wide.selfplay_autoturn(go[:1], mv[:1], (30, 1.0, 0.1), go[:1], nn_in.ptr)
+        wide.close()
+        # a search that is still running when the turn comes up: nothing is played, the collect says so, the turn can be made again
+        nl, term, goo = eng.selfplay_begin(go, nn_in.ptr)
+        eng.selfplay_autoturn(goo, mv, (30, 1.0, 0.1), go, nn_in.ptr)
+        with pytest.raises(E.EngineError, match="has not been collected"):
+            eng.selfplay_autoturn(goo, mv, (30, 1.0, 0.1), go, nn_in.ptr)
+        with pytest.raises(E.EngineError, match="autoturn_collect"):
+            eng.selfplay_turn(goo, mv, (30, 1.0, 0.1), out, go, nn_in.ptr, poll_first=True, defer_noise=True)
+        assert eng.autoturn_ready()
+        assert eng.autoturn_collect(out) == (None, None)        # (the searches had not finished: no move was made)
+        assert eng.root_info()[2].tolist() == [0, 0]            # ... both games are still at ply 0
+        eng.close()
