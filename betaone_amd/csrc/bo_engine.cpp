@@ -755,7 +755,9 @@ struct BoPool {
     // and waiting for every one of them to report back costs a futex round trip (~30-50 us) the device idles through
     void run(int n, const std::function<void(int)> &f, bool light = false) {
         // (a fork()ed child inherits the object but not the threads: it works inline)
-        if (workers.empty() || n < 64 || (light && n <= 2048) || getpid() != owner) { for (int i = 0; i < n; i++) f(i); return; }
+        // (fewer than 256 items -- a cohort's 64 roots take ~40 us inline -- are not worth waking the workers for: their wake-up is ~50 us
+        //  at best and milliseconds when a worker's core sleeps deeply or is busy: p99 2.9 ms of bo_selfplay_noise, profiles/r05_logs/s16_plyprof.log)
+        if (workers.empty() || n < 256 || (light && n <= 2048) || getpid() != owner) { for (int i = 0; i < n; i++) f(i); return; }
         {
             std::lock_guard<std::mutex> l(m);
             job = &f; n_items = n; chunk = 8; next = 0; pending = (int)workers.size(); generation++;
