@@ -233,6 +233,7 @@ extern "C" int bo_engine_create(const bo_config *cfg, int device, bo_engine **ou
     }
     // (fast mode keeps its trees in child-block arenas, bo_fastw.h; the node arrays below then only hold the root's slot)
     c.NCAP = fast ? 2 : (int)ceil(c.S * per_sim) + 2 * root_m + 4;
+    c.nstride = c.NCAP;
     c.PLY_CAP = cfg->max_plies; c.TRK_CAP = cfg->max_plies;
     c.UL_MAX = fast ? 1 : c.B; c.CH_MAX = ch_max < 1 ? 1 : ch_max;
     c.cpuct = (float)cfg->cpuct;

@@ -44,6 +44,7 @@ enum { POLICY_NONE = 0, POLICY_LOGITS = 1, POLICY_PROBS = 2 };
 struct EngCfg {
     int G, S, B;                 // games, simulations per move, MCTS batch size
     int NCAP, PLY_CAP, TRK_CAP;  // nodes per game, positions per game, tracker entries per game
+    int nstride;                 // distance between two games' node blocks in the node arrays (= NCAP; a view of ONE game's block has 0)
     int UL_MAX, CH_MAX;          // cached evaluated leaves per game; children per expansion
     float cpuct, keep;           // f32(CPUCT), f32(1 - DIRICHLET_EPSILON)
     double eps;                  // DIRICHLET_EPSILON
@@ -93,7 +94,7 @@ struct Eng {
                                       // loop iterations, first visits.  profile = N > 1 counts only game-steps longer than N cycles
 };
 
-#define NOFF(e, g) ((size_t)(g) * (size_t)(e).c.NCAP)
+#define NOFF(e, g) ((size_t)(g) * (size_t)(e).c.nstride)
 
 // exp for the policy softmax: the hardware v_exp_f32 (exp2) path on gfx950, libm in the emulator build.  The
 // in-kernel softmax (policy_kind LOGITS) is held to the north-star tolerance (1e-4), not to bit-equality.
@@ -860,11 +861,9 @@ BO_DEV void apply_leaf(const Eng &e, int g, int leaf, const float *row, int kind
 // One step of every running search: consume the previous NN outputs (row g <-> game g), advance the
 // simulation loop until the game needs a new evaluation or its search is complete, and write the
 // requested leaf's planes into NN input row g.
-BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kind, float *nn_in) {
-    BO_SHARED StepShared sh;
-    const int g = bo_block();
+// (returns the game's node count when it leaves)
+BO_DEV int step_body(const Eng &e, int g, const float *policy, const float *value, int kind, float *nn_in, StepShared &sh) {
     const int lane = bo_lane();
-    if (e.phase[g] != PH_RUN) return;
     const size_t no = NOFF(e, g);
     int flags = 0;
     int sims = e.sims_done[g], rows = e.rows[g], n_runs = e.n_runs[g], n_ul = e.n_ul[g], n_nodes = e.n_nodes[g];
@@ -879,7 +878,7 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
     const unsigned long long t_start = tk;
 #define BO_PROF(slot)                                                    \
     if (prof) { const unsigned long long _n = bo_clock(); pc[slot] += _n - tk; tk = _n; }
-    if (req >= 0 && kind == POLICY_NONE) return;  // evaluation still outstanding
+    if (req >= 0 && kind == POLICY_NONE) return n_nodes;  // evaluation still outstanding
     const float *lut = e.sqrt_lut;  // (an LDS copy costs a round trip per launch; the table entry is requested with the children)
     if (req >= 0) {
         if (req == 0) apply_root(e, g, policy + (size_t)g * BO_NUM_ACTIONS, kind, sh, &n_nodes, &flags);
@@ -989,6 +988,13 @@ BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kin
         e.req_node[g] = req; e.phase[g] = phase;
         if (flags) e.status[g] |= flags;
     }
+    return n_nodes;
+}
+BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kind, float *nn_in) {
+    BO_SHARED StepShared sh;
+    const int g = bo_block();
+    if (e.phase[g] != PH_RUN) return;
+    step_body(e, g, policy, value, kind, nn_in, sh);
 }
 
 // Prepare the root of game g's next search from the top of its position stack: reset the tree,
