@@ -78,7 +78,10 @@ def parse():
     ap.add_argument("--cpu-cores", type=int, default=0, help="0 = the box's CPU share (affinity mask, at most 16)")
     ap.add_argument("--preroll", type=int, default=None, help="untimed plies played before warm-up to reach steady state (0 = opening phase; default 640, --fast: 10)")
     ap.add_argument("--opening-steps", type=int, default=20, help="plies of the labelled opening-only extra measurement (0 = skip)")
-    ap.add_argument("--softmax", default="torch", choices=["torch", "engine"], help="policy softmax: torch.softmax in the graph (the reference's op) or the step kernel's own")
+    ap.add_argument("--softmax", default="torch", choices=["torch", "engine"],
+                    help="policy softmax: in the evaluate stage (torch: torch.softmax as in the reference, or the stage's own head kernel bo_k_heads_rows: the "
+                         "seam the oracle replays are recorded at) or in the tree kernel that consumes the row (engine; with the hand-written float32 heads the "
+                         "step kernel then finishes the value head too, bo_step_heads -- same bits, same speed: profiles/r05_device_turn_and_tiles.md section 6)")
     ap.add_argument("--exchange-every", type=int, default=16, help="N>1: plies per record-exchange period")
     ap.add_argument("--dump-games", default="", help="write the move lists of finished games to this JSON file")
     ap.add_argument("--wide-trees", type=int, default=0, help="0 = 262144 if >= 150 GB of HBM is free, else 131072")
@@ -149,6 +152,15 @@ class CastIn(torch.nn.Module):
             return self.net(x)
         return self.net(x.to(self.dtype))
 
+    def tail_supported(self, batch):  # (logits, value_fc1 partial sums) for Engine.step_heads: passed through to a net that takes float32 planes
+        return bool(getattr(self.net, "wants_float32_input", False) and hasattr(self.net, "forward_tail") and self.net.tail_supported(batch))
+
+    def forward_tail(self, x):
+        return self.net.forward_tail(x)
+
+    def tail_params(self):
+        return self.net.tail_params()
+
     def forward_probs(self, x):  # (softmax(logits), value) where the net has its own fused form
         if hasattr(self.net, "forward_probs") and getattr(self.net, "wants_float32_input", False):
             return self.net.forward_probs(x)
@@ -159,6 +171,9 @@ class CastIn(torch.nn.Module):
 def softmax_site(net, args, rows):
     """Where the policy softmax of mcts.py:185,287 actually runs in this configuration (the label follows the code path)."""
     if args.softmax != "torch":
+        if not args.fast and hasattr(net, "forward_tail") and net.tail_supported(rows) and os.environ.get("BETAONE_STEP_TAIL", "1") != "0":
+            return ("bo_k_step (bo_step_heads: the wave that consumes a row finishes it -- softmax and the value head's last layer, bit for bit what "
+                    "bo_k_heads_rows writes; the evaluate stage ends behind bo_k_heads_tiles)")
         return "bo_k_step / bo_k_fw_apply (the tree kernel's own softmax over the row)"
     inner = getattr(net, "net", net)
     conv = getattr(inner, "conv", None)

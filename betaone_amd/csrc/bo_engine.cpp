@@ -548,10 +548,7 @@ static int launch_fw_select(bo_engine *e, const float *value_dev, int kind, void
 #undef SEL
 }
 
-extern "C" int bo_step(bo_engine *e, const float *policy_dev, const float *value_dev, int policy_kind, float *nn_in_dev,
-                       void *stream) {
-    if (!e || !nn_in_dev) return fail(BO_E_ARG, "null argument");
-    if (policy_kind != BO_POLICY_NONE && (!policy_dev || !value_dev)) return fail(BO_E_ARG, "policy/value required");
+static int step_launch(bo_engine *e, const float *policy_dev, const float *value_dev, int policy_kind, float *nn_in_dev, void *stream, const StepTail &vt) {
     e->prefetch_valid = false;  // (a prefetched result block is older than this step; replays of a captured step are the caller's to track)
     if (e->fast) {  // apply (one wave per row) -> backup + select (half a wave per game) -> leaf positions and planes (one wave per row)
         const int rows = e->d.c.G * e->f.L;
@@ -574,9 +571,22 @@ extern "C" int bo_step(bo_engine *e, const float *policy_dev, const float *value
 #endif
         RT(RT_LAUNCH(bo_k_fw_leaf, rows, stream, e->d, e->f, nn_in_dev));
     } else {
-        RT(RT_LAUNCH(bo_k_step, e->d.c.G, stream, e->d, policy_dev, value_dev, policy_kind, nn_in_dev));
+        RT(RT_LAUNCH(bo_k_step, e->d.c.G, stream, e->d, policy_dev, value_dev, policy_kind, nn_in_dev, vt));
     }
     return BO_OK;
+}
+extern "C" int bo_step(bo_engine *e, const float *policy_dev, const float *value_dev, int policy_kind, float *nn_in_dev,
+                       void *stream) {
+    if (!e || !nn_in_dev) return fail(BO_E_ARG, "null argument");
+    if (policy_kind != BO_POLICY_NONE && (!policy_dev || !value_dev)) return fail(BO_E_ARG, "policy/value required");
+    return step_launch(e, policy_dev, value_dev, policy_kind, nn_in_dev, stream, StepTail{nullptr, nullptr, nullptr, nullptr, 0});
+}
+extern "C" int bo_step_heads(bo_engine *e, const float *logits_dev, const float *vpart_dev, const float *b1_dev, const float *w2_dev,
+                             const float *b2_dev, int rows, float *nn_in_dev, void *stream) {
+    if (!e || !nn_in_dev || !logits_dev || !vpart_dev || !b1_dev || !w2_dev || !b2_dev) return fail(BO_E_ARG, "null argument");
+    if (e->fast) return fail(BO_E_CONFIG, "bo_step_heads: the reference-semantics search only (fast mode evaluates rows, not games)");
+    if (rows < e->d.c.G) return fail(BO_E_ARG, "bo_step_heads: the partial sums must hold a row per game (rows >= G)");
+    return step_launch(e, logits_dev, nullptr, BO_POLICY_LOGITS, nn_in_dev, stream, StepTail{vpart_dev, b1_dev, w2_dev, b2_dev, rows});
 }
 
 extern "C" int bo_search_poll(bo_engine *e, int32_t *n_running, int32_t *n_requested, int32_t *requested_mask, void *stream) {
@@ -2031,8 +2041,9 @@ extern "C" int bo_nn_heads(const void *p_dev, const void *v_dev, const float *wp
     (void)value_out_dev; (void)scratch_dev; (void)batch; (void)flags; (void)stream;
     return fail(BO_E_CONFIG, "bo_nn_heads is a gfx950-only kernel");
 #else
-    if (!p_dev || !v_dev || !wp_dev || !bp_dev || !w1_dev || !b1_dev || !w2_dev || !b2_dev || !policy_out_dev || !value_out_dev || !scratch_dev)
+    if (!p_dev || !v_dev || !wp_dev || !bp_dev || !w1_dev || !b1_dev || !w2_dev || !b2_dev || !policy_out_dev || (!value_out_dev && !(flags & 4)) || !scratch_dev)
         return fail(BO_E_ARG, "null argument");
+    if ((flags & 4) && (flags & 1)) return fail(BO_E_ARG, "bo_nn_heads: flags 4 (no rows kernel) leaves LOGITS: it excludes flags 1 (softmax)");
     if (batch < 1 || batch > 65536) return fail(BO_E_ARG, "bo_nn_heads: 1 <= batch <= 65536");
     bo_heads_args a;
     a.p = p_dev; a.v = v_dev; a.wp = wp_dev; a.bp = bp_dev; a.w1 = w1_dev; a.b1 = b1_dev; a.w2 = w2_dev; a.b2 = b2_dev;
@@ -2043,7 +2054,7 @@ extern "C" int bo_nn_heads(const void *p_dev, const void *v_dev, const float *wp
     const unsigned tiles = (unsigned)(((batch + a.pb - 1) / a.pb) * ((BO_HEADS_NA / 32 + otw - 1) / otw) + ((batch + 63) / 64) * 4 * BO_HEADS_KS);
     if (flags & 2) hipLaunchKernelGGL(bo_k_heads_tiles<true>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);   // fp16 head planes
     else hipLaunchKernelGGL(bo_k_heads_tiles<false>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
-    hipLaunchKernelGGL(bo_k_heads_rows, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, a);
+    if (!(flags & 4)) hipLaunchKernelGGL(bo_k_heads_rows, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, a);  // (4: bo_step_heads is the rows' consumer)
     RT((int)hipGetLastError());
     return BO_OK;
 #endif

@@ -209,7 +209,7 @@ bo_k_heads_rows(bo_heads_args a) {
         for (int u = 0; u < IT; u++) {
             if (tid + 256 * u < N4) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) { x[u][e] = expf(x[u][e] - mx); sum += x[u][e]; }
+                for (int e = 0; e < 4; e++) { x[u][e] = expf(x[u][e] - mx); sum += x[u][e]; }  // (bo_tree.h: row_load_max_sum keeps this exp and this order)
             }
         }
 #pragma unroll

@@ -106,15 +106,27 @@ BO_DEV float bo_expf(float x) {
 #endif
 }
 struct bo_f4 { float x, y, z, w; };
+// exp of the PARITY mode's row softmax: the accurate expf on both sides of the seam -- bo_k_heads_rows (bo_heads.h) writes
+// expf(x - max) / sum, and the step kernel's own softmax (policy_kind LOGITS) produces the SAME BITS from the same logits: same exp,
+// same order of the sum (below), same division.  That identity is what lets a run whose softmax is in the step kernel be compared
+// game for game with a run whose probabilities were recorded behind bo_k_heads_rows and replayed through the oracle.
+BO_DEV float bo_exp_row(float x) { return expf(x); }
 // max and sum(exp(x - max)) over one 4672-float policy row: 1168 float4 over 64 lanes.  All 19 loads of a lane are
 // issued before the first use (one memory round trip for the 18.7 KB row; as two dependent-looking loops the row
 // cost ~40 serial misses = 25 k cycles of a 87 k-cycle game-step) and both passes run from registers.
+// ORDER of the sum = bo_k_heads_rows' (256 threads, thread t takes float4 t + 256 u, adds its exps one by one, a 32..1 butterfly per
+// 64 threads, then (w0 + w1) + (w2 + w3)): lane l plays threads l, l + 64, l + 128, l + 192 -- its float4 number i belongs to thread
+// l + 64 (i & 3).
 #if defined(BO_WAVE_EMU)
 #define BO_UNROLL
 #else
 #define BO_UNROLL _Pragma("unroll")
 #endif
 constexpr int BO_ROW_N4 = BO_NUM_ACTIONS / 4, BO_ROW_IT = (BO_ROW_N4 + 63) / 64;
+BO_DEV float bo_wave_sum_desc_f(float v) {  // the head kernels' butterfly: partners 32, 16, .. 1
+    for (int m = 32; m >= 1; m >>= 1) v = v + bo_shfl_xor_f(v, m);
+    return v;
+}
 // v[] = this lane's float4s of the row (-inf beyond the end); returns max and sum(exp(x - max)) over the row
 BO_DEV void row_load_max_sum(const float *row, bo_f4 (&v)[BO_ROW_IT], float *mx_out, float *sum_out) {
     const bo_f4 *r4 = reinterpret_cast<const bo_f4 *>(row);
@@ -133,12 +145,18 @@ BO_DEV void row_load_max_sum(const float *row, bo_f4 (&v)[BO_ROW_IT], float *mx_
         mx = c > mx ? c : mx;
     }
     mx = bo_wave_max_f(mx);
-    float sum = 0.0f;
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     BO_UNROLL
     for (int i = 0; i < BO_ROW_IT; i++)
-        if (lane + 64 * i < BO_ROW_N4) sum += (bo_expf(v[i].x - mx) + bo_expf(v[i].y - mx)) + (bo_expf(v[i].z - mx) + bo_expf(v[i].w - mx));
+        if (lane + 64 * i < BO_ROW_N4) {
+            float t = s[i & 3];
+            t += bo_exp_row(v[i].x - mx); t += bo_exp_row(v[i].y - mx); t += bo_exp_row(v[i].z - mx); t += bo_exp_row(v[i].w - mx);
+            s[i & 3] = t;
+        }
+    BO_UNROLL
+    for (int w = 0; w < 4; w++) s[w] = bo_wave_sum_desc_f(s[w]);
     *mx_out = mx;
-    *sum_out = bo_wave_sum_f(sum);
+    *sum_out = (s[0] + s[1]) + (s[2] + s[3]);
 }
 BO_DEV void row_max_sum(const float *row, float *mx_out, float *sum_out) {
     bo_f4 v[BO_ROW_IT];
@@ -754,8 +772,8 @@ BO_DEV void load_probs(const float *row, int kind, float *out) {
         for (int i = 0; i < BO_ROW_IT; i++) {
             const int k = lane + 64 * i;
             if (k < BO_ROW_N4) {
-                out[4 * k] = bo_expf(v[i].x - mx) / sum; out[4 * k + 1] = bo_expf(v[i].y - mx) / sum;
-                out[4 * k + 2] = bo_expf(v[i].z - mx) / sum; out[4 * k + 3] = bo_expf(v[i].w - mx) / sum;
+                out[4 * k] = bo_exp_row(v[i].x - mx) / sum; out[4 * k + 1] = bo_exp_row(v[i].y - mx) / sum;
+                out[4 * k + 2] = bo_exp_row(v[i].z - mx) / sum; out[4 * k + 3] = bo_exp_row(v[i].w - mx) / sum;
             }
         }
     }
@@ -824,8 +842,43 @@ BO_DEV void apply_root(const Eng &e, int g, const float *row, int kind, StepShar
     bo_sync();
 }
 
+// The evaluate stage's TAIL inside the step (bo_step_heads): bo_k_heads_tiles has left the logits and the 16 K-chunk partial sums of
+// value_fc1; what bo_k_heads_rows would do with a board's row -- softmax, value = tanh(value_fc2(relu(sum of the chunks + bias))) --
+// the game's own wave does when (and only when) it consumes the row.  Same operations in the same order as bo_k_heads_rows
+// (thread t of its 256 <-> lane t & 63, pass t >> 6): the value's bits are the ones that kernel would have written.
+struct StepTail { const float *vpart, *b1, *w2, *b2; int rows; };  // vpart == NULL: the step reads value[g]
+struct TailRegs { float part[4][16], b1[4], w2[4], b2; };
+BO_DEV void tail_load(const StepTail &t, int g, TailRegs &r) {  // requests only: issued in front of the row's loads, one round trip for both
+    const int lane = bo_lane();
+    BO_UNROLL
+    for (int w = 0; w < 4; w++) {
+        BO_UNROLL
+        for (int ks = 0; ks < 16; ks++) r.part[w][ks] = t.vpart[((size_t)ks * t.rows + g) * 256 + lane + 64 * w];
+        r.b1[w] = t.b1[lane + 64 * w];
+        r.w2[w] = t.w2[lane + 64 * w];
+    }
+    r.b2 = t.b2[0];
+}
+BO_DEV float tail_value(const TailRegs &r) {
+    float s[4];
+    BO_UNROLL
+    for (int w = 0; w < 4; w++) {
+        float h = 0.0f;
+        BO_UNROLL
+        for (int ks = 0; ks < 16; ks++) h += r.part[w][ks];
+        h += r.b1[w];
+        s[w] = (h > 0.0f ? h : 0.0f) * r.w2[w];
+    }
+    for (int m = 32; m >= 1; m >>= 1) {  // the four butterflies side by side
+        BO_UNROLL
+        for (int w = 0; w < 4; w++) s[w] = s[w] + bo_shfl_xor_f(s[w], m);
+    }
+    return tanhf(((s[0] + s[1]) + (s[2] + s[3])) + r.b2);
+}
+
 // a leaf's evaluation arrives: keep its value and its CH_MAX best (move, prior) pairs until the flush
-BO_DEV void apply_leaf(const Eng &e, int g, int leaf, const float *row, int kind, float value, StepShared &sh, int *n_ul_io, int *flags) {
+BO_DEV void apply_leaf(const Eng &e, int g, int leaf, const float *row, int kind, const float *value_of, const StepTail &vt, StepShared &sh,
+                       int *n_ul_io, int *flags) {
     const size_t no = NOFF(e, g);
     const int lane = bo_lane();
     const int n = e.req_nlegal[g];
@@ -833,12 +886,22 @@ BO_DEV void apply_leaf(const Eng &e, int g, int leaf, const float *row, int kind
     int slot = *n_ul_io;
     if (slot >= e.c.UL_MAX) { *flags |= ST_UL_OVERFLOW; slot = e.c.UL_MAX - 1; }
     const size_t uo = (size_t)g * e.c.UL_MAX + slot;
+    float value;
     if (kind == POLICY_PROBS) {
+        value = value_of[g];
         for (int j = lane; j < n; j += 64) sh.pv[j] = row[move_to_index(mv[j])];
     } else {  // softmax restricted to what is needed: max and sum over the row, exp at the legal indices
         float mx, sum;
-        row_max_sum(row, &mx, &sum);
-        for (int j = lane; j < n; j += 64) sh.pv[j] = bo_expf(row[move_to_index(mv[j])] - mx) / sum;
+        if (vt.vpart) {  // bo_step_heads: the value's operands are requested in front of the row (one round trip for both)
+            TailRegs tr;
+            tail_load(vt, g, tr);
+            row_max_sum(row, &mx, &sum);
+            value = tail_value(tr);
+        } else {
+            value = value_of[g];
+            row_max_sum(row, &mx, &sum);
+        }
+        for (int j = lane; j < n; j += 64) sh.pv[j] = bo_exp_row(row[move_to_index(mv[j])] - mx) / sum;
     }
     bo_sync();
     const int M = n < e.c.CH_MAX ? n : e.c.CH_MAX;
@@ -862,7 +925,7 @@ BO_DEV void apply_leaf(const Eng &e, int g, int leaf, const float *row, int kind
 // simulation loop until the game needs a new evaluation or its search is complete, and write the
 // requested leaf's planes into NN input row g.
 // (returns the game's node count when it leaves)
-BO_DEV int step_body(const Eng &e, int g, const float *policy, const float *value, int kind, float *nn_in, StepShared &sh) {
+BO_DEV int step_body(const Eng &e, int g, const float *policy, const float *value, int kind, float *nn_in, StepShared &sh, const StepTail &vt) {
     const int lane = bo_lane();
     const size_t no = NOFF(e, g);
     int flags = 0;
@@ -882,7 +945,7 @@ BO_DEV int step_body(const Eng &e, int g, const float *policy, const float *valu
     const float *lut = e.sqrt_lut;  // (an LDS copy costs a round trip per launch; the table entry is requested with the children)
     if (req >= 0) {
         if (req == 0) apply_root(e, g, policy + (size_t)g * BO_NUM_ACTIONS, kind, sh, &n_nodes, &flags);
-        else apply_leaf(e, g, req, policy + (size_t)g * BO_NUM_ACTIONS, kind, value[g], sh, &n_ul, &flags);
+        else apply_leaf(e, g, req, policy + (size_t)g * BO_NUM_ACTIONS, kind, value, vt, sh, &n_ul, &flags);
         req = -1;
     }
     BO_PROF(0)
@@ -990,11 +1053,11 @@ BO_DEV int step_body(const Eng &e, int g, const float *policy, const float *valu
     }
     return n_nodes;
 }
-BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kind, float *nn_in) {
+BO_KERNEL void bo_k_step(Eng e, const float *policy, const float *value, int kind, float *nn_in, StepTail vt) {
     BO_SHARED StepShared sh;
     const int g = bo_block();
     if (e.phase[g] != PH_RUN) return;
-    step_body(e, g, policy, value, kind, nn_in, sh);
+    step_body(e, g, policy, value, kind, nn_in, sh, vt);
 }
 
 // Prepare the root of game g's next search from the top of its position stack: reset the tree,

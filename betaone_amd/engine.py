@@ -77,6 +77,7 @@ _SYMBOLS = {  # include/betaone_engine.h: the drop-in boundary
     "bo_root_info": (C.c_int, [C.c_void_p, _I32P, _I32P, _I32P, C.c_void_p]),
     "bo_search_begin": (C.c_int, [C.c_void_p, _I32P, _F64P, C.c_void_p, C.c_void_p]),
     "bo_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "bo_step_heads": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_void_p]),
     "bo_search_poll": (C.c_int, [C.c_void_p, _I32P, _I32P, _I32P, C.c_void_p]),
     "bo_search_stop": (C.c_int, [C.c_void_p, _I32P, _I32P, C.c_void_p]),
     "bo_search_result": (C.c_int, [C.c_void_p, _I32P, _I32P, _F32P, _I32P, _I32P, _I32P, C.c_void_p]),
@@ -163,7 +164,7 @@ def bind(cdll: C.CDLL) -> C.CDLL:
 
 
 _hip_lib: Optional[C.CDLL] = None
-ABI_VERSION = 5   # BO_ABI_VERSION of include/betaone_engine.h this binding was written against (tests/test_abi.py compares)
+ABI_VERSION = 6   # BO_ABI_VERSION of include/betaone_engine.h this binding was written against (tests/test_abi.py compares)
 PROF_SLOTS = 16   # BO_PROF_SLOTS
 
 
@@ -349,6 +350,10 @@ class Engine:
 
     def step(self, policy_ptr: int, value_ptr: int, kind: int, nn_in_ptr: int, stream: int = 0):
         self._check(self.lib.bo_step(self.h, policy_ptr, value_ptr, kind, nn_in_ptr, stream))
+
+    def step_heads(self, logits_ptr: int, vpart_ptr: int, b1_ptr: int, w2_ptr: int, b2_ptr: int, rows: int, nn_in_ptr: int, stream: int = 0):
+        """bo_step with the evaluate stage's tail (row softmax, value head's last layer) inside the step kernel (bo_step_heads)."""
+        self._check(self.lib.bo_step_heads(self.h, logits_ptr, vpart_ptr, b1_ptr, w2_ptr, b2_ptr, rows, nn_in_ptr, stream))
 
     def poll(self, stream: int = 0, want_mask: bool = True):
         run, req = C.c_int32(), C.c_int32()

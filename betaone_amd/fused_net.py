@@ -624,7 +624,9 @@ class FusedPolicyValueNet(nn.Module):
             raise E.EngineError(self.lib.bo_last_error().decode())
         return out
 
-    def _heads(self, p, v, probs):
+    def _heads(self, p, v, probs, tail=False):
+        """tail=True: stop behind the first launch -> (logits, value_fc1's partial sums [16, B, 256]); Engine.step_heads finishes the
+        row (softmax, value) in the step kernel that consumes it (bo_nn_heads flags 4)."""
         B = p.shape[0]
         dev = p.device
         # value_fc1 partial sums: allocated per call -- under graph capture it then comes from the graph's own pool (a module-wide
@@ -632,15 +634,33 @@ class FusedPolicyValueNet(nn.Module):
         # by concurrent streams); the caching allocator makes the eager cost a free-list lookup
         scr = torch.empty(4096 * B, dtype=torch.float32, device=dev)
         out = torch.empty((B, 4672), dtype=torch.float32, device=dev)
-        value = torch.empty((B, 1), dtype=torch.float32, device=dev)
+        value = None if tail else torch.empty((B, 1), dtype=torch.float32, device=dev)
         rc = self.lib.bo_nn_heads(p.data_ptr(), v.data_ptr(), self.policy_fc.weight.data_ptr(), self.policy_fc.bias.data_ptr(),
                                   self.value_fc1.weight.data_ptr(), self.value_fc1.bias.data_ptr(), self.value_fc2.weight.data_ptr(),
-                                  self.value_fc2.bias.data_ptr(), out.data_ptr(), value.data_ptr(), scr.data_ptr(), B,
-                                  (1 if probs else 0) | (2 if p.dtype == torch.float16 else 0),
+                                  self.value_fc2.bias.data_ptr(), out.data_ptr(), None if tail else value.data_ptr(), scr.data_ptr(), B,
+                                  (4 if tail else 1 if probs else 0) | (2 if p.dtype == torch.float16 else 0),
                                   torch.cuda.current_stream(dev).cuda_stream)
         if rc:
             raise E.EngineError(self.lib.bo_last_error().decode())
-        return out, value
+        return (out, scr.view(16, B, 256)) if tail else (out, value)
+
+    def tail_supported(self, batch: int) -> bool:
+        """forward_tail exists for this net at this batch: the evaluate stage ends in bo_nn_heads (the reference's head shapes,
+        float32 head weights; behind the fp16 tower up to 1024 boards)."""
+        ok = self.fused_heads and self.policy_fc.weight.shape == (4672, 128) and self.value_fc1.weight.shape == (256, 2048)
+        return bool(ok and (self.conv != "tower_f16" or batch <= 1024))
+
+    def tail_params(self):
+        """(value_fc1.bias, value_fc2.weight, value_fc2.bias) device pointers for Engine.step_heads (a captured graph holds copies of
+        them as it holds every other weight address of this module: Rollout.swap_model drops its graphs and reads these again)."""
+        return self.value_fc1.bias.data_ptr(), self.value_fc2.weight.data_ptr(), self.value_fc2.bias.data_ptr()
+
+    @torch.no_grad()
+    def forward_tail(self, x):
+        """(logits [B, 4672], partial sums of value_fc1 [16, B, 256]): the evaluate stage without its last launch."""
+        if not self.tail_supported(x.shape[0]):
+            raise E.EngineError(f"forward_tail: not available for conv={self.conv!r} at batch {x.shape[0]}")
+        return self.forward(x, tail=True)
 
     def _heads_f16(self, p, v, probs):
         B, dev = p.shape[0], p.device
@@ -714,7 +734,7 @@ class FusedPolicyValueNet(nn.Module):
         return self.forward(x, probs=True)
 
     @torch.no_grad()
-    def forward(self, x, probs: bool = False):
+    def forward(self, x, probs: bool = False, tail: bool = False):
         if self.conv == "tower_f16":
             p, v = self._tower_f16_forward(x)
             if self.fused_heads and p.shape[1] == 128 and v.shape[1] == 2048:
@@ -723,7 +743,7 @@ class FusedPolicyValueNet(nn.Module):
                 # hundred rows still fill the chip).  Beyond (fast mode: 4 096 .. 131 072 rows): fp16 weights on the fp16 pipe, the
                 # policy FC and its softmax fused per 32-board wave, the value head in one kernel (bo_heads.h) -- no library launch.
                 if p.shape[0] <= 1024:
-                    return self._heads(p, v, probs)
+                    return self._heads(p, v, probs, tail)
                 if os.environ.get("BETAONE_HEADS_F16", "1") != "0":  # (0: the library path below, for A/B runs)
                     return self._heads_f16(p, v, probs)
             logits = self.policy_fc_h(p)
@@ -731,7 +751,7 @@ class FusedPolicyValueNet(nn.Module):
         if self.conv in ("tower_wg", "tower_split"):  # tower + head convolutions in one kernel, then the heads
             p, v = self._tower_forward(x, heads=True)
             if self.fused_heads and p.shape[1] == 128 and v.shape[1] == 2048:
-                return self._heads(p, v, probs)  # policy FC + softmax + value head: one launch (csrc/bo_heads.h)
+                return self._heads(p, v, probs, tail)  # policy FC + softmax + value head: two launches (csrc/bo_heads.h)
             # the value head (2 small kernels) runs beside the policy GEMM: a fork/join of streams, also inside a captured graph
             cur = torch.cuda.current_stream(x.device)
             side = self.__dict__.get("_side")
@@ -754,7 +774,7 @@ class FusedPolicyValueNet(nn.Module):
             v = h[:, self.n_policy_ch:].flatten(1)
             if self.fused_heads and h.dtype == torch.float32 and p.shape[1] == 128 and v.shape[1] == 2048:
                 # (batch 1 -- uci.py's analysis -- : the slices are contiguous already; this replaces nine small launches)
-                return self._heads(p.contiguous(), v.contiguous(), probs)
+                return self._heads(p.contiguous(), v.contiguous(), probs, tail)
             logits = self.policy_fc(p)
             return (torch.softmax(logits.float(), dim=1) if probs else logits), torch.tanh(self.value_fc2(F.relu(self.value_fc1(v))))
         x = self._epi(F.conv2d(x, self.w_in, None, padding=1), self.b_in)

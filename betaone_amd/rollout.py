@@ -209,6 +209,25 @@ class Rollout:
         self._out = dict(n=np.zeros(G, np.int32), idx=np.zeros((G, E.RES_CAP), np.int32), val=np.zeros((G, E.RES_CAP), np.float32),
                          best_idx=np.zeros(G, np.int32), action=np.zeros(G, np.int32))
         self._watch_net()
+        self._set_tail()
+
+    def _set_tail(self):
+        """step_tail: the evaluate stage stops behind its logits / value_fc1 partial sums (model.forward_tail) and the step kernel
+        finishes the row it consumes -- softmax and value, the bits bo_k_heads_rows would have written (Engine.step_heads): one
+        launch and one pass over the [G, 4672] rows less per evaluation.  Engine softmax ("logits"), float32 evaluate stage with the
+        hand-written head kernels, reference-semantics search; BETAONE_STEP_TAIL=0 keeps the stage's own last launch (A/B runs)."""
+        m = self.model
+        ok = (self.policy_kind == E.POLICY_LOGITS and not self.fast and not self.autocast and self.device.type == "cuda"
+              and os.environ.get("BETAONE_STEP_TAIL", "1") != "0" and hasattr(m, "forward_tail") and m.tail_supported(self.G))
+        self.step_tail = bool(ok)
+        self._tail_params = tuple(m.tail_params()) if ok else None
+
+    def _step_after(self, first, second):
+        """The tree step behind an evaluation: (logits or probabilities, value) -> bo_step; (logits, partial sums) -> bo_step_heads."""
+        if self.step_tail:
+            self.eng.step_heads(first.data_ptr(), second.data_ptr(), *self._tail_params, second.shape[1], self.nn_in.data_ptr(), self._stream())
+        else:
+            self.eng.step(first.data_ptr(), second.data_ptr(), self.policy_kind, self.nn_in.data_ptr(), self._stream())
 
     def _watch_net(self):
         """The evaluate stage's own fault word (the split-precision tower: an activation beyond the fp16 range) travels with every
@@ -238,6 +257,9 @@ class Rollout:
         want_probs = self.policy_kind == E.POLICY_PROBS
         fused = getattr(self.model, "forward_probs", None) if (want_probs and not self.autocast) else None
         with torch.no_grad():
+            if self.step_tail:  # (logits, value_fc1's partial sums [16, G, 256]): _step_after hands both to the step kernel
+                logits, part = self.model.forward_tail(self.nn_in)
+                return logits, part
             if fused is not None:  # the evaluate stage places the softmax itself (beside its value head)
                 logits, value = fused(self.nn_in)
                 want_probs = False
@@ -256,7 +278,7 @@ class Rollout:
         logits, value = self._forward()
         self._stamp(2)
         self._logits, self._value = logits, value  # keep alive until the step kernel has run
-        self.eng.step(logits.data_ptr(), value.data_ptr(), self.policy_kind, self.nn_in.data_ptr(), self._stream())
+        self._step_after(logits, value)
         self._stamp(3)
 
     def _capture(self):
@@ -271,7 +293,7 @@ class Rollout:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
             logits, value = self._forward()
-            self.eng.step(logits.data_ptr(), value.data_ptr(), self.policy_kind, self.nn_in.data_ptr(), self._stream())
+            self._step_after(logits, value)
         self._graph, self._logits, self._value = g, logits, value
 
     def _eval_and_step(self):
@@ -309,7 +331,7 @@ class Rollout:
                     self._stamp(1)
                     logits, value = self._forward()
                     self._stamp(2)
-                    self.eng.step(logits.data_ptr(), value.data_ptr(), self.policy_kind, self.nn_in.data_ptr(), self._stream())
+                    self._step_after(logits, value)
                     self._stamp(3)
                     keep.append((logits, value))
             g = self._graphs_n[n] = (cg, keep)
@@ -459,7 +481,7 @@ class Rollout:
             if self.ply_profile is not None: self._pp("begun")
             self.eng.selfplay_noise(self._stream())
             if self.ply_profile is not None: self._pp("noise")
-            self.eng.step(self._f_logits.data_ptr(), self._f_value.data_ptr(), self.policy_kind, self.nn_in.data_ptr(), self._stream())
+            self._step_after(self._f_logits, self._f_value)
             burst -= 1
         while True:
             self._eval_and_step_n(burst)
@@ -763,6 +785,7 @@ class Rollout:
         self._logits = self._value = None
         self._fwd_early = False  # (a root evaluation enqueued early ran the old weights: it is repeated with the new ones)
         self._watch_net()
+        self._set_tail()
 
     @_on_main
     def check_net(self):

@@ -28,7 +28,7 @@ extern "C" {
  * [G][BO_PROF_SLOTS = 16] counters, the BO_TOWER_WINOGRAD packed-weight K order for 128 filters is winograd_k_order's;
  * 3: fast-mode arenas are allocated in 128-byte granules of 8 records, bo_fast_stats counts granules).  A caller checks
  * bo_abi_version() == BO_ABI_VERSION before anything else (tests/c_abi_smoke.c). */
-#define BO_ABI_VERSION 5
+#define BO_ABI_VERSION 6
 #define BO_NUM_ACTIONS 4672          /* config.NUM_ACTIONS, config.py:29 */
 #define BO_INPUT_CHANNELS 120        /* config.INPUT_CHANNELS, config.py:28 */
 #define BO_ROW_FLOATS (120 * 64)
@@ -125,6 +125,15 @@ int bo_search_begin(bo_engine *e, const int32_t *go, const double *noise, float 
  * policy_kind = BO_POLICY_NONE.  Asynchronous on `stream`. */
 int bo_step(bo_engine *e, const float *policy_dev, const float *value_dev, int policy_kind, float *nn_in_dev,
             void *stream);
+/* (ABI 6) bo_step with the TAIL of the evaluate stage inside the step kernel: behind bo_nn_heads(flags & 4) -- which stops after the
+ * logits and the partial sums of value_fc1 -- the wave that consumes a game's row does what the stage's rows kernel would have done
+ * with it: the softmax of mcts.py:185,287 (at the indices it needs) and value = tanh(value_fc2(relu(value_fc1 + bias)))
+ * (network.py:195-197).  Same float32 operations in the same order as bo_nn_heads' own second launch: the search sees the same
+ * bits either way (tests/test_baseline_configs_gpu.py), one launch and one pass over the rows less per evaluation.
+ * logits_dev [G,4672]; vpart_dev = bo_nn_heads' scratch_dev [16][rows][256] (rows = that call's batch >= G, row g <-> game g);
+ * b1_dev [256], w2_dev [256], b2_dev [1] = value_fc1.bias, value_fc2.weight, value_fc2.bias.  Reference-semantics engines only. */
+int bo_step_heads(bo_engine *e, const float *logits_dev, const float *vpart_dev, const float *b1_dev, const float *w2_dev,
+                  const float *b2_dev, int rows, float *nn_in_dev, void *stream);
 
 /* How many searches are still running / how many rows were requested by the last step.
  * requested_mask (optional, [G] int32) marks the rows the net must evaluate.  Synchronises. */
@@ -280,7 +289,9 @@ int bo_nn_se_residual_small(const float *x_dev, const float *bias_dev, const flo
  * [256] + bias [1], all float32 row-major on the device; policy_out [batch,4672], value_out [batch].  scratch_dev:
  * 4096 * batch floats (value_fc1's partial sums, no initial contents needed).  Any batch up to 65536.
  * flags: bit 0 = softmax; bit 1 (value 2) = p and v are float16 (the head planes of the BO_TOWER_DIRECT_F16 tower): they are
- * widened on load, weights, accumulation and outputs stay float32. */
+ * widened on load, weights, accumulation and outputs stay float32; bit 2 (value 4, ABI 6; excludes bit 0) = stop after the first
+ * launch: policy_out holds the logits, scratch_dev the partial sums, value_out_dev is not written (may be NULL) -- bo_step_heads
+ * finishes both where they are consumed. */
 int bo_nn_heads(const void *p_dev, const void *v_dev, const float *wp_dev, const float *bp_dev, const float *w1_dev,
                 const float *b1_dev, const float *w2_dev, const float *b2_dev, float *policy_out_dev, float *value_out_dev,
                 float *scratch_dev, int batch, int flags, void *stream);

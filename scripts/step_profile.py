@@ -11,7 +11,9 @@ warm = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 thr = int(sys.argv[3]) if len(sys.argv) > 3 else 1   # > 1: only game-steps longer than that many cycles
 _, net = bench.make_net("10x128", torch.device("cuda:0"), "fp32", 256)
-ro = Rollout(net, 256, num_simulations=800, mcts_batch_size=96, device="cuda:0", use_graph=False, rng_mode="native")
+ro = Rollout(net, 256, num_simulations=800, mcts_batch_size=96, device="cuda:0", use_graph=False, rng_mode="native",
+             policy_kind=os.environ.get("BO_PROFILE_KIND", "logits"))  # logits (+ BETAONE_STEP_TAIL=0 / 1) or probs
+print("policy_kind", os.environ.get("BO_PROFILE_KIND", "logits"), "step_tail", ro.step_tail)
 ro.start_games(list(range(256)), list(range(256)), list(range(256)))
 nid = [256]
 def refill(_s):

@@ -113,7 +113,10 @@ LATE_GAME_FENS = [
 ]
 
 
-def _bench_like_run(net, G, sims, max_game_moves, preroll, steps, watch, record, cohorts=1, cu_masks=None):
+_LAST_RUN = {}
+
+
+def _bench_like_run(net, G, sims, max_game_moves, preroll, steps, watch, record, cohorts=1, cu_masks=None, policy_kind="probs"):
     """bench.py's own step loop (bench.Driver: staggered pre-roll, finished games exported and their slots refilled on the side
     stream inside the run, n-iteration graphs, native RNG), with every 8th refilled game starting from a late-game position.
     record=True: the same run with the evaluate stage launched one iteration at a time and the seam of the `watch` slots read
@@ -121,9 +124,10 @@ def _bench_like_run(net, G, sims, max_game_moves, preroll, steps, watch, record,
     import bench
     from betaone_amd.rollout import CohortRollout, Rollout
 
-    kw = dict(num_simulations=sims, mcts_batch_size=96, device="cuda:0", use_graph=True, rng_mode="native", policy_kind="probs",
+    kw = dict(num_simulations=sims, mcts_batch_size=96, device="cuda:0", use_graph=True, rng_mode="native", policy_kind=policy_kind,
               max_game_moves=max_game_moves)
     ro = CohortRollout(net, G, cohorts=cohorts, cu_masks=cu_masks, **kw) if cohorts > 1 else Rollout(net, G, **kw)
+    _LAST_RUN["step_tail"] = all(p.step_tail for p in ro.parts) if cohorts > 1 else ro.step_tail
     rec = SeamRecorder(ro, watch) if record else None
     fens = {}
 
@@ -250,6 +254,47 @@ def test_bench_steady_state_path_with_refills_and_late_game_positions_matches_or
             assert rz == z and np.signbit(rz) == np.signbit(z), gid
         n_checked += 1
     assert n_checked >= 8 and late, (n_checked, late)
+
+
+@pytest.mark.parametrize("cohorts,cu_masks", [(1, None), (4, "contiguous")])
+def test_step_kernel_finishing_the_evaluate_stage_plays_the_games_of_the_recorded_seam(env, cohorts, cu_masks, monkeypatch):
+    """bench.py's default path since ABI 6: the evaluate stage ends behind bo_k_heads_tiles and bo_k_step finishes the row it consumes
+    (Rollout.step_tail: policy_kind "logits" + FusedPolicyValueNet.forward_tail -> Engine.step_heads).  Its softmax and value are
+    bo_k_heads_rows' operations in bo_k_heads_rows' order, so the bench-like steady-state run (256 slots x 800 sims, real 8+2 x 128 net,
+    refills, late-game positions) must finish, game for game and bit for bit, the games of the run whose probabilities and values were
+    written by bo_k_heads_rows -- the seam the test above records and replays through the CPU oracle.  Also with BETAONE_STEP_TAIL=0
+    (logits, value from the rows kernel, softmax in the step kernel): the same games."""
+    import torch
+    import network
+    from betaone_amd.fused_net import FusedPolicyValueNet
+
+    config = env
+    config.RESIDUAL_BLOCKS, config.SE_RESIDUAL_BLOCKS, config.CONV_FILTERS = 8, 2, 128
+    G, SIMS, LIMIT, PREROLL, STEPS = 256, 800, 28, 40, 36
+    torch.manual_seed(0)
+    net = FusedPolicyValueNet(network.PolicyValueNet().to("cuda:0").eval(), conv="tower_split").to("cuda:0")
+    seam, fens_s, _, _, _ = _bench_like_run(net, G, SIMS, LIMIT, PREROLL, STEPS, (), record=False)
+    assert _LAST_RUN["step_tail"] is False
+    tail, fens_t, _, _, n_graphs = _bench_like_run(net, G, SIMS, LIMIT, PREROLL, STEPS + (1 if cohorts > 1 else 0), (), record=False, cohorts=cohorts,
+                                                   cu_masks=cu_masks, policy_kind="logits")
+    assert _LAST_RUN["step_tail"] is True and n_graphs > 0
+    runs = [(tail, fens_t)]
+    if cohorts == 1:
+        monkeypatch.setenv("BETAONE_STEP_TAIL", "0")
+        mid, fens_m, _, _, _ = _bench_like_run(net, G, SIMS, LIMIT, PREROLL, STEPS, (), record=False, policy_kind="logits")
+        assert _LAST_RUN["step_tail"] is False
+        runs.append((mid, fens_m))
+    for other, fens_o in runs:
+        # (cohorts refill slots in another order: ids handed out in the same ply can meet different start positions -- compare the rest)
+        common = [gid for gid in seam if gid in other and fens_s.get(gid) == fens_o.get(gid)]
+        assert len(common) >= G and sum(1 for gid in common if gid >= G) >= G // 4 and (cohorts > 1 or sorted(seam) == sorted(other))
+        assert sum(1 for gid in common if seam[gid].terminal != 0) >= 4
+        for gid in common:
+            a, b = seam[gid], other[gid]
+            assert list(a.moves) == list(b.moves) and a.terminal == b.terminal and a.outcome == b.outcome, gid
+            assert len(a.pis) == len(b.pis), gid
+            for (ia, va), (ib, vb) in zip(a.pis, b.pis):
+                assert ia.tolist() == ib.tolist() and va.view(np.uint32).tolist() == vb.view(np.uint32).tolist(), gid
 
 
 @pytest.mark.parametrize("cohorts,cu_masks", [(2, None), (4, None), (4, "contiguous")])

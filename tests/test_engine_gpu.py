@@ -836,3 +836,82 @@ def test_masked_stream_runs_kernels_and_refuses_an_empty_mask(backend):
     zero = (ctypes.c_uint32 * len(masks[0]))()
     h = ctypes.c_void_p()
     assert ms.lib.bo_stream_create_cu_mask(0, zero, len(masks[0]), ctypes.byref(h)) != 0 and not h.value
+
+
+def test_step_heads_sees_the_bits_of_the_rows_kernel(backend):
+    """bo_step_heads (ABI 6): the evaluate stage stops behind bo_k_heads_tiles and the step kernel finishes the row it consumes.
+    Three engines search the same positions from the same head planes, one launch form each:
+      A  bo_nn_heads(softmax) -> probabilities, value -> bo_step(PROBS)      (the seam the oracle replays are recorded at)
+      B  bo_nn_heads(logits)  -> logits, value        -> bo_step(LOGITS)     (the step kernel's own softmax)
+      C  bo_nn_heads(flags 4) -> logits, partial sums -> bo_step_heads       (softmax AND value in the step kernel)
+    The three trees are the same bit for bit (visit counts, q, priors) after every search of a short game: the step kernel's softmax
+    and value are bo_k_heads_rows' operations in bo_k_heads_rows' order."""
+    import torch
+    from betaone_amd import engine as E
+    from engine_harness import canonical_tree
+
+    lib = E.load_hip_library()
+    dev = torch.device("cuda:0")
+    G, SIMS = 8, 300
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    rnd = lambda *s, k=1.0: (torch.randn(*s, generator=gen) * k).to(dev).contiguous()
+    wp, bp = rnd(4672, 128, k=0.35), rnd(4672, k=0.5)
+    w1, b1, w2, b2 = rnd(256, 2048, k=0.03), rnd(256, k=0.1), rnd(256, k=0.2), rnd(1, k=0.1)
+    mix_p, mix_v = rnd(120 * 64, 128, k=0.08), rnd(120 * 64, 2048, k=0.08)
+    fens = [None, "6k1/5ppp/8/8/8/8/5PPP/3R2K1 w - - 0 40", None, "r1bq1rk1/pp2bppp/2n1pn2/3p4/3P1B2/2PBPN2/PP1N1PPP/R2QK2R w KQ - 4 29",
+            "8/5k2/8/8/8/2K5/8/4R3 b - - 90 75", None, "7k/5Q2/5K2/8/8/8/8/8 w - - 10 70", None]
+    engs = [E.Engine(G, num_simulations=SIMS, mcts_batch_size=32, max_plies=64) for _ in range(3)]
+    nn_in = [torch.zeros((G, 120, 8, 8), dtype=torch.float32, device=dev) for _ in range(3)]
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def evaluate(k):
+        x = nn_in[k].flatten(1)
+        p, v = torch.relu(x @ mix_p).contiguous(), torch.relu(x @ mix_v).contiguous()  # ReLU'd head planes, a function of the position only
+        out = torch.empty((G, 4672), dtype=torch.float32, device=dev)
+        val = torch.full((G,), float("nan"), dtype=torch.float32, device=dev)
+        scr = torch.empty(4096 * G, dtype=torch.float32, device=dev)
+        flags = (1, 0, 4)[k]
+        rc = lib.bo_nn_heads(p.data_ptr(), v.data_ptr(), wp.data_ptr(), bp.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                             out.data_ptr(), None if k == 2 else val.data_ptr(), scr.data_ptr(), G, flags, st)
+        assert rc == 0, lib.bo_last_error().decode()
+        if k == 2:
+            engs[k].step_heads(out.data_ptr(), scr.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), G, nn_in[k].data_ptr(), st)
+        else:
+            engs[k].step(out.data_ptr(), val.data_ptr(), E.POLICY_PROBS if k == 0 else E.POLICY_LOGITS, nn_in[k].data_ptr(), st)
+        return out, val, scr
+
+    rc = lib.bo_nn_heads(wp.data_ptr(), wp.data_ptr(), wp.data_ptr(), bp.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                         wp.data_ptr(), None, wp.data_ptr(), G, 5, st)  # (refused before any launch)
+    assert rc != 0 and "excludes" in lib.bo_last_error().decode()
+    for e in engs:
+        e.reset(list(range(G)), fens)
+    rng = [np.random.RandomState(5) for _ in range(3)]
+    for ply in range(5):
+        trees = []
+        for k, e in enumerate(engs):
+            nl, term, _ = e.root_info()
+            go = (term == 0).astype(np.int32)
+            noise = np.zeros((G, E.MAX_LEGAL), dtype=np.float64)
+            for g in range(G):
+                if go[g]:
+                    noise[g, :nl[g]] = rng[k].dirichlet([0.3] * int(nl[g]))
+            e.search_begin(go, noise, nn_in[k].data_ptr(), st)
+            e.step(0, 0, E.POLICY_NONE, nn_in[k].data_ptr(), st)
+            keep = []
+            while e.poll(st, want_mask=False)[0]:
+                keep.append(evaluate(k))
+            e.check_status()
+            res = e.result(st)
+            trees.append(([canonical_tree(e.debug_tree(g)) for g in range(G)], res))
+            acts = np.where(go != 0, res["best_idx"], -1).astype(np.int32)
+            e.play(acts, st)
+        (ta, ra), (tb, rb), (tc, rc_) = trees
+        assert max(len(t) for t in ta) > 40
+        for g in range(G):
+            assert ta[g] == tb[g], (ply, g, "the step kernel's softmax differs from bo_k_heads_rows'")
+            assert tb[g] == tc[g], (ply, g, "the step kernel's value differs from bo_k_heads_rows'")
+        for key in ("n", "idx", "best_idx"):
+            assert ra[key].tolist() == rb[key].tolist() == rc_[key].tolist()
+        assert ra["val"].view(np.uint32).tolist() == rb["val"].view(np.uint32).tolist() == rc_["val"].view(np.uint32).tolist()
+    for e in engs:
+        e.close()
