@@ -279,21 +279,9 @@ def _union(iv):
     return tot + (ce - cs if ce is not None else 0.0)
 
 
-def nn_roofline(net, batch, device, timed=None, wall_us=None):
-    """MFMA roofline of the evaluate stage's tower kernel.  `achieved` / `frac` = ALGORITHMIC flops per launch (SURVEY.md section 8d:
-    2 x MACs of the tower's direct 3x3 convolutions) / the kernel's average launch duration IN THE TIMED REGION, which the kernel notes
-    itself (first workgroup's start, last workgroup's end, constant-rate device clock: `timed` = (durations us, intervals) from
-    tower_timings) -- event pairs cannot sit between the nodes of the captured graphs the timed region replays; rocprofv3's per-kernel
-    average of the same command is the check (profiles/).  With cohorts several launches of a share of the boards overlap: `concurrency` =
-    sum of durations / time with at least one launch running; `achieved` prices a launch against the chip's time per launch (see below).
-    `back_to_back_us`: the same kernel alone on the chip, replayed as 20 consecutive graph nodes."""
-    conv = getattr(net, "conv", None)
-    if conv not in ("tower", "tower_wg", "tower_split"):
-        return None
-    heads = conv in ("tower_wg", "tower_split")
-    C, n_conv = net.c, 1 + 2 * len(net.blocks)
+def _tower_back_to_back_us(net, batch, device, heads, per_graph=20, replays=4):
+    """The tower kernel alone on the chip at `batch` boards: `per_graph` consecutive graph nodes, `replays` replays, microseconds per launch."""
     x = torch.rand((batch, 120, 8, 8), device=device)
-    net.__dict__.pop("tower_timing_buf", None)
     with torch.no_grad():
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
@@ -302,7 +290,6 @@ def nn_roofline(net, batch, device, timed=None, wall_us=None):
                 net._tower_forward(x, heads=heads)
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
-        per_graph, replays = 20, 4
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):  # (the RCCL watchdog thread may query events meanwhile)
             keep = [net._tower_forward(x, heads=heads) for _ in range(per_graph)]
@@ -314,7 +301,36 @@ def nn_roofline(net, batch, device, timed=None, wall_us=None):
         e1.record()
         e1.synchronize()
         del keep
-    b2b = e0.elapsed_time(e1) * 1e3 / (per_graph * replays)
+    return e0.elapsed_time(e1) * 1e3 / (per_graph * replays)
+
+
+def nn_roofline(net, batch, device, timed=None, wall_us=None, all_boards=None, ply_us=None, launches_per_ply=None):
+    """MFMA roofline of the evaluate stage's tower kernel.  `achieved` / `frac` = ALGORITHMIC flops per launch (SURVEY.md section 8d:
+    2 x MACs of the tower's direct 3x3 convolutions) / the kernel's average launch duration IN THE TIMED REGION, which the kernel notes
+    itself (first workgroup's start, last workgroup's end, constant-rate device clock: `timed` = (durations us, intervals) from
+    tower_timings) -- event pairs cannot sit between the nodes of the captured graphs the timed region replays; rocprofv3's per-kernel
+    average of the same command is the check (profiles/).  With cohorts several launches of a share of the boards overlap: `concurrency` =
+    sum of durations / time with at least one launch running; `achieved` prices a launch against the chip's time per launch (see below).
+    `back_to_back_us`: the same kernel alone on the chip, replayed as 20 consecutive graph nodes.
+    `towers_only`: the same for ONE launch over all `all_boards` games of the GPU (every CU on the matrix pipe, nothing else on the chip)
+    x the evaluations a ply needs = the ply if the chip did nothing but towers, against the measured ply (`ply_us`)."""
+    conv = getattr(net, "conv", None)
+    if conv not in ("tower", "tower_wg", "tower_split"):
+        return None
+    heads = conv in ("tower_wg", "tower_split")
+    C, n_conv = net.c, 1 + 2 * len(net.blocks)
+    net.__dict__.pop("tower_timing_buf", None)
+    per_graph, replays = 20, 4
+    b2b = _tower_back_to_back_us(net, batch, device, heads, per_graph, replays)
+    towers_only = None
+    if all_boards and ply_us and launches_per_ply:
+        t_all = _tower_back_to_back_us(net, all_boards, device, heads, per_graph, replays)
+        towers_only = {"boards": all_boards, "lone_launch_us": round(t_all, 1), "evaluations_per_ply": round(launches_per_ply, 2),
+                       "ply_ms_if_towers_only": round(t_all * launches_per_ply / 1e3, 3), "ply_ms_measured": round(ply_us / 1e3, 3),
+                       "frac": round(t_all * launches_per_ply / ply_us, 3),
+                       "note": "one launch of this kernel over ALL the GPU's games, alone on the chip, back to back (every CU on the matrix pipe: the "
+                               "clock the chip holds then) x the evaluations one game's ply needs, against the ply of the timed region: what is left "
+                               "for better overlap of tree steps, heads and gaps -- the rest is the tower's own rate"}
     us, n_timed, how, conc = b2b, per_graph * replays, "20 consecutive graph nodes x 4 replays (no in-kernel timings for this kernel)", None
     if timed and timed[0]:
         dur, iv = timed
@@ -364,7 +380,7 @@ def nn_roofline(net, batch, device, timed=None, wall_us=None):
             "pipe_utilisation": round(executed / eff_us / 1e6 / peak, 4),
             "executed_tflops": round(executed / eff_us / 1e6, 1),
             "chip_us_per_launch": round(eff_us, 1),
-            "avg_launch_us": round(us, 1), "launches_timed": n_timed, "timing": how, "back_to_back_us": round(b2b, 1),
+            "avg_launch_us": round(us, 1), "launches_timed": n_timed, "timing": how, "back_to_back_us": round(b2b, 1), "towers_only": towers_only,
             "launch_us_p10_p50_p90": ([round(float(v), 1) for v in np.percentile(timed[0], [10, 50, 90])] if timed and timed[0] else None),
             "concurrency": (round(conc, 3) if conc else None),
             "share_of_wall_time": (round(_union(timed[1]) / wall_us, 4) if (conc and wall_us) else None),  # time with >= 1 tower launch running / the timed region
@@ -806,7 +822,8 @@ def main():
         if fast_roof is not None and args.select_sweep:
             fast_roof["variants"] = sweep
     if rank == 0 and not args.no_roofline and not args.fast and args.net_dtype == "fp32":
-        rn = nn_roofline(net, G // args.cohorts, device, timed, dt * 1e6)
+        rn = nn_roofline(net, G // args.cohorts, device, timed, dt * 1e6, all_boards=G, launches_per_ply=fwd / args.steps / max(args.cohorts, 1),
+                         ply_us=(long_run["ms_per_step"] * 1e3 if long_run else dt / args.steps * 1e6))
 
     out = None
     if rank == 0:
