@@ -659,11 +659,26 @@ BO_DEV void backup_run(const Eng &e, int g, int leaf, float v, int cnt, int *scr
         const float val = (i & 1) ? -v : v;
         int n = e.n_visits[no + nd];
         float qv = e.q[no + nd];
-        for (int c = 0; c < cnt; c++) {  // (the table division of the burst does not pay here: its reciprocal would be a load per step)
-            n += 1;
-            const float dd = val - qv;
-            const float ee = dd / (float)n;
-            qv = qv + ee;
+        // The recurrence's chain is subtract -> divide -> add, 96 times in a row; the general division is ~10 dependent operations of it.
+        // RN(1 / n) does not depend on the chain: the compiler runs that (correctly rounded) division beside it, and the quotient comes
+        // from bo_div_count's three dependent operations -- the same correctly rounded dd / n (same bits; Markstein, see above: checked
+        // for n <= 4100, beyond that the general division stays).
+        if (n + cnt <= 4100) {
+            for (int c = 0; c < cnt; c++) {
+                n += 1;
+                const float fn = (float)n;
+                const float y = 1.0f / fn;
+                const float dd = val - qv;
+                const float ee = bo_div_count(dd, fn, y);
+                qv = qv + ee;
+            }
+        } else {
+            for (int c = 0; c < cnt; c++) {
+                n += 1;
+                const float dd = val - qv;
+                const float ee = dd / (float)n;
+                qv = qv + ee;
+            }
         }
         e.n_visits[no + nd] = n;
         e.q[no + nd] = qv;

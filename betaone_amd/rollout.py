@@ -615,14 +615,19 @@ class Rollout:
         return self._turn_due is not None and (self._ply_event is None or self._ply_event.query())
 
     @_on_main
-    def ply_end(self, block: bool = True) -> Optional[int]:
+    def ply_end(self, block: bool = True, drop: Sequence[int] = ()) -> Optional[int]:
         """Second half of a ply: wait for the searches ply_begin enqueued (the ply's ONE host round trip), sample and play the
         moves, begin the next searches on the device and enqueue their root evaluation.  Returns the number of moves played.
         block=False (CohortRollout's scheduler): if a search turns out to need one more evaluation than was enqueued, enqueue it
-        and return None instead of waiting for it -- the ply stays due, ply_ready() tells when to call again."""
+        and return None instead of waiting for it -- the ply stays due, ply_ready() tells when to call again.
+        drop: slots whose game is being taken out of play (CohortRollout.retire): their search of the due ply counts for nothing --
+        no pi, no ply -- so a retired game carries the records a single Rollout, which retires between two plies, would give it."""
         eng, G = self.eng, self.G
         stream = self._stream()
         go, self._turn_due = self._turn_due, None
+        if len(drop):
+            go = go.copy()
+            go[list(drop)] = 0
         t0 = time.perf_counter()
         if self.ply_profile is not None: self._pp_t = t0
         move_number = self._start_full + (self._plies + self._start_black) // 2   # board.fullmove_number, self_play.py:104
@@ -992,7 +997,10 @@ class CohortRollout:
         k = g // self.Gc
         fin_cb, refill_cb = self._callbacks(k, on_finished, refill)
         if self.parts[k]._turn_due is not None:
-            self.parts[k].ply_end()  # (a game leaves between two plies: its cohort's outstanding ply is ended first)
+            # a game leaves between two plies: its cohort's outstanding ply is ended first -- without a turn for the leaving game (the
+            # single Rollout retires it before that ply begins: same moves, same records; a turn the device has already made for the
+            # slot was refused there for the reason the game is retired, or is discarded with the slot's reset)
+            self.parts[k].ply_end(drop=[g % self.Gc])
         self.parts[k].retire(g % self.Gc, fin_cb, refill_cb)
 
     def swap_model(self, model) -> None:

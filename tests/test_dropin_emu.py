@@ -534,6 +534,32 @@ def test_one_overlong_game_does_not_end_the_others():
             assert torch.equal(s1[98:112], s2[98:112])   # the current-position block; repetition planes of older blocks use the end-of-game tracker
 
 
+def test_overlong_games_keep_the_same_records_under_cohorts():
+    """a game retired for a full position stack (ENGINE_MAX_PLIES) is found while its cohort's NEXT ply is already
+    enqueued; CohortRollout.retire ends that ply without a turn for the leaving game (ply_end(drop=...)), so the game keeps exactly the
+    records the single Rollout gives it -- same number of examples, same pi, same outcome signs -- and every other game is untouched."""
+    config.NUM_SIMULATIONS, config.MCTS_BATCH_SIZE, config.MAX_GAME_MOVES = 24, 8, 7
+    model = FakeNet(scale=1.0, salt=29)
+    ids, seeds = list(range(7)), [40 + i for i in range(7)]
+    config.ENGINE_MAX_PLIES = 6
+    runs = []
+    try:
+        for cohorts in (1, 2):
+            config.COHORTS, config.COHORT_MIN_SLOTS = cohorts, 1
+            runs.append(self_play.run_self_play_games(model, ids, seeds=seeds, n_slots=4))
+    finally:
+        config.ENGINE_MAX_PLIES = None
+        config.COHORTS = 1
+        del config.COHORT_MIN_SLOTS
+    one, two = runs
+    assert sorted(one) == sorted(two) == ids
+    for g in ids:
+        assert one[g] is not None and two[g] is not None and 1 <= len(one[g]) < 7
+        assert len(one[g]) == len(two[g]), g
+        for (s1, p1, z1), (s2, p2, z2) in zip(one[g], two[g]):
+            assert torch.equal(s1, s2) and np.array_equal(p1, p2) and z1 == z2 and np.signbit(z1) == np.signbit(z2)
+
+
 def test_game_from_a_finished_position_yields_no_examples():
     """A start position that is already over: the reference's loop body never runs and the game returns zero examples
     (self_play.py:101,200-216); the batched native-RNG path must not attach a stale pi of the slot's previous occupant."""
