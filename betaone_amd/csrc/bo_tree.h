@@ -659,26 +659,14 @@ BO_DEV void backup_run(const Eng &e, int g, int leaf, float v, int cnt, int *scr
         const float val = (i & 1) ? -v : v;
         int n = e.n_visits[no + nd];
         float qv = e.q[no + nd];
-        // The recurrence's chain is subtract -> divide -> add, 96 times in a row; the general division is ~10 dependent operations of it.
-        // RN(1 / n) does not depend on the chain: the compiler runs that (correctly rounded) division beside it, and the quotient comes
-        // from bo_div_count's three dependent operations -- the same correctly rounded dd / n (same bits; Markstein, see above: checked
-        // for n <= 4100, beyond that the general division stays).
-        if (n + cnt <= 4100) {
-            for (int c = 0; c < cnt; c++) {
-                n += 1;
-                const float fn = (float)n;
-                const float y = 1.0f / fn;
-                const float dd = val - qv;
-                const float ee = bo_div_count(dd, fn, y);
-                qv = qv + ee;
-            }
-        } else {
-            for (int c = 0; c < cnt; c++) {
-                n += 1;
-                const float dd = val - qv;
-                const float ee = dd / (float)n;
-                qv = qv + ee;
-            }
+        // (Neither the burst's table division nor a reciprocal computed beside the chain pays here: one wave issues one instruction at a
+        // time, so the recurrence costs its instruction COUNT, and both forms add to it -- measured: flush 18.7 k -> 25.8 k cycles per
+        // game-step with RN(1 / n) by a second division off the chain, profiles/r05_device_turn_and_tiles.md section 7.)
+        for (int c = 0; c < cnt; c++) {
+            n += 1;
+            const float dd = val - qv;
+            const float ee = dd / (float)n;
+            qv = qv + ee;
         }
         e.n_visits[no + nd] = n;
         e.q[no + nd] = qv;

@@ -501,7 +501,8 @@ class PeriodicGameExchange:
         self.n_size_gathers = self.n_payload_gathers = 0
         self.blocked_ticks = 0  # ticks that found their collective unfinished (should stay 0)
 
-    def _tick(self, start_new: bool) -> List[dict]:
+    def _tick(self, start_new: bool, waiting: bool = False) -> List[dict]:
+        """waiting: the caller (flush) started the collective a moment ago and means to wait for it -- not a blocked tick."""
         out: List[dict] = []
         if not self.dist_on:
             if self._buf:
@@ -510,14 +511,14 @@ class PeriodicGameExchange:
             return out
         if self._payload is not None:
             sizes, g = self._payload
-            self.blocked_ticks += 0 if g.done() else 1
+            self.blocked_ticks += 0 if (waiting or g.done()) else 1
             rows = g.result(self.timeout_s)
             for r in range(self.world):
                 out.extend(unpack_games(rows[r, :sizes[r]].tobytes()))
             self._payload = None
         if self._sizes is not None:
             payload, g = self._sizes
-            self.blocked_ticks += 0 if g.done() else 1
+            self.blocked_ticks += 0 if (waiting or g.done()) else 1
             sizes = [int(x) for x in g.result(self.timeout_s).reshape(-1)]
             self._sizes = None
             mx = max(sizes)
@@ -539,7 +540,7 @@ class PeriodicGameExchange:
         return self._tick(True) if self._calls % self.every == 0 else []
 
     def flush(self) -> List[dict]:
-        return self._tick(True) + self._tick(False) + self._tick(False)
+        return self._tick(True) + self._tick(False, waiting=True) + self._tick(False, waiting=True)
 
 
 def shard_game_ids(n_games_total: int, rank: int, world: int) -> List[int]:
