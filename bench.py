@@ -700,6 +700,10 @@ def main():
     else:
         ids = [drv.new_id() for _ in range(G)]
         ro.start_games(list(range(G)), ids, ids)
+    import gc
+
+    gc.collect()  # (before the warm-up steps, not between them and the timed region: a full collection walks the heap and leaves the first
+    gc.disable()  # timed step with cold caches -- +0.2 ms on its first cohort; no cyclic-GC pause inside a 0.1 s timed region: up to 5 % of 20 steps)
     for _ in range(args.warmup):
         drv.step()
     if dist is not None:
@@ -711,19 +715,22 @@ def main():
     seq0 = [int(p.tower_timing[0].item()) for p in parts] if timing_on else None
     fin_pre = drv.n_finished
     s0, p0, f0, h0, n0, pf0 = ro.n_sims, ro.n_plies, ro.n_forward, ro.host_seconds, drv.n_finished, drv.plies_finished
-    import gc
-
-    gc.collect()
-    gc.disable()  # no cyclic-GC pause of the interpreter inside a 0.1 s timed region (it was worth up to 5 % of 20 steps)
     t0 = time.perf_counter()
     step_end = []
+    step_wait = []  # CohortRollout: the host's time without a ready cohort, per step
     for _ in range(args.steps):
+        w0 = getattr(ro, "wait_seconds", 0.0)
         drv.step()
         step_end.append(time.perf_counter())
+        step_wait.append(getattr(ro, "wait_seconds", 0.0) - w0)
     torch.cuda.synchronize(device)
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if os.environ.get("BO_PLY_PROFILE") == "trace":  # the host's phases inside the first two timed steps, in order
+        for a_, b_, who, name in Rollout.PLY_TRACE:
+            if t0 <= b_ <= step_end[min(1, len(step_end) - 1)]:
+                print(f"[ply trace] {(a_ - t0) * 1e6:8.0f} -> {(b_ - t0) * 1e6:8.0f} us  cohort {who}  {name}", file=sys.stderr, flush=True)
     gc.enable()
     timed = None
     if timing_on:  # the tower launches of the timed region, timed by the kernel itself
@@ -766,7 +773,7 @@ def main():
             acc[name].append(sec * 1e6)
         for name, v in acc.items():
             v.sort()
-            print("[ply profile] %-18s n %5d  p50 %8.1f  p90 %8.1f  p99 %8.1f  max %8.1f us" % (name, len(v), v[len(v) // 2], v[int(len(v) * 0.9)], v[int(len(v) * 0.99)], v[-1]),
+            print("[ply profile] %-18s n %5d  p50 %8.1f  p90 %8.1f  p99 %8.1f  max %8.1f  sum %10.1f us" % (name, len(v), v[len(v) // 2], v[int(len(v) * 0.9)], v[int(len(v) * 0.99)], v[-1], sum(v)),
                   file=sys.stderr, flush=True)
     host_frac = (ro.host_seconds - h0) / dt
 
@@ -855,7 +862,8 @@ def main():
             "games_per_hour_measured": (round(fin_timed * 3600.0 / dt, 1) if fin_timed else None),
             "mean_plies_of_finished_games": (round(fin_plies_timed / fin_timed, 1) if fin_timed else None),
             "step_ms_min_p50_p90_max": [round(float(x), 3) for x in (step_ms.min(), np.percentile(step_ms, 50), np.percentile(step_ms, 90), step_ms.max())],
-            "step_ms_each": ([round(float(x), 2) for x in step_ms] if len(step_ms) <= 64 else None),  # (host-side period of every timed step, in order)
+            "step_ms_each": ([round(float(x), 2) for x in step_ms] if (len(step_ms) <= 64 or os.environ.get("BO_ALL_STEPS")) else None),  # (host-side period of every timed step, in order)
+            "step_host_wait_ms_each": ([round(w * 1e3, 2) for w in step_wait] if (len(step_wait) <= 64 and hasattr(ro, "wait_seconds")) else None),  # (of which: no cohort was ready -- the host waited for the device)
             "games_finished_since_start": int(fin_all),
             "mean_plies_of_all_finished_games": (round(mean_len, 1) if mean_len else None),
             "games_per_hour_from_ply_rate": (round(plies / dt * 3600.0 / mean_len, 1) if mean_len else None),

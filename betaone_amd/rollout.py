@@ -458,9 +458,13 @@ class Rollout:
             self._fgraph, self._f_logits, self._f_value = g, logits, value
         self._fgraph.replay()
 
+    PLY_TRACE = []  # BO_PLY_PROFILE=trace: (time, cohort, phase-ended) of every phase boundary, every Rollout of the process
+
     def _pp(self, name):
         now = time.perf_counter()
         self.ply_profile.append((name, now - self._pp_t))
+        if os.environ.get("BO_PLY_PROFILE") == "trace":
+            Rollout.PLY_TRACE.append((self._pp_t, now, self._stamp_id, name))
         self._pp_t = now
 
     def _run_search_steps(self, poll: bool = True):
@@ -571,6 +575,7 @@ class Rollout:
         else:
             self._prefetch_result()
         self._mark_enqueued()
+        if self.ply_profile is not None: self._pp("enqueue_turn")
         return True
 
     def _device_turn_ok(self) -> bool:
@@ -644,6 +649,7 @@ class Rollout:
                     self._auto = False
                     break
                 self._fwd_early = False
+                if self.ply_profile is not None: self.ply_profile.append(("redo_turn", 0.0))
                 self._check_watch()  # (the turn also holds still when the evaluate stage's fault word is set: raise, play nothing)
                 self._eval_and_step()  # a search needed one more evaluation than expected: nothing was played; step, then the same turn again
                 self._enqueue_autoturn(go, redo=True)
@@ -897,6 +903,7 @@ class CohortRollout:
             torch.cuda.synchronize(self.device)  # (buffers zeroed on the constructing stream are used on the cohorts' streams from here on)
         self.eng = _CohortEngines(self.parts)
         self._rr = 0
+        self.wait_seconds = 0.0
         p0 = self.parts[0]
         self.S, self.B, self.L, self.fast = p0.S, p0.B, p0.L, p0.fast
         self.expected_evals, self.rng_mode, self.max_game_moves = p0.expected_evals, p0.rng_mode, p0.max_game_moves
@@ -977,6 +984,8 @@ class CohortRollout:
                 k = cands[(self._rr + i) % len(cands)]
                 if self.parts[k].ply_ready():
                     self._rr = (self._rr + i + 1) % max(1, len(cands))
+                    if t0 is not None:
+                        self.wait_seconds += time.perf_counter() - t0  # (the host's time without a ready cohort: the device is the bottleneck then)
                     return k
             # Cohorts come due every ~0.7 ms: poll on (yielding the core between polls -- a timer sleep's wake-up latency would land on the
             # device's critical path) for 2 ms; only a wait longer than that (a long search, a stalled device) backs off to 50 us sleeps,
