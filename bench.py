@@ -906,10 +906,12 @@ def main():
         else:
             # LAB kernel, run by no search: PUCT select alone over static synthetic trees (SURVEY.md section 8d's workload); the
             # product's select + backup kernel on grown trees is priced by `python bench.py --fast`
-            wide = select_roofline(args, device)
-            wide["kernel"] = "bo_k_select_wide (lab kernel: select only, static synthetic trees; no search runs it)"
+            # (N = 1 only, or when it is the only roofline there is: the other ranks of an N > 1 run wait in the closing barrier meanwhile)
+            wide = select_roofline(args, device) if (world == 1 or not rn) else None
+            if wide is not None:
+                wide["kernel"] = "bo_k_select_wide (lab kernel: select only, static synthetic trees; no search runs it)"
+                out["roofline_select_wide_synthetic"] = wide
             out["roofline"] = rn if rn else wide
-            out["roofline_select_wide_synthetic"] = wide
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.fast:  # "on rank 0 at N=1 only"
         out["cpu_baseline"] = cpu_baseline(args)
     elif rank == 0 and args.fast:
