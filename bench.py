@@ -437,6 +437,20 @@ def fast_select_measure(ro, drv, steps):
                 kids=d["kids"] / launches, pnodes=d["pnodes"] / launches, arena_bytes=c1["arena"] * eng.GRANULE_BYTES)
 
 
+FAST_PMC_JSON = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_fast_select_pmc.json")
+
+
+def fast_pmc_traffic(games, leaves):
+    """The committed PMC pass of bo_k_fw_select at this launch shape: (HBM-side bytes per launch, ratio to that pass's algorithmic bytes, source)."""
+    try:
+        for e in json.load(open(FAST_PMC_JSON)).get("launch_shapes", []):
+            if int(e.get("games", -1)) == int(games) and int(e.get("leaves_per_step", -1)) == int(leaves):
+                return float(e["hbm_side_bytes_per_launch"]), float(e["ratio_to_algorithmic"]), f"profiles/r05_fast_select_pmc.json ({e.get('source')})"
+    except Exception:
+        pass
+    return None, None, "no PMC pass of bo_k_fw_select at this launch shape is committed (scripts/gpu_round.sh pmcfast pmcfastw)"
+
+
 def fast_select_roofline(ro, drv, steps, label=""):
     """FAST mode: the select + backup kernel (csrc/bo_fastw.h: bo_k_fw_select) on the trees the searches of this run grew --
     no synthetic topology; virtual loss and backup included (SURVEY.md section 8d: 12 B per child scanned + 8 B per level;
@@ -445,8 +459,15 @@ def fast_select_roofline(ro, drv, steps, label=""):
     if m is None:
         return None
     ach = m["alg"] / m["t"] / 1e9
+    traffic, ratio, tsrc = fast_pmc_traffic(ro.G, ro.L)
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "traffic": None, "kernel": "bo_k_fw_select" + label,
+            "traffic": traffic, "traffic_source": tsrc,
+            # what the counters say the kernel moves per second at this run's launch duration (the PMC pass's ratio of HBM-side to algorithmic
+            # bytes x this run's algorithmic rate): the north star's "rocprof-reported HBM GB/s" -- beside `frac`, never instead of it
+            "hbm_side": ({"GBps": round(ach * ratio, 1), "frac_of_peak": round(ach * ratio / HBM_PEAK_GBS, 4), "ratio_to_algorithmic": ratio,
+                          "note": "FETCH_SIZE x 2 + WRITE_SIZE of the committed PMC pass over that pass's algorithmic bytes, applied to this run's rate: "
+                                  "the kernel keeps this much of the HBM busy; `frac` counts only the bytes the algorithm needs"} if ratio else None),
+            "kernel": "bo_k_fw_select" + label,
             "workload": f"the search trees of this run ({ro.G} games x {ro.L} descents per launch under a virtual loss, backup of the previous "
                         f"launch's simulations in the same kernel; arenas of 128-byte granules, {m['arena_bytes'] / 1e9:.2f} GB live); "
                         f"bytes = 12 B x children scanned + 8 B x levels + 16 B x path nodes; the kernel requests whole 128-byte record granules",
