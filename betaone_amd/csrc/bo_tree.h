@@ -659,9 +659,10 @@ BO_DEV void backup_run(const Eng &e, int g, int leaf, float v, int cnt, int *scr
         const float val = (i & 1) ? -v : v;
         int n = e.n_visits[no + nd];
         float qv = e.q[no + nd];
-        // (Neither the burst's table division nor a reciprocal computed beside the chain pays here: one wave issues one instruction at a
-        // time, so the recurrence costs its instruction COUNT, and both forms add to it -- measured: flush 18.7 k -> 25.8 k cycles per
-        // game-step with RN(1 / n) by a second division off the chain, profiles/r05_device_turn_and_tiles.md section 7.)
+        // (The compiler's general division stays: both cheaper-looking forms of the quotient measured SLOWER in this loop -- RN(1 / n) by a second
+        // division beside the chain + bo_div_count: flush 18.7 k -> 25.8 k cycles per game-step; RN(1 / n) from the host-built table, requested
+        // eight iterations ahead, + bo_div_count: 22.0 k.  bo_div_count's guards (zero dividend, tiny quotient -> general division) cost
+        // more per iteration than the general sequence they replace.  profiles/r05_device_turn_and_tiles.md section 7.)
         for (int c = 0; c < cnt; c++) {
             n += 1;
             const float dd = val - qv;
