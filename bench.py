@@ -99,7 +99,7 @@ def parse():
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--long-run-steps", type=int, default=None,
                     help="plies of the confirmation leg run AFTER the timed steps (same workload, same timing brackets; reported as long_run); "
-                         "default 1000 at N=1 with the default workload, 0 elsewhere")
+                         "default 2000 at N=1 with the default workload (~5.5 s of GPU work: longer than a 5-second utilisation sampler's period), 0 elsewhere")
     args = ap.parse_args()
     # --fast is priced on its own workload: enough resident games for the select + backup kernel to be
     # bandwidth-bound (a descent is a chain of dependent reads), a small fp16 net so that the evaluate stage does not starve it
@@ -116,9 +116,9 @@ def parse():
         args.steps, args.warmup = 1, 0  # (a ply of 32768 games x 800 simulations is 26 M evaluations: ~12 s)
     if args.fast and args.opening_steps == 20:
         args.opening_steps = 0          # (the opening-only extra would be twenty such plies)
-    if args.long_run_steps is None:     # ~3 s of the default workload; off for other workloads, N > 1 and with measurement switches off
+    if args.long_run_steps is None:     # ~5.5 s of the default workload; off for other workloads, N > 1 and with measurement switches off
         default_workload = (not args.fast and args.gpus == 1 and (args.games, args.sims, args.net, args.net_dtype) == (256, 800, "10x128", "fp32"))
-        args.long_run_steps = 1000 if (default_workload and args.preroll > 0 and not args.no_roofline) else 0
+        args.long_run_steps = 2000 if (default_workload and args.preroll > 0 and not args.no_roofline) else 0
     return args
 
 
