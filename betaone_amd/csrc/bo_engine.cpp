@@ -1348,8 +1348,15 @@ extern "C" int bo_debug_fast(bo_engine *e, int slot, int32_t *ctl_out, int32_t c
         if (ctl_cap < f.CS) return fail(BO_E_ARG, "control block buffer too small");
         RT(rt_d2h(ctl_out, f.ctl + (size_t)slot * f.CS, (size_t)f.CS * 4, stream));
     }
-    if (paths_out) RT(rt_d2h(paths_out, f.sim_path + (size_t)slot * f.L * BO_FW_PATH_CAP, (size_t)f.L * BO_FW_PATH_CAP * 4, stream));
+    std::vector<int32_t> dm;  // the device keeps the path rows depth-major (FW_PIDX); this call hands them out simulation-major [L][PATH_CAP] as it always has
+    if (paths_out) {
+        dm.resize((size_t)f.L * BO_FW_PATH_CAP);
+        RT(rt_d2h(dm.data(), f.sim_path + (size_t)slot * f.L * BO_FW_PATH_CAP, dm.size() * 4, stream));
+    }
     RT(rt_sync(stream));
+    if (paths_out)
+        for (int s = 0; s < f.L; s++)
+            for (int d = 0; d < BO_FW_PATH_CAP; d++) paths_out[(size_t)s * BO_FW_PATH_CAP + d] = dm[FW_PIDX(f.L, s, d)];
     return BO_OK;
 }
 

@@ -95,6 +95,10 @@ enum { FWR_SLOT = 0,    // leaf record of row r
        FWS_PLEN = 6,    // its path length
        FWR_FIELDS = 7 };
 #define FWC_F(L, field, i) (FWC_HEAD + (field) * (L) + (i))
+// index of (simulation s, depth d) in a game's block of FastW::sim_path.  Depth-major: the L simulations' record ids of one depth are
+// adjacent, so the depths a step's paths actually reach (~3 of 64) x L ids are ONE 128-byte line per game for the backup to fetch and
+// for the descents to write -- simulation-major they were L lines 256 bytes apart.
+#define FW_PIDX(L, s, d) ((size_t)(d) * (size_t)(L) + (size_t)(s))
 
 struct FastW {
     int L, NG, CS;             // leaves per game per step; granules per arena; ints per control block (a multiple of 32)
@@ -105,7 +109,7 @@ struct FastW {
     const float *sqrt_tab, *rcp_tab;  // [BO_FW_SQRT_TAB] RN(sqrt(n)); [BO_FW_RCP_TAB] RN(1 / k), entry 0 = 0
     DPos *row_pos;             // [G][L] position of row r's leaf
     bo_mv *row_moves;          // [G][L][256] its legal moves (python-chess order)
-    int *sim_path;             // [G][L][PATH_CAP] record ids root..leaf (record id = granule * GR + index)
+    int *sim_path;             // [G][PATH_CAP][L] record ids root..leaf, DEPTH-major (record id = granule * GR + index): FW_PIDX
     int *played_now;           // [G] move played by the last bo_k_play (0: none); the same array as Eng::played_now
 };
 
@@ -315,7 +319,7 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
             BO_UNROLL
             for (int a = 0; a < 2; a++) root2[u][a] = fw_ld<false>(f.arena + fw_arena_off(f, gg, a));
             BO_UNROLL
-            for (int j = 0; j < BO_FW_BK_CH; j++) pid[u][j] = f.sim_path[((size_t)gg * L + (j < L ? j : L - 1)) * BO_FW_PATH_CAP + c];
+            for (int j = 0; j < BO_FW_BK_CH; j++) pid[u][j] = f.sim_path[(size_t)gg * L * BO_FW_PATH_CAP + FW_PIDX(L, j < L ? j : L - 1, c)];
             BO_UNROLL
             for (int k = 0; k < NCR; k++) creg[u][k] = c + W * k < f.CS ? ctl[c + W * k] : 0;
             BO_UNROLL
@@ -386,7 +390,7 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
                         const int cd = c + W * ds;
                         val[u][j][ds] = cd >= 1 && cd < plen;  // the root (depth 0) only counts visits
                         sgn[u][j][ds] = ((plen - 1 - cd) & 1) ? -v : v;
-                        rec[u][j][ds] = val[u][j][ds] ? ((s0 == 0 && ds == 0) ? pid[u][j] : sp[(size_t)s * BO_FW_PATH_CAP + cd]) : 0;
+                        rec[u][j][ds] = val[u][j][ds] ? ((s0 == 0 && ds == 0) ? pid[u][j] : sp[FW_PIDX(L, s, cd)]) : 0;
                     }
                 }
             }
@@ -431,7 +435,7 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
                     if (q >= 0) { const int t = FW_C(u, FWC_F(L, FWR_TERM, q)); v = t > 0 ? (t == 1 ? 1.0f : 0.0f) : -s_val[FW_SLOT(u)][q]; }
                     else v = q == FW_SIM_MATE ? 1.0f : 0.0f;
                     for (int k = c + W * DS; k < plen; k += W) {
-                        WRec *R = FW_A(u) + sp[(size_t)s * BO_FW_PATH_CAP + k];
+                        WRec *R = FW_A(u) + sp[FW_PIDX(L, s, k)];
                         const fw_nw y = fw_ld_nw(R);
                         fw_st_nw(R, y.n + 1, y.w + (((plen - 1 - k) & 1) ? -v : v));
                     }
@@ -669,7 +673,7 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
             const int leaf = first * BO_FW_GR + win;
             if (lv && c == 0) {
                 reinterpret_cast<unsigned char *>(&s_idx[slot][dd][0])[s] = (unsigned char)win;
-                f.sim_path[((size_t)FW_G(u) * L + s) * BO_FW_PATH_CAP + dd] = leaf;  // (the path, level by level: read back by the next launch's backup)
+                f.sim_path[(size_t)FW_G(u) * L * BO_FW_PATH_CAP + FW_PIDX(L, s, dd)] = leaf;  // (the path, level by level: read back by the next launch's backup)
                 FW_ST(u, ST_LEVELS) += 1; FW_ST(u, ST_KIDS) += nk;
                 if (!(ROOTC && atroot)) FW_ST(u, ST_GRAN) += ngran;
             }
@@ -700,7 +704,7 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
                         }
                     }
                     if (c == 0) { FW_C(u, FWC_F(L, FWS_ROW, s)) = q; FW_C(u, FWC_F(L, FWS_PLEN, s)) = plen; FW_C(u, FWC_NSTEP) = s + 1; }
-                    if (more && c == 0) f.sim_path[((size_t)FW_G(u) * L + s + 1) * BO_FW_PATH_CAP] = 0;  // (the next descent's path starts at the root)
+                    if (more && c == 0) f.sim_path[(size_t)FW_G(u) * L * BO_FW_PATH_CAP + FW_PIDX(L, s + 1, 0)] = 0;  // (the next descent's path starts at the root)
                 }
                 bo_wave_sync();  // (the row / simulation lists in LDS)
             }
@@ -726,7 +730,7 @@ BO_DEV void fw_select_body(const Eng &e, const FastW &f, const float *value, int
                     const float v = q == FW_SIM_MATE ? 1.0f : 0.0f;
                     for (int k = c; k < plen; k += W) {
                         if (k == 0) continue;
-                        WRec *R = FW_A(u) + sp[(size_t)s * BO_FW_PATH_CAP + k];
+                        WRec *R = FW_A(u) + sp[FW_PIDX(L, s, k)];
                         const fw_nw y = fw_ld_nw(R);
                         fw_st_nw(R, y.n + 1, y.w + (((plen - 1 - k) & 1) ? -v : v));
                     }
@@ -863,12 +867,13 @@ BO_DEV void fw_select_lane_body(const Eng &e, const FastW &f, const float *value
                 }
                 maxlen = plen[s] > maxlen ? plen[s] : maxlen;
             }
-            // eight depths at a time: the record ids of all simulations (two 16-byte reads per path), then their (n, w), then the
-            // updates -- three round trips; simulations that share a record at a depth are chained in registers
+            // eight depths at a time: the record ids of all simulations (one 16-byte read per depth: the path rows are depth-major, LC = 4
+            // simulations side by side), then their (n, w), then the updates -- three round trips; simulations that share a record at a
+            // depth are chained in registers
             for (int k0 = 0; k0 < maxlen; k0 += 8) {
-                fw_v4 pa[LC], pb[LC];
+                fw_v4 pd[8];
                 BO_UNROLL
-                for (int s = 0; s < LC; s++) { pa[s] = fw_ld4(sp + s * BO_FW_PATH_CAP + k0); pb[s] = fw_ld4(sp + s * BO_FW_PATH_CAP + k0 + 4); }
+                for (int kk = 0; kk < 8; kk++) pd[kk] = fw_ld4(sp + FW_PIDX(LC, 0, k0 + kk));
                 int rec[8][LC];
                 bool vl[8][LC];
                 fw_nw x[8][LC];
@@ -877,7 +882,7 @@ BO_DEV void fw_select_lane_body(const Eng &e, const FastW &f, const float *value
                     BO_UNROLL
                     for (int s = 0; s < LC; s++) {
                         vl[kk][s] = k0 + kk >= 1 && k0 + kk < plen[s];  // the root (depth 0) only counts visits
-                        rec[kk][s] = vl[kk][s] ? (kk < 4 ? pa[s][kk & 3] : pb[s][kk & 3]) : 0;
+                        rec[kk][s] = vl[kk][s] ? pd[kk][s] : 0;
                     }
                 }
                 BO_UNROLL
@@ -1002,7 +1007,7 @@ BO_DEV void fw_select_lane_body(const Eng &e, const FastW &f, const float *value
                 if ((int)((iw >> 16) & 255u) != bi) M &= ~4u;
                 s_idx[d][lane] = (iw & ~(255u << (8 * s))) | ((unsigned)bi << (8 * s));
             }
-            sp[(size_t)s * BO_FW_PATH_CAP + d] = leaf;
+            sp[FW_PIDX(LC, s, d)] = leaf;
             levels++; grans += ngran;
             const int old_link = link;
             int nl = bl;
@@ -1032,7 +1037,7 @@ BO_DEV void fw_select_lane_body(const Eng &e, const FastW &f, const float *value
             if (n_step < nmax) {  // the game's next descent starts at the root
                 link = root_link; pn = root_n + n_step + 1; d = 1;
                 M = (1u << n_step) - 1u;
-                sp[(size_t)n_step * BO_FW_PATH_CAP] = 0;
+                sp[FW_PIDX(LC, n_step, 0)] = 0;
             } else {
                 busy = false;
             }
@@ -1044,7 +1049,7 @@ BO_DEV void fw_select_lane_body(const Eng &e, const FastW &f, const float *value
                 const int q = fw_pick(c_srow, s), plen = fw_pick(c_splen, s);
                 const float v = q == FW_SIM_MATE ? 1.0f : 0.0f;
                 for (int k = 1; k < plen; k++) {
-                    WRec *R = A + sp[(size_t)s * BO_FW_PATH_CAP + k];
+                    WRec *R = A + sp[FW_PIDX(LC, s, k)];
                     const fw_nw y = fw_ld_nw(R);
                     fw_st_nw(R, y.n + 1, y.w + (((plen - 1 - k) & 1) ? -v : v));
                 }
@@ -1139,14 +1144,14 @@ BO_KERNEL void bo_k_fw_leaf(Eng e, FastW f, float *nn_in) {
     bool chk;
     const int n = bo_movegen(P, sh.moves, &chk);
     const int s = ctl[FWC_F(L, FWR_SIM, r)];
-    const int *path = f.sim_path + ((size_t)g * L + s) * BO_FW_PATH_CAP;
+    const int *gpath = f.sim_path + (size_t)g * L * BO_FW_PATH_CAP;  // this game's block: (simulation s, depth k) at FW_PIDX(L, s, k)
     const int d = ctl[FWC_F(L, FWS_PLEN, s)] - 1;  // path[0..d], path[d] = this leaf
     const auto pos_of = [A](int ref) { return fw_head_at(A, ref)->pos; };  // chain refs >= 0: header granule of an ancestor's run
     const int t = terminal_eval_with(e, g, pos_of, P, sh.moves, n, chk, sh.moves2, sh.chain, [&]() {
         // ancestors path[k], k < d, are expanded: their positions head their runs.  Included while every move between
         // them and the leaf is reversible (python-chess pops back to the last irreversible move).
         for (int k = lane; k < d; k += 64) {
-            const int hg = fw_first(A[path[k]].link) - BO_FW_HG;
+            const int hg = fw_first(A[gpath[FW_PIDX(L, s, k)]].link) - BO_FW_HG;
             s_hg[k] = hg;
             s_flags[k] = fw_head_at(A, hg)->pos.flags;
         }
